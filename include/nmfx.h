@@ -1,0 +1,160 @@
+/*
+ * nmfx.h -- C ABI of libnmfx.so, the MI355X (gfx950) replacement for the NMF.jl
+ * iterative hot path.  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * This is what a Julia `ccall` (or any FFI) binds to keep NMF.jl's
+ *     NMF.solve!(alg, X, W, H) :: NMF.Result{T}
+ * call surface while the inner loops run as hand-written HIP on the GPU.
+ * The reference interface each entry point replaces is cited as
+ * /root/reference/<file>:<line>.  INTEGRATION.md shows the Julia-side binding.
+ *
+ * Conventions (same as Julia Matrix{T}): column-major, contiguous,
+ *   X is p x n (ld = p), W is p x k (ld = p), H is k x n (ld = k),
+ *   T is float (NMFX_F32) or double (NMFX_F64).
+ * Every function returns an nmfx_status; nmfx_last_error(ctx) gives the text.
+ * A context may be used by one host thread at a time; the library never calls
+ * back into the host language and keeps no global mutable state.
+ */
+#ifndef NMFX_H
+#define NMFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nmfx_ctx nmfx_ctx;
+
+/* element type T of X, W, H (the reference is generic over Float32/Float64) */
+enum { NMFX_F32 = 0, NMFX_F64 = 1 };
+
+/* algorithm selector = the `alg` structs accepted by NMF.solve!:
+ *   MultUpdate{T}(obj=:mse)  src/multupd.jl:9-52   (nnmf alg=:multmse, src/interf.jl:65-66)
+ *   MultUpdate{T}(obj=:div)  src/multupd.jl:9-52   (alg=:multdiv,  src/interf.jl:67-68)
+ *   ProjectedALS{T}          src/projals.jl:18-39  (alg=:projals,  src/interf.jl:61-62)
+ *   ALSPGrad{T}              src/alspgrad.jl:352-383 (alg=:alspgrad, src/interf.jl:63-64) */
+enum { NMFX_ALG_MULTMSE = 0, NMFX_ALG_MULTDIV = 1, NMFX_ALG_PROJALS = 2, NMFX_ALG_ALSPGRAD = 3 };
+
+/* status codes; the host shim maps them to the reference's exceptions:
+ *   BAD_ARG       -> ArgumentError       (src/multupd.jl:27-31, src/interf.jl:15-33)
+ *   DIM_MISMATCH  -> DimensionMismatch   (src/common.jl:12, :30)
+ *   NOT_POSDEF    -> PosDefException     (potrf! in src/utils.jl:68,78)
+ *   ALPHA_NONFINITE -> ErrorException("alpha is not finite") (src/alspgrad.jl:140,296) */
+typedef enum {
+    NMFX_OK = 0,
+    NMFX_ERR_BAD_ARG = 1,
+    NMFX_ERR_DIM_MISMATCH = 2,
+    NMFX_ERR_NOT_POSDEF = 3,
+    NMFX_ERR_ALPHA_NONFINITE = 4,
+    NMFX_ERR_HIP = 5,
+    NMFX_ERR_RCCL = 6,
+    NMFX_ERR_NO_DEVICE = 7,
+    NMFX_ERR_STATE = 8,
+    NMFX_ERR_UNSUPPORTED = 9
+} nmfx_status;
+
+/* Union of the reference option structs; every field is ALREADY RESOLVED by the
+ * caller (the Julia structs hold concrete values after construction):
+ *   MultUpdate   fields obj,maxiter,verbose,tol,update_H,lambda_w,lambda_h  src/multupd.jl:9-17
+ *   ProjectedALS fields maxiter,verbose,tol,update_H,lambda_w,lambda_h      src/projals.jl:18-24
+ *   ALSPGrad     fields maxiter,maxsubiter,tol,tolg,update_H,verbose        src/alspgrad.jl:352-358
+ * delta = sqrt(eps(T)) is what solve! passes to the MultUpd updaters (src/multupd.jl:48,50);
+ * traceiter/beta/sigma are the literals 20, 0.2, 0.01 of src/alspgrad.jl:407,417. */
+typedef struct {
+    int32_t maxiter;          /* outer iteration cap (nmf_skeleton!, src/common.jl:64) */
+    int32_t update_H;         /* 0: H is left bit-identical (test/interf.jl:33-37) */
+    int32_t track_objective;  /* 1: evaluate the objective at t=0 and after every iteration, like
+                                 verbose=true does (src/common.jl:56,79); fills objv_trace */
+    int32_t maxsubiter;       /* ALSPGrad.maxsubiter (200) */
+    int32_t traceiter;        /* back-tracking cap (20) */
+    int32_t check_every;      /* host polls the device-side stop flag every this many outer iterations
+                                 (>=1; results do not depend on it: iterations past the stop are no-ops) */
+    double tol;               /* stop_condition eps (src/common.jl:92-111) */
+    double lambda_w, lambda_h;
+    double delta;
+    double tolg;              /* initial ALSPGradUpd.tolg (decays *0.1, src/alspgrad.jl:409-421) */
+    double beta, sigma;
+} nmfx_opts;
+
+/* NMF.Result{T} minus the matrices (src/common.jl:21-27), plus measurement fields */
+typedef struct {
+    int64_t niters;           /* Result.niters */
+    int32_t converged;        /* Result.converged */
+    int32_t status;           /* nmfx_status of the solve (NOT_POSDEF / ALPHA_NONFINITE raised on device) */
+    double objvalue;          /* Result.objvalue, already rounded to T (src/common.jl:33) */
+    double seconds_loop;      /* device time of the iteration loop (hipEvent), excludes H2D/D2H */
+    int64_t inner_iters;      /* alspgrad: executed sub-solver iterations (H and W sides) */
+    int64_t backtracks;       /* alspgrad: executed back-tracking steps */
+    double final_tolg;        /* alspgrad: tolg after decay */
+} nmfx_result;
+
+/* ---- context ----------------------------------------------------------------
+ * One context = one GPU's share of one problem: the column shard X[:, c0:c0+n_local)
+ * with its H[:, c0:c0+n_local), and a full replica of W.  Single GPU: n_local = n.
+ * `device` is the HIP device ordinal.  Replaces the state objects built by
+ * prepare_state (src/multupd.jl:70-78,128-147; src/projals.jl:48-63;
+ * src/alspgrad.jl:385-396): all temporaries live on the device for the context's life. */
+int nmfx_create(nmfx_ctx **out, int dtype, int64_t p, int64_t n_local, int64_t k, int device);
+void nmfx_destroy(nmfx_ctx *ctx);
+const char *nmfx_last_error(const nmfx_ctx *ctx);     /* ctx may be NULL: last creation error */
+const char *nmfx_version(void);
+
+/* Upload X (host, column-major, leading dimension ldx >= p).  X is read-only
+ * for solve! (src/common.jl:45-47) and re-used across `replicates` (src/interf.jl:85-101),
+ * so it is uploaded once. */
+int nmfx_set_X(nmfx_ctx *ctx, const void *X_host, int64_t ldx);
+/* Same, but the source is already in device memory (bench / pipelines that keep X in HBM). */
+int nmfx_set_X_device(nmfx_ctx *ctx, const void *X_dev, int64_t ldx);
+
+/* Upload / download the factors (host, column-major, ldw = p, ldh = k). */
+int nmfx_set_factors(nmfx_ctx *ctx, const void *W_host, const void *H_host);
+int nmfx_get_factors(nmfx_ctx *ctx, void *W_host, void *H_host);
+
+/* Run the iteration loop on the resident X, W, H (nmf_skeleton!, src/common.jl:45-89).
+ * objv_trace: NULL or maxiter+1 doubles (entry t = objective after iteration t; entry 0 = initial). */
+int nmfx_iterate(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, nmfx_result *out, double *objv_trace);
+
+/* NMF.solve!(alg, X, W, H) (src/multupd.jl:45-52, src/projals.jl:37-39, src/alspgrad.jl:381-383):
+ * = nmfx_set_factors + nmfx_iterate + nmfx_get_factors; W and H are updated in place. */
+int nmfx_solve(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, void *W_host, void *H_host,
+               nmfx_result *out, double *objv_trace);
+
+/* Sub-solvers exported by the reference (src/alspgrad.jl:69-84, :225-240; test/alspgrad.jl:10-20):
+ * which = 0 -> alspgrad_updateh!(X, W, H) updates H; which = 1 -> alspgrad_updatew! updates W.
+ * Uses opts->maxsubiter as maxiter, opts->traceiter, tolg, beta, sigma.  out->niters = executed iterations. */
+int nmfx_alspgrad_subsolve(nmfx_ctx *ctx, int which, const nmfx_opts *opts, void *W_host, void *H_host,
+                           nmfx_result *out);
+
+/* ---- multi-GPU (column sharding, one process per GPU) -----------------------
+ * The reference has no distributed path; this is the build's data-parallel extension.
+ * Rank r owns columns [c0, c0+n_local) of X and H; W is replicated.  Per outer iteration
+ * ONE sum all-reduce (RCCL over xGMI) of the packed buffer [X_g H_g' | H_g H_g' | H row statistics].
+ * Usage: rank 0 calls nmfx_comm_get_unique_id, the host broadcasts the 128 bytes by any means,
+ * every rank calls nmfx_comm_init.  nranks == 1 is valid (exercises the RCCL path on one GPU). */
+#define NMFX_UNIQUE_ID_BYTES 128
+int nmfx_comm_get_unique_id(void *out_bytes /* NMFX_UNIQUE_ID_BYTES */);
+int nmfx_comm_init(nmfx_ctx *ctx, const void *unique_id_bytes, int rank, int nranks);
+
+/* ---- standalone passes of the hot path (measurement + parity of the HBM-bound pieces) ----
+ * Operate on the resident X, W, H; results are returned by value.
+ *   objective: 0.5*sqL2dist(X, W*H) (alg != MULTDIV) or gkldiv(X, W*H) (alg == MULTDIV)
+ *              evaluate_objv, src/multupd.jl:81,148; src/projals.jl:65-74; src/alspgrad.jl:398 */
+int nmfx_objective(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, double *out);
+
+/* Device/timing introspection used by bench.py (no reference counterpart). */
+typedef struct {
+    char name[64];
+    double ms_total;      /* summed hipEvent time on the solver stream */
+    int64_t launches;
+    double flops;         /* algorithmic flops summed over launches */
+    double bytes;         /* algorithmic HBM bytes summed over launches */
+} nmfx_kernel_stat;
+int nmfx_profile_enable(nmfx_ctx *ctx, int on);   /* brackets every launch with hipEvents (slow path) */
+int nmfx_profile_get(nmfx_ctx *ctx, nmfx_kernel_stat *out, int max_entries, int *n_entries);
+int nmfx_device_info(int device, char *name_out, int name_len, int *cu_count, int64_t *hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMFX_H */

@@ -1,0 +1,335 @@
+// gemm_mfma.hpp -- LDS-tiled MFMA GEMM for gfx950 with pluggable epilogues.
+//
+// Every GEMM of the NMF hot path goes through this one kernel template:
+//   W'X, W'W, (W'W)H           (src/multupd.jl:98-99, src/projals.jl:92-93, src/alspgrad.jl:63-67,124)
+//   XH', HH', W(HH')           (src/multupd.jl:109-110, src/projals.jl:100-101, src/alspgrad.jl:218-222,280)
+//   WH (never materialised; feeds the objective / ratio epilogues)
+//                              (src/multupd.jl:104,115,172-174; src/multupd.jl:81,148)
+//
+// The kernel computes  D(r, c) = sum_k A(r, k) * B(c, k)  for an R x C output whose
+// memory address is  c + r*ld  (c is the CONTIGUOUS index of the column-major Julia
+// matrix, r the strided one).  MFMA lanes run along c, so every epilogue load/store is a
+// 128-byte coalesced segment per 32 (f32) / 16 (f64) lanes.
+//
+// All operands are column-major Julia matrices, so an operand is either
+//   KCONTIG  : element (row, k) at base[row*ld + k]   (contraction index contiguous)
+//   KSTRIDED : element (row, k) at base[k*ld + row]   (row index contiguous)
+// Dimensions are pre-padded by the host (multiples of the block tile / BK) so the
+// main loop has no bounds checks; padding is zero and algebraically inert.
+//
+// f32 uses v_mfma_f32_32x32x2_f32 (exact f32), f64 uses v_mfma_f64_16x16x4_f64.
+// Within a k-group of 8 the lane's k-slot ks and step q map to k = 8g + VEC*ks + q for BOTH
+// operands, so one 16-byte LDS read feeds VEC consecutive MFMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nmfx {
+
+enum : int { KCONTIG = 0, KSTRIDED = 1 };
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f64x2 = __attribute__((ext_vector_type(2))) double;
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+    static constexpr int MT = 32, KS = 2, VEC = 4, NACC = 16, BK = 32;
+    using acc_t = f32x16;
+    using vec_t = f32x4;
+    // D = A(32 x 2) * B(2 x 32) + C ; lane l supplies A[l&31][l>>5] and B[l>>5][l&31]
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<double> {
+    static constexpr int MT = 16, KS = 4, VEC = 2, NACC = 4, BK = 16;
+    using acc_t = f64x4;
+    using vec_t = f64x2;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T> struct GemmArgs {
+    const T *A;             // rows <-> r (strided output index)
+    const T *B;             // rows <-> c (contiguous output index)
+    int64_t lda, ldb;
+    int tiles_r, tiles_c;   // grid of block tiles
+    int splits;             // split-K factor
+    int kchunk;             // contraction length handled by one split (multiple of BK)
+    int c_fastest;          // 1: consecutive blocks walk c-tiles first (they share the A tile)
+    const int *done;        // device stop flag: kernels of iterations past the stop are no-ops
+};
+
+// XOR swizzle of the 16-byte chunk position inside a KCONTIG LDS row (8 chunks/row):
+// conflict-free ds_read_b128 for 16 rows distinct mod 16 (MI355X LDS: 64 banks x 4 B).
+__device__ __forceinline__ int swz8(int row) { return (row >> 1) & 7; }
+
+template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
+    using M = Mfma<T>;
+    static constexpr int VEC = M::VEC, BK = M::BK;
+    static constexpr int CHUNKS = ROWS * BK / VEC;
+    static constexpr int PER_THREAD = CHUNKS / NTHREADS;
+    static_assert(CHUNKS % NTHREADS == 0, "tile chunks must divide evenly among threads");
+    using vec_t = typename M::vec_t;
+
+    // global -> registers
+    static __device__ __forceinline__ void load(vec_t (&r)[PER_THREAD], const T *base, int64_t ld,
+                                                int64_t row0, int64_t k0, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int s = tid + NTHREADS * i;
+            const T *p;
+            if constexpr (LAYOUT == KCONTIG) {
+                constexpr int CPR = BK / VEC;   // 8 chunks per row
+                const int row = s / CPR, cpos = s % CPR;
+                const int c = cpos ^ swz8(row);
+                p = base + (row0 + row) * ld + k0 + c * VEC;
+            } else {
+                constexpr int CPK = ROWS / VEC;
+                const int kk = s / CPK, r4 = s % CPK;
+                p = base + (k0 + kk) * ld + row0 + r4 * VEC;
+            }
+            r[i] = *reinterpret_cast<const vec_t *>(p);
+        }
+    }
+    // registers -> LDS (linear image: chunk s at byte 16*s)
+    static __device__ __forceinline__ void store(const vec_t (&r)[PER_THREAD], T *lds, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int s = tid + NTHREADS * i;
+            *reinterpret_cast<vec_t *>(lds + s * VEC) = r[i];
+        }
+    }
+};
+
+// Read the VEC operand values of k-group g for the MFMA row-tile starting at tile row rt.
+template <typename T, int LAYOUT, int ROWS>
+__device__ __forceinline__ void read_frag(T (&out)[Mfma<T>::VEC], const T *lds, int rt, int g, int lane) {
+    using M = Mfma<T>;
+    const int r = rt + (lane % M::MT);
+    const int ks = lane / M::MT;
+    if constexpr (LAYOUT == KCONTIG) {
+        const int c = (g * M::KS + ks) ^ swz8(r);
+        const typename M::vec_t v =
+            *reinterpret_cast<const typename M::vec_t *>(lds + (r * (M::BK / M::VEC) + c) * M::VEC);
+#pragma unroll
+        for (int q = 0; q < M::VEC; ++q) out[q] = v[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < M::VEC; ++q) out[q] = lds[(g * 8 + ks * M::VEC + q) * ROWS + r];
+    }
+}
+
+template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi>
+__global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g, Epi epi) {
+    using M = Mfma<T>;
+    constexpr int NT = WGR * WGC * 64;
+    constexpr int BK = M::BK, MT = M::MT;
+    constexpr int WTR = BR / WGR, WTC = BC / WGC;
+    constexpr int TR = WTR / MT, TC = WTC / MT;
+    static_assert(WTR % MT == 0 && WTC % MT == 0, "wave tile must be a multiple of the MFMA tile");
+    using LoadA = TileLoader<T, LA, BR, NT>;
+    using LoadB = TileLoader<T, LB, BC, NT>;
+
+    if (g.done != nullptr && *reinterpret_cast<const volatile int *>(g.done) != 0) return;
+
+    __shared__ __attribute__((aligned(16))) T smem[2 * (BR + BC) * BK];
+    constexpr int STAGE = (BR + BC) * BK;   // stage s: A tile at smem + s*STAGE, B tile right behind it
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WGC, wc = wave % WGC;
+
+    // block -> (tile_r, tile_c, split).  Blocks are dealt round-robin to the 8 XCDs (block b runs
+    // on XCD b % 8, each with a private L2), so re-index first: the blocks of one XCD get a
+    // contiguous range of logical ids and neighbours that share an operand tile share an L2.
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int tiles = g.tiles_r * g.tiles_c;
+    const int split = bid / tiles;
+    const int trem = bid % tiles;
+    int tr, tc;
+    if (g.c_fastest) { tc = trem % g.tiles_c; tr = trem / g.tiles_c; }
+    else             { tr = trem % g.tiles_r; tc = trem / g.tiles_r; }
+    const int64_t r0 = (int64_t)tr * BR, c0 = (int64_t)tc * BC;
+    const int64_t kbeg = (int64_t)split * g.kchunk;
+    const int nk = g.kchunk / BK;
+
+    typename M::acc_t acc[TR][TC];
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) acc[i][j][r] = (T)0;
+
+    typename M::vec_t ra[LoadA::PER_THREAD], rb[LoadB::PER_THREAD];
+    LoadA::load(ra, g.A, g.lda, r0, kbeg, tid);
+    LoadB::load(rb, g.B, g.ldb, c0, kbeg, tid);
+    LoadA::store(ra, smem, tid);
+    LoadB::store(rb, smem + BR * BK, tid);
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) {   // prefetch the next k-tile into registers; lands while the MFMAs run
+            LoadA::load(ra, g.A, g.lda, r0, kbeg + (int64_t)(t + 1) * BK, tid);
+            LoadB::load(rb, g.B, g.ldb, c0, kbeg + (int64_t)(t + 1) * BK, tid);
+        }
+        const T *a_s = smem + cur * STAGE, *b_s = a_s + BR * BK;
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            T af[TR][M::VEC], bf[TC][M::VEC];
+#pragma unroll
+            for (int i = 0; i < TR; ++i) read_frag<T, LA, BR>(af[i], a_s, wr * WTR + i * MT, kg, lane);
+#pragma unroll
+            for (int j = 0; j < TC; ++j) read_frag<T, LB, BC>(bf[j], b_s, wc * WTC + j * MT, kg, lane);
+#pragma unroll
+            for (int q = 0; q < M::VEC; ++q)
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) acc[i][j] = M::mma(af[i][q], bf[j][q], acc[i][j]);
+        }
+        if (t + 1 < nk) {
+            LoadA::store(ra, smem + (cur ^ 1) * STAGE, tid);
+            LoadB::store(rb, smem + (cur ^ 1) * STAGE + BR * BK, tid);
+        }
+        __syncthreads();
+    }
+
+    // Epilogue.  MFMA C/D layout: f32 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
+    // f64 16x16: col = lane&15, row = (lane>>4) + 4*reg.  col <-> c (contiguous), row <-> r.
+    epi.begin(split);
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            const int64_t c = c0 + wc * WTC + j * MT + (lane % MT);
+            const int64_t rbase = r0 + wr * WTR + i * MT;
+#pragma unroll
+            for (int reg = 0; reg < M::NACC; ++reg) {
+                int64_t r;
+                if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                else r = rbase + (lane >> 4) + 4 * reg;
+                epi.apply(r, c, acc[i][j][reg]);
+            }
+        }
+    epi.finish(reinterpret_cast<double *>(smem), tid, NT, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// Epilogues: apply(r, c, v) receives D(r, c); the element lives at  base[c + r*ld].
+// ---------------------------------------------------------------------------
+
+// C (or split-K slab `split`) = acc
+template <typename T> struct EpiStore {
+    T *C;
+    int64_t ld, slab_stride;
+    T *dst;
+    __device__ __forceinline__ void begin(int split) { dst = C + (int64_t)split * slab_stride; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) { dst[c + r * ld] = v; }
+    __device__ __forceinline__ void finish(double *, int, int, int) {}
+};
+
+// Multiplicative update (src/multupd.jl:101-103, 112-114):
+//   out = old * ( max(0, num - lambda) / (acc + delta) ),  acc = Gram-form denominator
+template <typename T> struct EpiMultUpdate {
+    const T *num;
+    const T *old;
+    T *out;
+    int64_t ld;
+    T lambda, delta;
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) {
+        const int64_t o = c + r * ld;
+        T t = num[o] - lambda;
+        t = (t > (T)0) ? t : ((t != t) ? t : (T)0);   // max(zero(T), t); NaN propagates like Julia's max
+        out[o] = old[o] * (t / (v + delta));
+    }
+    __device__ __forceinline__ void finish(double *, int, int, int) {}
+};
+
+// out = max(acc, 0)   (projectnn!, src/utils.jl:34-41; NaN passes through)
+template <typename T> struct EpiClampStore {
+    T *out;
+    int64_t ld;
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) { out[c + r * ld] = (v < (T)0) ? (T)0 : v; }
+    __device__ __forceinline__ void finish(double *, int, int, int) {}
+};
+
+// out = acc - sub   (projected-gradient G = Gram*Z - B, src/alspgrad.jl:124-127, 280-283)
+template <typename T> struct EpiSubStore {
+    const T *sub;
+    T *out;
+    int64_t ld;
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) {
+        const int64_t o = c + r * ld;
+        out[o] = v - sub[o];
+    }
+    __device__ __forceinline__ void finish(double *, int, int, int) {}
+};
+
+// Q = X ./ (acc + delta)   (src/multupd.jl:172-174, 184-186), acc = (W*H) tile kept in registers
+template <typename T> struct EpiRatio {
+    const T *X;
+    T *Q;
+    int64_t ld;
+    T delta;
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) {
+        const int64_t o = c + r * ld;
+        Q[o] = X[o] / (v + delta);
+    }
+    __device__ __forceinline__ void finish(double *, int, int, int) {}
+};
+
+// block-level sum of per-thread doubles in a fixed order -> *dst
+__device__ __forceinline__ void block_sum_store(double v, double *smem, int tid, int nthreads, double *dst) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();   // smem may alias a staging buffer: every wave is past its last LDS read here
+    if ((tid & 63) == 0) smem[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < nthreads / 64; ++w) s += smem[w];
+        *dst = s;
+    }
+}
+
+__device__ __forceinline__ float nmfx_log(float x) { return logf(x); }
+__device__ __forceinline__ double nmfx_log(double x) { return log(x); }
+
+// Objective partials without materialising WH (evaluate_objv):
+//   KL == 0: sum (x - acc)^2           term in T, sum in Float64 (StatsBase.sqL2dist; src/multupd.jl:81)
+//   KL == 1: sum x>0 ? x*log(x/acc) - x + acc : acc          (StatsBase.gkldiv;  src/multupd.jl:148)
+template <typename T, int KL> struct EpiObjective {
+    const T *X;
+    int64_t ld;
+    double *partial;   // one per block
+    double sum;
+    __device__ __forceinline__ void begin(int) { sum = 0.0; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) {
+        const T x = X[c + r * ld];
+        T t;
+        if constexpr (KL == 0) {
+            const T d = x - v;
+            t = d * d;
+        } else {
+            if (x > (T)0) t = x * nmfx_log(x / v) - x + v;
+            else t = v;
+        }
+        sum += (double)t;
+    }
+    __device__ __forceinline__ void finish(double *smem, int tid, int nthreads, int bid) {
+        block_sum_store(sum, smem, tid, nthreads, partial + bid);
+    }
+};
+
+}  // namespace nmfx

@@ -1,0 +1,248 @@
+// kernels.hpp -- the HBM-bound passes of the NMF hot path (everything that is not a GEMM):
+// split-K slab reduction, stop_condition statistics, convergence check, multdiv
+// scalings, objective finalisation.  All reductions use fixed summation orders
+// (no float atomics) so a solve is bit-reproducible run to run.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nmfx {
+
+// Device-resident loop control (replaces the host-side `converged`/`t` of nmf_skeleton!,
+// src/common.jl:62-64).  Kernels launched for iterations after `done` are no-ops.
+struct Ctrl {
+    int done;
+    int converged;
+    int status;          // nmfx_status raised on device (NOT_POSDEF, ALPHA_NONFINITE)
+    int pad;
+    long long niters;
+    long long inner_iters;
+    long long backtracks;
+    double tolg;         // ALSPGradUpd.tolg (mutable, src/alspgrad.jl:375-379)
+};
+
+#define NMFX_DONE_GUARD(done) \
+    if ((done) != nullptr && *reinterpret_cast<const volatile int *>(done) != 0) return
+
+// dst[i] = sum_s src[s*stride + i]  (s ascending: deterministic split-K combine)
+template <typename T>
+__global__ void reduce_slabs_kernel(T *dst, const T *src, int64_t count, int nslab, int64_t stride,
+                                    const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    T s = src[i];
+    for (int k = 1; k < nslab; ++k) s += src[(int64_t)k * stride + i];
+    dst[i] = s;
+}
+
+// A[i + i*ld] += a for i < m  (adddiag!, src/utils.jl:15-24)
+template <typename T>
+__global__ void adddiag_kernel(T *A, int64_t ld, int m, T a, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) A[i + (int64_t)i * ld] += a;
+}
+
+// stop_condition statistics for W (src/common.jl:95-99): per column j,
+//   dev = sum_i (W-preW)^2, sum = sum_i (W+preW)^2.   grid = (chunks, K); partial[(chunk*K + j)*2 + {0,1}]
+template <typename T>
+__global__ void col_stats_kernel(const T *Wn, const T *Wo, int64_t rows, int64_t ld, int K, double *partial,
+                                 const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ double sm[8];
+    const int j = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int64_t per = (rows + nchunks - 1) / nchunks;
+    const int64_t beg = chunk * per, end = (beg + per < rows) ? beg + per : rows;
+    double dev = 0.0, sum = 0.0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+        const T a = Wn[i + (int64_t)j * ld], b = Wo[i + (int64_t)j * ld];
+        const T d = a - b, s = a + b;
+        dev += (double)(T)(d * d);
+        sum += (double)(T)(s * s);
+    }
+    for (int off = 32; off > 0; off >>= 1) { dev += __shfl_down(dev, off, 64); sum += __shfl_down(sum, off, 64); }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[w] = dev; sm[4 + w] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double d = 0.0, s = 0.0;
+        for (int q = 0; q < nw; ++q) { d += sm[q]; s += sm[4 + q]; }
+        partial[((int64_t)chunk * K + j) * 2] = d;
+        partial[((int64_t)chunk * K + j) * 2 + 1] = s;
+    }
+}
+
+// stop_condition statistics for H (src/common.jl:100-104): per row j over the local columns.
+// grid = (chunks), block = 256 threads, thread <-> row (coalesced across rows).
+template <typename T>
+__global__ void row_stats_kernel(const T *Hn, const T *Ho, int64_t cols, int64_t ld, int K, double *partial,
+                                 const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int chunk = blockIdx.x, nchunks = gridDim.x;
+    const int64_t per = (cols + nchunks - 1) / nchunks;
+    const int64_t beg = chunk * per, end = (beg + per < cols) ? beg + per : cols;
+    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+        double dev = 0.0, sum = 0.0;
+        for (int64_t i = beg; i < end; ++i) {
+            const T a = Hn[j + i * ld], b = Ho[j + i * ld];
+            const T d = a - b, s = a + b;
+            dev += (double)(T)(d * d);
+            sum += (double)(T)(s * s);
+        }
+        partial[((int64_t)chunk * K + j) * 2] = dev;
+        partial[((int64_t)chunk * K + j) * 2 + 1] = sum;
+    }
+}
+
+// out[j*2 + {0,1}] = sum over chunks (ascending) of partial -- final per-component statistics
+__global__ void finalize_stats_kernel(const double *partial, int nchunks, int K, double *out, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * K) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * 2 * K + e];
+    out[e] = s;
+}
+
+// stop_condition decision (src/common.jl:105-110) + iteration bookkeeping.
+// wstat/hstat: [j*2] = dev, [j*2+1] = sum (hstat may be null when update_H is false).
+// The reference accumulates in T; the comparison is done in T on the rounded sums.
+template <typename T>
+__global__ void check_kernel(Ctrl *ctrl, const double *wstat, const double *hstat, int k, T tol, long long t) {
+    if (ctrl->done) return;
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const T dw = (T)wstat[2 * j], sw = (T)wstat[2 * j + 1];
+        bool b = sqrt(dw) > tol * sqrt(sw);
+        if (hstat != nullptr) {
+            const T dh = (T)hstat[2 * j], sh = (T)hstat[2 * j + 1];
+            b = b || (sqrt(dh) > tol * sqrt(sh));
+        }
+        if (b) atomicOr(&bad, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctrl->niters = t;
+        if (!bad) { ctrl->converged = 1; ctrl->done = 1; }
+    }
+}
+
+// objective finalisation (evaluate_objv): s = sum of block partials (ascending);
+//   mode 0: out = T(0.5*s + extra)   (src/multupd.jl:81, src/projals.jl:65-74, src/alspgrad.jl:398)
+//   mode 1: out = T(s)               (gkldiv, src/multupd.jl:148)
+// `extra` (nullable) holds already-scaled regularisation terms (projals).
+template <typename T>
+__global__ void finish_objective_kernel(const double *partial, int n, int mode, const double *extra, int nextra,
+                                        double *out, const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ double sm[4];
+    double v = 0.0;
+    // fixed order: thread-strided then lane tree then wave order
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sm[w];
+        double r = (mode == 0) ? 0.5 * s : s;
+        for (int e = 0; e < nextra; ++e) r += extra[e];
+        *out = (double)(T)r;   // Result{T} conversion (src/common.jl:33)
+    }
+}
+
+// generic strided "sum over one axis" used for multdiv's sW = sum(W, dims=1) and sH = sum(H, dims=2)
+// (src/multupd.jl:176,188) -- same two-stage shape as the stats kernels, one value per component.
+template <typename T>
+__global__ void col_sum_kernel(const T *W, int64_t rows, int64_t ld, int K, double *partial, const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ double sm[4];
+    const int j = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int64_t per = (rows + nchunks - 1) / nchunks;
+    const int64_t beg = chunk * per, end = (beg + per < rows) ? beg + per : rows;
+    double s = 0.0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) s += (double)W[i + (int64_t)j * ld];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sm[q];
+        partial[(int64_t)chunk * K + j] = t;
+    }
+}
+
+template <typename T>
+__global__ void row_sum_kernel(const T *H, int64_t cols, int64_t ld, int K, double *partial, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int chunk = blockIdx.x, nchunks = gridDim.x;
+    const int64_t per = (cols + nchunks - 1) / nchunks;
+    const int64_t beg = chunk * per, end = (beg + per < cols) ? beg + per : cols;
+    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+        double s = 0.0;
+        for (int64_t i = beg; i < end; ++i) s += (double)H[j + i * ld];
+        partial[(int64_t)chunk * K + j] = s;
+    }
+}
+
+// out[j] = T(sum over chunks of partial[chunk*K + j])
+template <typename T>
+__global__ void finalize_sum_kernel(const double *partial, int nchunks, int K, T *out, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= K) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * K + j];
+    out[j] = (T)s;
+}
+
+// multdiv scalings (src/multupd.jl:177-179, 189-191):
+//   along_contig = 1 (H, K x N): out[i + j*ld] = in * num / (s[i] + lambda)   (s indexed by the contiguous index)
+//   along_contig = 0 (W, P x K): out[i + j*ld] = in * num / (s[j] + lambda)
+template <typename T>
+__global__ void div_update_kernel(T *out, const T *in, const T *num, const T *s, int64_t rows, int64_t cols,
+                                  int64_t ld, T lambda, int along_contig, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = blockIdx.y;
+    if (i >= rows || j >= cols) return;
+    const int64_t o = i + j * ld;
+    const T d = (along_contig ? s[i] : s[j]) + lambda;
+    out[o] = in[o] * (num[o] / d);
+}
+
+// sum of squares in Float64 -> partial per block (projals objective ||W||^2, ||H||^2: src/projals.jl:67-72)
+template <typename T>
+__global__ void sumsq_kernel(const T *A, int64_t count, double *partial, const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const T a = A[i];
+        s += (double)(T)(a * a);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sm[q];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// extra[slot] = T(0.5*lambda) * T(sum partial)   (projals regulariser term, in T like the reference)
+template <typename T>
+__global__ void finish_sumsq_kernel(const double *partial, int n, T half_lambda, double *extra, int slot, const int *done) {
+    NMFX_DONE_GUARD(done);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    const T nrm = sqrt((T)s);           // abs2(norm(W)) with norm in T
+    extra[slot] = (double)(T)(half_lambda * (nrm * nrm));
+}
+
+}  // namespace nmfx

@@ -1,0 +1,165 @@
+// nmfx_api.hip -- extern "C" entry points of libnmfx.so (see include/nmfx.h).
+// Thin: argument checks, dtype dispatch, exception -> status translation.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+
+#include "solver_impl.hpp"
+#include "projals_impl.hpp"
+#include "alspgrad_impl.hpp"
+
+using namespace nmfx;
+
+struct nmfx_ctx {
+    SolverBase *impl = nullptr;
+    std::string err;
+};
+
+static std::string g_create_err;
+static std::mutex g_create_mu;
+
+template <typename F> static int guarded(nmfx_ctx *ctx, F &&f) {
+    std::string *err = ctx ? &ctx->err : &g_create_err;
+    try {
+        f();
+        err->clear();
+        return NMFX_OK;
+    } catch (const StatusError &e) {
+        *err = e.msg;
+        return e.status;
+    } catch (const HipError &e) {
+        *err = std::string("HIP error: ") + hipGetErrorString(e.e) + " at " + e.what + " (solver line " + std::to_string(e.line) + ")";
+        return NMFX_ERR_HIP;
+    } catch (const RcclError &e) {
+        *err = std::string("RCCL error: ") + ncclGetErrorString(e.e) + " at " + e.what;
+        return NMFX_ERR_RCCL;
+    } catch (const std::exception &e) {
+        *err = e.what();
+        return NMFX_ERR_STATE;
+    }
+}
+
+extern "C" {
+
+const char *nmfx_version(void) { return "nmfx 0.1 (gfx950, hand-written HIP/MFMA)"; }
+
+const char *nmfx_last_error(const nmfx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int nmfx_create(nmfx_ctx **out, int dtype, int64_t p, int64_t n_local, int64_t k, int device) {
+    std::lock_guard<std::mutex> lk(g_create_mu);
+    if (!out) { g_create_err = "out is NULL"; return NMFX_ERR_BAD_ARG; }
+    *out = nullptr;
+    if (dtype != NMFX_F32 && dtype != NMFX_F64) { g_create_err = "dtype must be NMFX_F32 or NMFX_F64"; return NMFX_ERR_BAD_ARG; }
+    if (p < 1 || n_local < 1 || k < 1) { g_create_err = "p, n, k must be positive"; return NMFX_ERR_DIM_MISMATCH; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_create_err = "no HIP device visible: libnmfx has no CPU fallback";
+        return NMFX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { g_create_err = "device ordinal out of range"; return NMFX_ERR_BAD_ARG; }
+    nmfx_ctx *c = new nmfx_ctx;
+    int st = guarded(nullptr, [&] {
+        if (dtype == NMFX_F32) c->impl = new Solver<float>(p, n_local, k, device);
+        else c->impl = new Solver<double>(p, n_local, k, device);
+    });
+    if (st != NMFX_OK) { delete c; return st; }
+    *out = c;
+    return NMFX_OK;
+}
+
+void nmfx_destroy(nmfx_ctx *ctx) {
+    if (!ctx) return;
+    delete ctx->impl;
+    delete ctx;
+}
+
+int nmfx_set_X(nmfx_ctx *ctx, const void *X_host, int64_t ldx) {
+    if (!ctx || !X_host) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->set_X(X_host, ldx, false); });
+}
+
+int nmfx_set_X_device(nmfx_ctx *ctx, const void *X_dev, int64_t ldx) {
+    if (!ctx || !X_dev) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->set_X(X_dev, ldx, true); });
+}
+
+int nmfx_set_factors(nmfx_ctx *ctx, const void *W_host, const void *H_host) {
+    if (!ctx || !W_host || !H_host) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->set_factors(W_host, H_host); });
+}
+
+int nmfx_get_factors(nmfx_ctx *ctx, void *W_host, void *H_host) {
+    if (!ctx) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->get_factors(W_host, H_host); });
+}
+
+int nmfx_iterate(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, nmfx_result *out, double *objv_trace) {
+    if (!ctx || !opts || !out) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->iterate(alg, *opts, out, objv_trace); });
+}
+
+int nmfx_solve(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, void *W_host, void *H_host, nmfx_result *out,
+               double *objv_trace) {
+    if (!ctx || !opts || !out || !W_host || !H_host) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        ctx->impl->set_factors(W_host, H_host);
+        ctx->impl->iterate(alg, *opts, out, objv_trace);
+        // update_H == 0: H must come back bit-identical (test/interf.jl:33-37) -> do not even copy it
+        ctx->impl->get_factors(W_host, opts->update_H ? H_host : nullptr);
+    });
+}
+
+int nmfx_alspgrad_subsolve(nmfx_ctx *ctx, int which, const nmfx_opts *opts, void *W_host, void *H_host,
+                           nmfx_result *out) {
+    if (!ctx || !opts || !out || !W_host || !H_host || (which != 0 && which != 1)) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        ctx->impl->set_factors(W_host, H_host);
+        ctx->impl->subsolve(which, *opts, out);
+        ctx->impl->get_factors(which == 1 ? W_host : nullptr, which == 0 ? H_host : nullptr);
+    });
+}
+
+int nmfx_comm_get_unique_id(void *out_bytes) {
+    if (!out_bytes) return NMFX_ERR_BAD_ARG;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return NMFX_ERR_RCCL;
+    std::memset(out_bytes, 0, NMFX_UNIQUE_ID_BYTES);
+    std::memcpy(out_bytes, &id, sizeof id);
+    return NMFX_OK;
+}
+
+int nmfx_comm_init(nmfx_ctx *ctx, const void *unique_id_bytes, int rank, int nranks) {
+    if (!ctx || !unique_id_bytes || nranks < 1 || rank < 0 || rank >= nranks) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->comm_init(unique_id_bytes, rank, nranks); });
+}
+
+int nmfx_objective(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, double *out) {
+    if (!ctx || !opts || !out) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { *out = ctx->impl->objective(alg, *opts); });
+}
+
+int nmfx_profile_enable(nmfx_ctx *ctx, int on) {
+    if (!ctx) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->profile_enable(on != 0); });
+}
+
+int nmfx_profile_get(nmfx_ctx *ctx, nmfx_kernel_stat *out, int max_entries, int *n_entries) {
+    if (!ctx || !out || !n_entries) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { *n_entries = ctx->impl->profile_get(out, max_entries); });
+}
+
+int nmfx_device_info(int device, char *name_out, int name_len, int *cu_count, int64_t *hbm_bytes) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return NMFX_ERR_NO_DEVICE;
+    if (name_out && name_len > 0) std::snprintf(name_out, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return NMFX_OK;
+}
+
+}  // extern "C"
+
+// explicit instantiation
+template class nmfx::Solver<float>;
+template class nmfx::Solver<double>;

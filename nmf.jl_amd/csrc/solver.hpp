@@ -1,0 +1,405 @@
+// solver.hpp -- device-resident NMF solver behind the C ABI (include/nmfx.h).
+//
+// One Solver<T> = one GPU's share of one problem (column shard of X and H, replica of W).
+// It replaces the reference's per-solve state objects and the nmf_skeleton! loop
+// (src/common.jl:45-89): the loop runs as a stream of kernel launches with a
+// device-side stop flag; the host polls that flag every `check_every` iterations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nmfx.h"
+#include "gemm_mfma.hpp"
+#include "kernels.hpp"
+
+namespace nmfx {
+
+struct HipError {
+    hipError_t e;
+    const char *what;
+    int line;
+};
+#define HIP_TRY(x)                                                  \
+    do {                                                            \
+        hipError_t _e = (x);                                        \
+        if (_e != hipSuccess) throw HipError{_e, #x, __LINE__};     \
+    } while (0)
+
+struct RcclError {
+    ncclResult_t e;
+    const char *what;
+    int line;
+};
+#define RCCL_TRY(x)                                                 \
+    do {                                                            \
+        ncclResult_t _e = (x);                                      \
+        if (_e != ncclSuccess) throw RcclError{_e, #x, __LINE__};   \
+    } while (0)
+
+struct StatusError {
+    int status;
+    std::string msg;
+};
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct SolverBase {
+    std::string err;
+    int dtype = 0;
+    virtual ~SolverBase() {}
+    virtual void set_X(const void *X, int64_t ldx, bool on_device) = 0;
+    virtual void set_factors(const void *W, const void *H) = 0;
+    virtual void get_factors(void *W, void *H) = 0;
+    virtual void iterate(int alg, const nmfx_opts &o, nmfx_result *out, double *trace) = 0;
+    virtual void subsolve(int which, const nmfx_opts &o, nmfx_result *out) = 0;
+    virtual void comm_init(const void *uid, int rank, int nranks) = 0;
+    virtual double objective(int alg, const nmfx_opts &o) = 0;
+    virtual void profile_enable(bool on) = 0;
+    virtual int profile_get(nmfx_kernel_stat *out, int max_entries) = 0;
+};
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    void alloc(size_t n) {
+        release();
+        count = n;
+        if (n == 0) return;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+        HIP_TRY(hipMemset(p, 0, n * sizeof(T)));
+    }
+    void ensure(size_t n) {
+        if (n > count) alloc(n);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+template <typename T> class Solver : public SolverBase {
+  public:
+    using M = Mfma<T>;
+    static constexpr int BK = M::BK;
+
+    Solver(int64_t p_, int64_t n_, int64_t k_, int device_) : p(p_), n(n_), k(k_), device(device_) {
+        dtype = sizeof(T) == 4 ? NMFX_F32 : NMFX_F64;
+        HIP_TRY(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        num_cu = prop.multiProcessorCount;
+        P = round_up(p, 256);
+        N = round_up(n, 256);
+        K = (k <= 64) ? 64 : round_up(k, 128);
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&ev_beg));
+        HIP_TRY(hipEventCreate(&ev_end));
+        X.alloc((size_t)P * N);
+        for (int i = 0; i < 2; ++i) { W[i].alloc((size_t)P * K); H[i].alloc((size_t)K * N); }
+        numH.alloc((size_t)K * N);
+        gramW.alloc((size_t)K * K);
+        // W-side numerator, Gram and multdiv's rowsum(H) live in ONE buffer: it is the packed
+        // all-reduce payload of the column-sharded path  [ X_g H_g' | H_g H_g' | rowsum(H_g) ]
+        pack.alloc((size_t)P * K + (size_t)K * K + (size_t)K);
+        numW_p = pack.p;
+        gramH_p = pack.p + (size_t)P * K;
+        sH_p = gramH_p + (size_t)K * K;
+        // split-K slabs: sized for the largest (splits x output) product any GEMM of the path can ask for
+        s_h = pick_splits((int)(N / 128) * (int)((K + 127) / 128), P);
+        s_w = pick_splits((int)(P / 128) * (int)((K + 127) / 128), N);
+        s_gw = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), P);
+        s_gh = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), N);
+        size_t slab_elems = std::max(std::max((size_t)s_h * K * N, (size_t)s_w * P * K),
+                                     std::max((size_t)s_gw * K * K, (size_t)s_gh * K * K));
+        slabs.alloc(slab_elems);
+        stat_chunks_w = (int)std::max<int64_t>(1, std::min<int64_t>(64, P / 1024));
+        stat_chunks_h = (int)std::max<int64_t>(1, std::min<int64_t>(256, N / 64));
+        stat_part.alloc((size_t)std::max(stat_chunks_w, stat_chunks_h) * 2 * K);
+        wstat.alloc((size_t)2 * K);
+        hstat.alloc((size_t)2 * K);
+        svec.alloc((size_t)K);
+        obj_part.alloc((size_t)(P / 128) * (N / 128) + 4096);
+        obj_extra.alloc(4);
+        obj_final.alloc(1);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
+        HIP_TRY(hipMemset(ctrl, 0, sizeof(Ctrl)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctrl_host), sizeof(Ctrl)));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+
+    ~Solver() override {
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(stream);
+        if (comm) (void)ncclCommDestroy(comm);
+        for (auto &e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (ctrl) (void)hipFree(ctrl);
+        if (ctrl_host) (void)hipHostFree(ctrl_host);
+        (void)hipEventDestroy(ev_beg);
+        (void)hipEventDestroy(ev_end);
+        (void)hipStreamDestroy(stream);
+    }
+
+    // ---------------------------------------------------------------- data movement
+    void set_X(const void *Xsrc, int64_t ldx, bool on_device) override {
+        if (ldx < p) throw StatusError{NMFX_ERR_DIM_MISMATCH, "ldx < p"};
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipMemsetAsync(X.p, 0, X.count * sizeof(T), stream));
+        HIP_TRY(hipMemcpy2DAsync(X.p, P * sizeof(T), Xsrc, ldx * sizeof(T), p * sizeof(T), n,
+                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        have_X = true;
+    }
+
+    void set_factors(const void *Wsrc, const void *Hsrc) override {
+        HIP_TRY(hipSetDevice(device));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipMemsetAsync(W[i].p, 0, W[i].count * sizeof(T), stream));
+            HIP_TRY(hipMemsetAsync(H[i].p, 0, H[i].count * sizeof(T), stream));
+        }
+        HIP_TRY(hipMemcpy2DAsync(W[0].p, P * sizeof(T), Wsrc, p * sizeof(T), p * sizeof(T), k, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpy2DAsync(H[0].p, K * sizeof(T), Hsrc, k * sizeof(T), k * sizeof(T), n, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        wcur = hcur = 0;
+        have_F = true;
+    }
+
+    void get_factors(void *Wdst, void *Hdst) override {
+        HIP_TRY(hipSetDevice(device));
+        if (Wdst) HIP_TRY(hipMemcpy2DAsync(Wdst, p * sizeof(T), W[wcur].p, P * sizeof(T), p * sizeof(T), k, hipMemcpyDeviceToHost, stream));
+        if (Hdst) HIP_TRY(hipMemcpy2DAsync(Hdst, k * sizeof(T), H[hcur].p, K * sizeof(T), k * sizeof(T), n, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+
+    void comm_init(const void *uid, int rank_, int nranks_) override {
+        HIP_TRY(hipSetDevice(device));
+        ncclUniqueId id;
+        static_assert(sizeof(ncclUniqueId) <= NMFX_UNIQUE_ID_BYTES, "unique id size");
+        std::memcpy(&id, uid, sizeof(id));
+        RCCL_TRY(ncclCommInitRank(&comm, nranks_, id, rank_));
+        rank = rank_;
+        nranks = nranks_;
+    }
+
+    void profile_enable(bool on) override {
+        profiling = on;
+        records.clear();
+        ev_used = 0;
+    }
+
+    int profile_get(nmfx_kernel_stat *out, int max_entries) override {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::map<std::string, nmfx_kernel_stat> agg;
+        std::vector<std::string> order;
+        for (auto &r : records) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ev_pool[r.ev].first, ev_pool[r.ev].second));
+            auto it = agg.find(r.name);
+            if (it == agg.end()) {
+                nmfx_kernel_stat s;
+                std::memset(&s, 0, sizeof s);
+                std::snprintf(s.name, sizeof s.name, "%s", r.name);
+                it = agg.emplace(r.name, s).first;
+                order.push_back(r.name);
+            }
+            it->second.ms_total += ms;
+            it->second.launches += 1;
+            it->second.flops += r.flops;
+            it->second.bytes += r.bytes;
+        }
+        int cnt = 0;
+        for (auto &nm : order) {
+            if (cnt >= max_entries) break;
+            out[cnt++] = agg[nm];
+        }
+        return cnt;
+    }
+
+    // ---------------------------------------------------------------- the loop
+    void iterate(int alg, const nmfx_opts &o, nmfx_result *out, double *trace) override;
+    void subsolve(int which, const nmfx_opts &o, nmfx_result *out) override;
+    double objective(int alg, const nmfx_opts &o) override {
+        require_ready();
+        HIP_TRY(hipSetDevice(device));
+        enqueue_objective(alg, o, obj_final.p, nullptr);
+        double v = 0.0;
+        HIP_TRY(hipMemcpyAsync(&v, obj_final.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return v;
+    }
+
+  private:
+    int64_t p, n, k, P, N, K;
+    int device, num_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_beg = nullptr, ev_end = nullptr;
+    DevBuf<T> X, Q, W[2], H[2], numH, gramW, slabs, svec, pack;
+    T *numW_p = nullptr, *gramH_p = nullptr, *sH_p = nullptr;
+    DevBuf<T> work[8];   // algorithm-specific scratch (projals factor/inverse, alspgrad G/Zn/Zp/D/GD)
+    DevBuf<double> stat_part, wstat, hstat, obj_part, obj_extra, obj_final, trace_dev;
+    Ctrl *ctrl = nullptr, *ctrl_host = nullptr;
+    int wcur = 0, hcur = 0;
+    int s_h = 1, s_w = 1, s_gw = 1, s_gh = 1;
+    int stat_chunks_w = 1, stat_chunks_h = 1;
+    bool have_X = false, have_F = false;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+
+    // profiling (hipEvent pair per launch, resolved lazily)
+    struct Rec { const char *name; int ev; double flops, bytes; };
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<Rec> records;
+    int ev_used = 0;
+
+    void require_ready() {
+        if (!have_X) throw StatusError{NMFX_ERR_STATE, "X has not been uploaded (nmfx_set_X)"};
+        if (!have_F) throw StatusError{NMFX_ERR_STATE, "W/H have not been uploaded (nmfx_set_factors)"};
+    }
+
+    int pick_splits(int tiles, int64_t kdim) const {
+        const int64_t nkt = kdim / BK;
+        int want = (2 * num_cu + tiles - 1) / tiles;
+        if (want > 64) want = 64;
+        int best = 1;
+        for (int d = 1; d <= want; ++d)
+            if (nkt % d == 0 && nkt / d >= 8) best = d;
+        return best;
+    }
+
+    template <typename F> void timed(const char *name, double flops, double bytes, F &&launch) {
+        if (!profiling) { launch(); return; }
+        if (ev_used == (int)ev_pool.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            ev_pool.emplace_back(a, b);
+        }
+        const int id = ev_used++;
+        HIP_TRY(hipEventRecord(ev_pool[id].first, stream));
+        launch();
+        HIP_TRY(hipEventRecord(ev_pool[id].second, stream));
+        records.push_back(Rec{name, id, flops, bytes});
+    }
+
+    template <int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi>
+    void launch_gemm_cfg(const GemmArgs<T> &g, const Epi &epi) {
+        const int blocks = g.tiles_r * g.tiles_c * g.splits;
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi>), dim3(blocks), dim3(WGR * WGC * 64), 0,
+                           stream, g, epi);
+        HIP_TRY(hipGetLastError());
+    }
+
+    // D(R x C) = sum_k A(r,k) B(c,k); R, C, Kdim are padded sizes.  Picks the block tile from R, C.
+    template <int LA, int LB, typename Epi>
+    void gemm(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim,
+              int splits, bool c_fastest, const Epi &epi, const int *done, double bytes = 0.0) {
+        GemmArgs<T> g;
+        g.A = A; g.B = B; g.lda = lda; g.ldb = ldb;
+        g.splits = splits;
+        g.kchunk = (int)(Kdim / splits);
+        g.c_fastest = c_fastest ? 1 : 0;
+        g.done = done;
+        const double flops = 2.0 * (double)R * (double)C * (double)Kdim;
+        timed(name, flops, bytes, [&] {
+            if (R % 128 == 0 && C % 128 == 0) {
+                g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 128);
+                launch_gemm_cfg<LA, LB, 128, 128, 2, 2>(g, epi);
+            } else if (C == 64 && R % 256 == 0) {
+                g.tiles_r = (int)(R / 256); g.tiles_c = 1;
+                launch_gemm_cfg<LA, LB, 256, 64, 4, 1>(g, epi);
+            } else if (R == 64 && C % 256 == 0) {
+                g.tiles_r = 1; g.tiles_c = (int)(C / 256);
+                launch_gemm_cfg<LA, LB, 64, 256, 1, 4>(g, epi);
+            } else if (R == 64 && C == 64) {
+                g.tiles_r = 1; g.tiles_c = 1;
+                launch_gemm_cfg<LA, LB, 64, 64, 2, 2>(g, epi);
+            } else {
+                throw StatusError{NMFX_ERR_UNSUPPORTED, "internal: no tile configuration for this GEMM shape"};
+            }
+        });
+    }
+
+    void reduce_slabs(const char *name, T *dst, int64_t count, int nslab, const int *done) {
+        timed(name, 0.0, (double)count * (nslab + 1) * sizeof(T), [&] {
+            const int bs = 256;
+            hipLaunchKernelGGL(reduce_slabs_kernel<T>, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, stream, dst,
+                               slabs.p, count, nslab, count, done);
+            HIP_TRY(hipGetLastError());
+        });
+    }
+
+    // ---- shared building blocks ------------------------------------------------
+    // numH = W' * Bmat   (K x N, ld K);  Bmat is X or Q (P x N).   src/multupd.jl:98,175; projals.jl:93
+    void wt_times(const T *Wp, const T *Bmat, T *dst, const int *done) {
+        EpiStore<T> e{slabs.p, K, (int64_t)K * N, nullptr};
+        gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
+                               (double)(P * N + P * K) * sizeof(T));
+        reduce_slabs("reduce_WtX", dst, (int64_t)K * N, s_h, done);
+    }
+    // gramW = W'W  (K x K).   src/projals.jl:92, src/alspgrad.jl:65
+    void gram_w(const T *Wp, const int *done) {
+        EpiStore<T> e{slabs.p, K, (int64_t)K * K, nullptr};
+        gemm<KCONTIG, KCONTIG>("gemm_WtW", Wp, P, K, Wp, P, K, P, s_gw, true, e, done, (double)(P * K) * sizeof(T));
+        reduce_slabs("reduce_WtW", gramW.p, (int64_t)K * K, s_gw, done);
+    }
+    // numW = Amat * H'  (P x K, ld P);  Amat is X or Q.   src/multupd.jl:109,187; projals.jl:101
+    void times_ht(const T *Amat, const T *Hp, T *dst, const int *done) {
+        EpiStore<T> e{slabs.p, P, (int64_t)P * K, nullptr};
+        gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
+                                 (double)(P * N + K * N) * sizeof(T));
+        reduce_slabs("reduce_XHt", dst, (int64_t)P * K, s_w, done);
+    }
+    // gramH = HH'  (K x K).   src/projals.jl:100, src/alspgrad.jl:220
+    void gram_h(const T *Hp, T *dst, const int *done) {
+        EpiStore<T> e{slabs.p, K, (int64_t)K * K, nullptr};
+        gemm<KSTRIDED, KSTRIDED>("gemm_HHt", Hp, K, K, Hp, K, K, N, s_gh, true, e, done, (double)(K * N) * sizeof(T));
+        reduce_slabs("reduce_HHt", dst, (int64_t)K * K, s_gh, done);
+    }
+
+    void stats_w(const T *Wn, const T *Wo, const int *done) {
+        timed("stats_W", 0.0, 2.0 * P * K * sizeof(T), [&] {
+            hipLaunchKernelGGL(col_stats_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wn, Wo, P, P,
+                               (int)K, stat_part.p, done);
+            hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)((2 * K + 255) / 256)), dim3(256), 0, stream,
+                               stat_part.p, stat_chunks_w, (int)K, wstat.p, done);
+            HIP_TRY(hipGetLastError());
+        });
+    }
+    void stats_h(const T *Hn, const T *Ho, const int *done) {
+        timed("stats_H", 0.0, 2.0 * K * N * sizeof(T), [&] {
+            hipLaunchKernelGGL(row_stats_kernel<T>, dim3(stat_chunks_h), dim3(256), 0, stream, Hn, Ho, N, K, (int)K,
+                               stat_part.p, done);
+            hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)((2 * K + 255) / 256)), dim3(256), 0, stream,
+                               stat_part.p, stat_chunks_h, (int)K, hstat.p, done);
+            HIP_TRY(hipGetLastError());
+        });
+    }
+
+    // One all-reduce per outer iteration (multi-GPU): numW, gramH and the H statistics.
+    void allreduce_w_side(bool with_hstat, const int *done);
+
+    void enqueue_objective(int alg, const nmfx_opts &o, double *dst, const int *done);
+    void enqueue_multmse(const nmfx_opts &o, long long t);
+    void enqueue_multdiv(const nmfx_opts &o, long long t);
+    void enqueue_projals(const nmfx_opts &o, long long t);
+    void enqueue_check(const nmfx_opts &o, long long t) {
+        hipLaunchKernelGGL(check_kernel<T>, dim3(1), dim3(256), 0, stream, ctrl, wstat.p,
+                           o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t);
+        HIP_TRY(hipGetLastError());
+    }
+    const int *done_flag() const { return &ctrl->done; }
+
+    void run_alspgrad(const nmfx_opts &o, nmfx_result *out, double *trace);
+};
+
+}  // namespace nmfx

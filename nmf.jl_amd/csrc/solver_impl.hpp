@@ -1,0 +1,234 @@
+// solver_impl.hpp -- the per-algorithm kernel sequences and the iteration loop.
+#pragma once
+#include "solver.hpp"
+
+namespace nmfx {
+
+// ---------------------------------------------------------------------------
+// objective without materialising WH:  D(r=j, c=i) = sum_a H(a,j) W(i,a), fused with the
+// reduction over (X - WH)^2 or the KL term.   evaluate_objv: src/multupd.jl:81,148;
+// src/projals.jl:65-74; src/alspgrad.jl:398
+// ---------------------------------------------------------------------------
+template <typename T>
+void Solver<T>::enqueue_objective(int alg, const nmfx_opts &o, double *dst, const int *done) {
+    const T *Wp = W[wcur].p, *Hp = H[hcur].p;
+    const int nblk = (int)((P / 128) * (N / 128));
+    const double bytes = (double)(P * N) * sizeof(T);
+    if (alg == NMFX_ALG_MULTDIV) {
+        EpiObjective<T, 1> e{X.p, P, obj_part.p, 0.0};
+        gemm<KCONTIG, KSTRIDED>("gemm_WH_kldiv", Hp, K, N, Wp, P, P, K, 1, true, e, done, bytes);
+    } else {
+        EpiObjective<T, 0> e{X.p, P, obj_part.p, 0.0};
+        gemm<KCONTIG, KSTRIDED>("gemm_WH_sqdist", Hp, K, N, Wp, P, P, K, 1, true, e, done, bytes);
+    }
+    int nextra = 0;
+    if (alg == NMFX_ALG_PROJALS) {   // + 0.5*lambda_w*||W||^2 + 0.5*lambda_h*||H||^2   (projals.jl:67-72)
+        const int nb = 1024;
+        if (o.lambda_w > 0) {
+            hipLaunchKernelGGL(sumsq_kernel<T>, dim3(nb), dim3(256), 0, stream, Wp, (int64_t)P * K, obj_part.p + nblk, done);
+            hipLaunchKernelGGL(finish_sumsq_kernel<T>, dim3(1), dim3(64), 0, stream, obj_part.p + nblk, nb,
+                               (T)((T)0.5 * (T)o.lambda_w), obj_extra.p, nextra, done);
+            ++nextra;
+        }
+        if (o.lambda_h > 0) {
+            hipLaunchKernelGGL(sumsq_kernel<T>, dim3(nb), dim3(256), 0, stream, Hp, (int64_t)K * N, obj_part.p + nblk + nb, done);
+            hipLaunchKernelGGL(finish_sumsq_kernel<T>, dim3(1), dim3(64), 0, stream, obj_part.p + nblk + nb, nb,
+                               (T)((T)0.5 * (T)o.lambda_h), obj_extra.p, nextra, done);
+            ++nextra;
+        }
+    }
+    if (nranks > 1) {
+        // the data term is a sum over column shards; regularisers: ||W||^2 is replicated, ||H||^2 is sharded.
+        // Reduce the per-block partials to one value first, all-reduce it, then finish.
+        hipLaunchKernelGGL(finish_objective_kernel<double>, dim3(1), dim3(256), 0, stream, obj_part.p, nblk, 1,
+                           (const double *)nullptr, 0, obj_part.p, done);
+        RCCL_TRY(ncclAllReduce(obj_part.p, obj_part.p, 1, ncclDouble, ncclSum, comm, stream));
+        if (alg == NMFX_ALG_PROJALS && o.lambda_h > 0) {
+            // sharded ||H||^2 term: sum the already-scaled shard terms (norm in T per shard; documented deviation)
+            const int slot = (o.lambda_w > 0) ? 1 : 0;
+            RCCL_TRY(ncclAllReduce(obj_extra.p + slot, obj_extra.p + slot, 1, ncclDouble, ncclSum, comm, stream));
+        }
+        hipLaunchKernelGGL(finish_objective_kernel<T>, dim3(1), dim3(256), 0, stream, obj_part.p, 1,
+                           alg == NMFX_ALG_MULTDIV ? 1 : 0, obj_extra.p, nextra, dst, done);
+    } else {
+        hipLaunchKernelGGL(finish_objective_kernel<T>, dim3(1), dim3(256), 0, stream, obj_part.p, nblk,
+                           alg == NMFX_ALG_MULTDIV ? 1 : 0, obj_extra.p, nextra, dst, done);
+    }
+    HIP_TRY(hipGetLastError());
+}
+
+template <typename T> void Solver<T>::allreduce_w_side(bool with_hstat, const int *done) {
+    (void)done;
+    if (nranks <= 1) return;
+    timed("allreduce_pack", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
+        RCCL_TRY(ncclGroupStart());
+        RCCL_TRY(ncclAllReduce(pack.p, pack.p, pack.count,
+                               sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, comm, stream));
+        if (with_hstat) RCCL_TRY(ncclAllReduce(hstat.p, hstat.p, (size_t)2 * K, ncclDouble, ncclSum, comm, stream));
+        RCCL_TRY(ncclGroupEnd());
+    });
+}
+
+// ---------------------------------------------------------------------------
+// MultUpdate, MSE objective.  update_wh!(::MultUpdMSE), src/multupd.jl:83-116, in Gram form:
+//   H <- H .* max(0, W'X - lh) ./ ((W'W) H + delta)      [reference: W'(WH)]
+//   W <- W .* max(0, XH' - lw) ./ (W (HH') + delta)      [reference: (WH)H']
+// ---------------------------------------------------------------------------
+template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long long t) {
+    (void)t;
+    const int *done = done_flag();
+    if (o.update_H) {
+        const T *Wp = W[wcur].p;
+        const T *Ho = H[hcur].p;
+        T *Hn = H[hcur ^ 1].p;
+        wt_times(Wp, X.p, numH.p, done);                                   // :98
+        gram_w(Wp, done);
+        EpiMultUpdate<T> e{numH.p, Ho, Hn, K, (T)o.lambda_h, (T)o.delta};  // :99-103
+        gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW.p, K, K, K, 1, true, e, done, 3.0 * K * N * sizeof(T));
+        stats_h(Hn, Ho, done);
+        hcur ^= 1;
+    }
+    const T *Hp = H[hcur].p;
+    const T *Wo = W[wcur].p;
+    T *Wn = W[wcur ^ 1].p;
+    times_ht(X.p, Hp, numW_p, done);                                       // :109
+    gram_h(Hp, gramH_p, done);
+    allreduce_w_side(o.update_H != 0, done);
+    EpiMultUpdate<T> e{numW_p, Wo, Wn, P, (T)o.lambda_w, (T)o.delta};      // :110-114
+    gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo, P, P, K, 1, false, e, done, 3.0 * P * K * sizeof(T));
+    stats_w(Wn, Wo, done);
+    wcur ^= 1;
+}
+
+// ---------------------------------------------------------------------------
+// MultUpdate, divergence objective.  update_wh!(::MultUpdDiv), src/multupd.jl:150-193.
+// Q = X ./ (WH + delta) is produced by the W*H GEMM's epilogue (WH itself never hits HBM).
+// ---------------------------------------------------------------------------
+template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long long t) {
+    (void)t;
+    const int *done = done_flag();
+    Q.ensure((size_t)P * N);
+    const double qbytes = 2.0 * P * N * sizeof(T);
+    if (o.update_H) {
+        const T *Wp = W[wcur].p;
+        const T *Ho = H[hcur].p;
+        T *Hn = H[hcur ^ 1].p;
+        EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                           // :172-174
+        gemm<KCONTIG, KSTRIDED>("gemm_WH_ratio", Ho, K, N, Wp, P, P, K, 1, true, er, done, qbytes);
+        wt_times(Wp, Q.p, numH.p, done);                                   // :175
+        timed("colsum_W", 0.0, (double)P * K * sizeof(T), [&] {            // :176
+            hipLaunchKernelGGL(col_sum_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wp, P, P, (int)K,
+                               stat_part.p, done);
+            hipLaunchKernelGGL(finalize_sum_kernel<T>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, stream, stat_part.p,
+                               stat_chunks_w, (int)K, svec.p, done);
+        });
+        timed("div_update_H", 0.0, 3.0 * K * N * sizeof(T), [&] {           // :177-179
+            hipLaunchKernelGGL(div_update_kernel<T>, dim3((unsigned)((K + 255) / 256), (unsigned)N), dim3(256), 0, stream, Hn,
+                               Ho, numH.p, svec.p, K, N, K, (T)o.lambda_h, 1, done);
+        });
+        stats_h(Hn, Ho, done);
+        hcur ^= 1;
+    }
+    const T *Hp = H[hcur].p;
+    const T *Wo = W[wcur].p;
+    T *Wn = W[wcur ^ 1].p;
+    EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                               // :184-186
+    gemm<KCONTIG, KSTRIDED>("gemm_WH_ratio", Hp, K, N, Wo, P, P, K, 1, true, er, done, qbytes);
+    times_ht(Q.p, Hp, numW_p, done);                                       // :187
+    T *sH = sH_p;                                                          // tail of the packed buffer
+    timed("rowsum_H", 0.0, (double)K * N * sizeof(T), [&] {                // :188
+        hipLaunchKernelGGL(row_sum_kernel<T>, dim3(stat_chunks_h), dim3(256), 0, stream, Hp, N, K, (int)K, stat_part.p, done);
+        hipLaunchKernelGGL(finalize_sum_kernel<T>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, stream, stat_part.p,
+                           stat_chunks_h, (int)K, sH, done);
+    });
+    allreduce_w_side(o.update_H != 0, done);
+    timed("div_update_W", 0.0, 3.0 * P * K * sizeof(T), [&] {               // :189-191
+        hipLaunchKernelGGL(div_update_kernel<T>, dim3((unsigned)((P + 255) / 256), (unsigned)K), dim3(256), 0, stream, Wn, Wo,
+                           numW_p, sH, P, K, P, (T)o.lambda_w, 0, done);
+    });
+    HIP_TRY(hipGetLastError());
+    stats_w(Wn, Wo, done);
+    wcur ^= 1;
+}
+
+// ---------------------------------------------------------------------------
+// nmf_skeleton! (src/common.jl:45-89)
+// ---------------------------------------------------------------------------
+template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_result *out, double *trace) {
+    require_ready();
+    if (o.maxiter < 1) throw StatusError{NMFX_ERR_BAD_ARG, "maxiter must be >= 1"};
+    if (!(o.tol > 0)) throw StatusError{NMFX_ERR_BAD_ARG, "tol must be positive."};
+    if (alg == NMFX_ALG_MULTMSE || alg == NMFX_ALG_MULTDIV) {
+        if (!(o.lambda_w >= 0)) throw StatusError{NMFX_ERR_BAD_ARG, "lambda_w must be non-negative."};
+        if (!(o.lambda_h >= 0)) throw StatusError{NMFX_ERR_BAD_ARG, "lambda_h must be non-negative."};
+    }
+    if (alg < 0 || alg > 3) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid algorithm."};
+    HIP_TRY(hipSetDevice(device));
+    std::memset(out, 0, sizeof *out);
+    if (alg == NMFX_ALG_ALSPGRAD) { run_alspgrad(o, out, trace); return; }
+
+    const int check_every = o.check_every > 0 ? o.check_every : 4;
+    const bool track = o.track_objective != 0;
+    Ctrl init;
+    std::memset(&init, 0, sizeof init);
+    init.tolg = o.tolg;
+    HIP_TRY(hipMemcpyAsync(ctrl, &init, sizeof init, hipMemcpyHostToDevice, stream));
+    if (track) {
+        trace_dev.ensure((size_t)o.maxiter + 1);
+        std::vector<double> nanv((size_t)o.maxiter + 1, std::nan(""));
+        HIP_TRY(hipMemcpyAsync(trace_dev.p, nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    const int w0 = wcur, h0 = hcur;
+    HIP_TRY(hipEventRecord(ev_beg, stream));
+    if (track) enqueue_objective(alg, o, trace_dev.p, done_flag());        // common.jl:56
+    long long t = 0;
+    while (t < o.maxiter) {
+        ++t;
+        switch (alg) {
+            case NMFX_ALG_MULTMSE: enqueue_multmse(o, t); break;
+            case NMFX_ALG_MULTDIV: enqueue_multdiv(o, t); break;
+            case NMFX_ALG_PROJALS: enqueue_projals(o, t); break;
+        }
+        enqueue_check(o, t);                                               // common.jl:73
+        if (track) enqueue_objective(alg, o, trace_dev.p + t, done_flag());   // common.jl:79
+        if (t % check_every == 0 || t == o.maxiter) {
+            HIP_TRY(hipMemcpyAsync(ctrl_host, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (ctrl_host->done || ctrl_host->status != 0) break;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(ctrl_host, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const long long niters = ctrl_host->niters;
+    // iterations enqueued after the stop were no-ops: the live buffers are those of iteration `niters`
+    wcur = (int)((w0 + niters) & 1);
+    hcur = o.update_H ? (int)((h0 + niters) & 1) : h0;
+    if (ctrl_host->status == 0) {
+        if (!track) enqueue_objective(alg, o, obj_final.p, nullptr);       // common.jl:85-87
+    }
+    HIP_TRY(hipEventRecord(ev_end, stream));
+    double objv = std::nan("");
+    if (ctrl_host->status == 0) {
+        if (track) {
+            HIP_TRY(hipMemcpyAsync(&objv, trace_dev.p + niters, sizeof(double), hipMemcpyDeviceToHost, stream));
+            if (trace) HIP_TRY(hipMemcpyAsync(trace, trace_dev.p, ((size_t)o.maxiter + 1) * sizeof(double), hipMemcpyDeviceToHost, stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(&objv, obj_final.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev_beg, ev_end));
+    out->niters = niters;
+    out->converged = ctrl_host->converged;
+    out->status = ctrl_host->status;
+    out->objvalue = objv;
+    out->seconds_loop = ms * 1e-3;
+    out->inner_iters = ctrl_host->inner_iters;
+    out->backtracks = ctrl_host->backtracks;
+    out->final_tolg = ctrl_host->tolg;
+    if (ctrl_host->status == NMFX_ERR_NOT_POSDEF) throw StatusError{NMFX_ERR_NOT_POSDEF, "matrix is not positive definite (potrf)"};
+}
+
+}  // namespace nmfx

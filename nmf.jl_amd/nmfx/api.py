@@ -1,0 +1,412 @@
+"""Host-side mirror of the NMF.jl operator interface for the accelerated path.
+
+Same names, argument meaning and error behaviour as the reference so the parity
+tests read like the reference's own tests:
+
+    nnmf(X, k; init, alg, maxiter, tol, replicates, W0, H0, update_H, verbose)   src/interf.jl:3-83
+    solve(alg, X, W, H) -> Result        NMF.solve!             src/multupd.jl:45, projals.jl:37, alspgrad.jl:381
+    MultUpdate / ProjectedALS / ALSPGrad option structs         src/multupd.jl:9-42, projals.jl:18-34, alspgrad.jl:352-373
+    Result(W, H, niters, converged, objvalue)                   src/common.jl:21-38
+    alspgrad_updateh / alspgrad_updatew                         src/alspgrad.jl:69-84, 225-240
+
+In production the host stays in Julia (nmf.jl_amd/julia/NMFX.jl does the same over
+`ccall`); this Python twin exists because the build image has no Julia.  All numeric
+work happens in libnmfx.so on the GPU -- this module only validates, marshals and
+maps status codes to the reference's exception types.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import warnings
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+
+# ---- the reference's exception vocabulary -------------------------------------------------
+class ArgumentError(ValueError):
+    """Julia ArgumentError (src/interf.jl:15-33, src/multupd.jl:27-31)."""
+
+
+class DimensionMismatch(ValueError):
+    """Julia DimensionMismatch (src/common.jl:12,30)."""
+
+
+class PosDefException(np.linalg.LinAlgError):
+    """LinearAlgebra.PosDefException raised by potrf! (src/utils.jl:68,78)."""
+
+
+class NMFXError(RuntimeError):
+    """HIP / RCCL / state errors of the library itself."""
+
+
+def _raise(status: int, msg: str):
+    if status == L.ERR_BAD_ARG:
+        raise ArgumentError(msg)
+    if status == L.ERR_DIM_MISMATCH:
+        raise DimensionMismatch(msg)
+    if status == L.ERR_NOT_POSDEF:
+        raise PosDefException(msg)
+    if status == L.ERR_ALPHA_NONFINITE:
+        raise RuntimeError("α is not finite")          # error("α is not finite"), src/alspgrad.jl:140
+    raise NMFXError(f"nmfx status {status}: {msg}")
+
+
+def _eps(T):
+    return float(np.finfo(T).eps)
+
+
+# ---- option structs --------------------------------------------------------------------
+class MultUpdate:
+    """MultUpdate{T}(; obj, maxiter, verbose, tol, update_H, lambda_w, lambda_h)  (src/multupd.jl:9-42)."""
+
+    def __init__(self, T, obj="mse", maxiter=100, verbose=False, tol=None, update_H=True,
+                 lambda_w=0.0, lambda_h=0.0, lambda_=None):
+        T = np.dtype(T).type
+        tol = float(T(np.cbrt(_eps(T)))) if tol is None else tol
+        if obj not in ("mse", "div"):
+            raise ArgumentError("Invalid value for obj.")
+        if not maxiter > 1:
+            raise ArgumentError("maxiter must be greater than 1.")
+        if not tol > 0:
+            raise ArgumentError("tol must be positive.")
+        if not lambda_w >= 0:
+            raise ArgumentError("lambda_w must be non-negative.")
+        if not lambda_h >= 0:
+            raise ArgumentError("lambda_h must be non-negative.")
+        if lambda_ is not None and lambda_ >= 0:
+            warnings.warn("lambda is deprecated, use lambda_w and lambda_h instead.")
+            lambda_w = lambda_ if lambda_w == 0 else lambda_w
+            lambda_h = lambda_ if lambda_h == 0 else lambda_h
+        if obj == "div":
+            lambda_w = max(lambda_w, math.sqrt(_eps(T)))
+            lambda_h = max(lambda_h, math.sqrt(_eps(T)))
+        self.T, self.obj, self.maxiter, self.verbose = T, obj, int(maxiter), bool(verbose)
+        self.tol, self.update_H = float(T(tol)), bool(update_H)
+        self.lambda_w, self.lambda_h = float(T(lambda_w)), float(T(lambda_h))
+
+    def _alg(self):
+        return L.ALG_MULTMSE if self.obj == "mse" else L.ALG_MULTDIV
+
+    def _opts(self):
+        return dict(maxiter=self.maxiter, tol=self.tol, update_H=self.update_H, lambda_w=self.lambda_w,
+                    lambda_h=self.lambda_h, delta=float(self.T(math.sqrt(_eps(self.T)))))   # src/multupd.jl:48,50
+
+
+class ProjectedALS:
+    """ProjectedALS{T}(; maxiter, verbose, tol, update_H, lambda_w, lambda_h)  (src/projals.jl:18-34); no validation."""
+
+    def __init__(self, T, maxiter=100, verbose=False, tol=None, update_H=True, lambda_w=None, lambda_h=None):
+        T = np.dtype(T).type
+        d = float(T(np.cbrt(_eps(T))))
+        self.T, self.maxiter, self.verbose = T, int(maxiter), bool(verbose)
+        self.tol = float(T(d if tol is None else tol))
+        self.update_H = bool(update_H)
+        self.lambda_w = float(T(d if lambda_w is None else lambda_w))
+        self.lambda_h = float(T(d if lambda_h is None else lambda_h))
+
+    def _alg(self):
+        return L.ALG_PROJALS
+
+    def _opts(self):
+        return dict(maxiter=self.maxiter, tol=self.tol, update_H=self.update_H, lambda_w=self.lambda_w,
+                    lambda_h=self.lambda_h)
+
+
+class ALSPGrad:
+    """ALSPGrad{T}(; maxiter, maxsubiter, tol, tolg, update_H, verbose)  (src/alspgrad.jl:352-373)."""
+
+    def __init__(self, T, maxiter=100, maxsubiter=200, tol=None, tolg=None, update_H=True, verbose=False):
+        T = np.dtype(T).type
+        self.T, self.maxiter, self.maxsubiter = T, int(maxiter), int(maxsubiter)
+        self.tol = float(T(np.cbrt(_eps(T)) if tol is None else tol))
+        self.tolg = float(T(_eps(T) ** 0.25 if tolg is None else tolg))
+        self.update_H, self.verbose = bool(update_H), bool(verbose)
+
+    def _alg(self):
+        return L.ALG_ALSPGRAD
+
+    def _opts(self):
+        return dict(maxiter=self.maxiter, tol=self.tol, update_H=self.update_H, maxsubiter=self.maxsubiter,
+                    tolg=self.tolg)
+
+
+@dataclass
+class Result:
+    """NMF.Result{T} (src/common.jl:21-38).  W and H are the caller's arrays, updated in place."""
+    W: np.ndarray
+    H: np.ndarray
+    niters: int
+    converged: bool
+    objvalue: float
+    trace: np.ndarray | None = None
+    info: dict | None = None
+
+    def __post_init__(self):
+        if self.W.shape[1] != self.H.shape[0]:
+            raise DimensionMismatch("Inner dimensions of W and H mismatch.")
+
+    def __eq__(self, o):
+        return (np.array_equal(self.W, o.W) and np.array_equal(self.H, o.H) and self.niters == o.niters
+                and self.converged == o.converged and self.objvalue == o.objvalue)
+
+    def __hash__(self):
+        return hash((self.W.tobytes(), self.H.tobytes(), self.niters, self.converged, self.objvalue))
+
+
+def make_opts(T, maxiter=100, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.0, delta=None, maxsubiter=200,
+              traceiter=20, tolg=None, beta=0.2, sigma=0.01, track_objective=False, check_every=4) -> L.Opts:
+    T = np.dtype(T).type
+    return L.Opts(int(maxiter), int(bool(update_H)), int(bool(track_objective)), int(maxsubiter), int(traceiter),
+                  int(check_every),
+                  float(T(np.cbrt(_eps(T)) if tol is None else tol)), float(lambda_w), float(lambda_h),
+                  float(T(math.sqrt(_eps(T))) if delta is None else delta),
+                  float(T(_eps(T) ** 0.25) if tolg is None else tolg), float(T(beta)), float(T(sigma)))
+
+
+def nmf_checksize(X, W, H):
+    """src/common.jl:5-16."""
+    p, n = X.shape
+    k = W.shape[1]
+    if not (W.shape[0] == p and H.shape == (k, n)):
+        raise DimensionMismatch("Dimensions of X, W, and H are inconsistent.")
+    return p, n, k
+
+
+class Context:
+    """Owns one nmfx_ctx: the device-resident X (uploaded once, src/interf.jl:85-101 re-uses it across
+    replicates) and all solver temporaries (the reference's prepare_state objects)."""
+
+    def __init__(self, dtype, p, n, k, device=0):
+        self.lib = L.load()
+        self.T = np.dtype(dtype).type
+        if self.T not in (np.float32, np.float64):
+            raise ArgumentError("element type must be Float32 or Float64")
+        self.p, self.n, self.k = int(p), int(n), int(k)
+        h = C.c_void_p()
+        st = self.lib.nmfx_create(C.byref(h), L.F32 if self.T == np.float32 else L.F64, self.p, self.n, self.k, device)
+        if st != L.OK:
+            _raise(st, self.lib.nmfx_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nmfx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, st):
+        if st != L.OK:
+            _raise(st, self.lib.nmfx_last_error(self.h).decode())
+
+    def set_X(self, X):
+        X = np.asfortranarray(X, dtype=self.T)
+        assert X.shape == (self.p, self.n)
+        self._ck(self.lib.nmfx_set_X(self.h, X.ctypes.data, X.shape[0]))
+
+    def set_X_device(self, ptr, ldx):
+        self._ck(self.lib.nmfx_set_X_device(self.h, C.c_void_p(ptr), ldx))
+
+    def set_factors(self, W, H):
+        assert W.flags.f_contiguous and H.flags.f_contiguous and W.dtype == self.T and H.dtype == self.T
+        self._ck(self.lib.nmfx_set_factors(self.h, W.ctypes.data, H.ctypes.data))
+
+    def get_factors(self, W=None, H=None):
+        self._ck(self.lib.nmfx_get_factors(self.h, W.ctypes.data if W is not None else None,
+                                           H.ctypes.data if H is not None else None))
+
+    def iterate(self, alg, opts: L.Opts):
+        res = L.CResult()
+        trace = np.full(opts.maxiter + 1, np.nan) if opts.track_objective else None
+        st = self.lib.nmfx_iterate(self.h, alg, C.byref(opts), C.byref(res), trace.ctypes.data if trace is not None else None)
+        self._ck(st)
+        return res, trace
+
+    def solve(self, alg, opts: L.Opts, W, H):
+        assert W.flags.f_contiguous and H.flags.f_contiguous and W.dtype == self.T and H.dtype == self.T
+        if W.shape != (self.p, self.k) or H.shape != (self.k, self.n):
+            raise DimensionMismatch("Dimensions of X, W, and H are inconsistent.")
+        res = L.CResult()
+        trace = np.full(opts.maxiter + 1, np.nan) if opts.track_objective else None
+        st = self.lib.nmfx_solve(self.h, alg, C.byref(opts), W.ctypes.data, H.ctypes.data, C.byref(res),
+                                 trace.ctypes.data if trace is not None else None)
+        self._ck(st)
+        return res, trace
+
+    def subsolve(self, which, opts: L.Opts, W, H):
+        res = L.CResult()
+        self._ck(self.lib.nmfx_alspgrad_subsolve(self.h, which, C.byref(opts), W.ctypes.data, H.ctypes.data, C.byref(res)))
+        return res
+
+    def objective(self, alg, opts: L.Opts):
+        out = C.c_double()
+        self._ck(self.lib.nmfx_objective(self.h, alg, C.byref(opts), C.byref(out)))
+        return out.value
+
+    def comm_init(self, uid: bytes, rank: int, nranks: int):
+        buf = C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)
+        self._ck(self.lib.nmfx_comm_init(self.h, buf, rank, nranks))
+
+    def profile_enable(self, on=True):
+        self._ck(self.lib.nmfx_profile_enable(self.h, int(on)))
+
+    def profile_get(self):
+        arr = (L.KernelStat * 64)()
+        cnt = C.c_int()
+        self._ck(self.lib.nmfx_profile_get(self.h, arr, 64, C.byref(cnt)))
+        return [dict(name=arr[i].name.decode(), ms_total=arr[i].ms_total, launches=arr[i].launches,
+                     flops=arr[i].flops, bytes=arr[i].bytes) for i in range(cnt.value)]
+
+
+def comm_unique_id() -> bytes:
+    lib = L.load()
+    buf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+    st = lib.nmfx_comm_get_unique_id(buf)
+    if st != L.OK:
+        _raise(st, "ncclGetUniqueId failed")
+    return buf.raw
+
+
+def _result(T, W, H, res, trace):
+    tr = None if trace is None else trace[: res.niters + 1]
+    return Result(W, H, int(res.niters), bool(res.converged), float(T(res.objvalue)), tr,
+                  dict(seconds_loop=res.seconds_loop, inner_iters=res.inner_iters, backtracks=res.backtracks,
+                       final_tolg=res.final_tolg))
+
+
+def solve(alg, X, W, H, ctx: Context | None = None, track_objective=False, check_every=4) -> Result:
+    """NMF.solve!(alg, X, W, H): W and H (Fortran-ordered, dtype of X) are updated in place."""
+    p, n, k = nmf_checksize(X, W, H)
+    T = alg.T
+    if X.dtype != T or W.dtype != T or H.dtype != T:
+        raise ArgumentError("X, W, H must have the algorithm's element type")
+    own = ctx is None
+    if own:
+        ctx = Context(T, p, n, k)
+        ctx.set_X(X)
+    try:
+        o = make_opts(T, track_objective=track_objective, check_every=check_every, **alg._opts())
+        res, trace = ctx.solve(alg._alg(), o, W, H)
+        return _result(T, W, H, res, trace)
+    finally:
+        if own:
+            ctx.close()
+
+
+def alspgrad_updateh(X, W, H, maxiter=1000, traceiter=20, tolg=None, beta=0.2, sigma=0.01):
+    """alspgrad_updateh!(X, W, H; ...) (src/alspgrad.jl:69-84); tolg default cbrt(eps(T)).  Returns iterations."""
+    T = H.dtype.type
+    p, n, k = nmf_checksize(X, W, H)
+    with Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        o = make_opts(T, maxsubiter=maxiter, traceiter=traceiter, tolg=float(T(np.cbrt(_eps(T)))) if tolg is None else tolg,
+                      beta=beta, sigma=sigma)
+        return int(ctx.subsolve(0, o, W, H).niters)
+
+
+def alspgrad_updatew(X, W, H, maxiter=1000, traceiter=20, tolg=None, beta=0.2, sigma=0.01):
+    """alspgrad_updatew!(X, W, H; ...) (src/alspgrad.jl:225-240)."""
+    T = W.dtype.type
+    p, n, k = nmf_checksize(X, W, H)
+    with Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        o = make_opts(T, maxsubiter=maxiter, traceiter=traceiter, tolg=float(T(np.cbrt(_eps(T)))) if tolg is None else tolg,
+                      beta=beta, sigma=sigma)
+        return int(ctx.subsolve(1, o, W, H).niters)
+
+
+def randinit(X, k, normalize=False, zeroh=False, rng=None):
+    """randinit (src/initialization.jl:4-17).  The Julia Xoshiro stream is not reproducible here;
+    parity runs pass explicit W0/H0 (init=:custom)."""
+    rng = np.random.default_rng() if rng is None else rng
+    p, n = X.shape
+    T = X.dtype.type
+    W = np.asfortranarray(rng.random((p, k)).astype(T))
+    if normalize:
+        W /= W.sum(axis=0, keepdims=True)                 # normalize1_cols! (src/utils.jl:28-32)
+    H = np.zeros((k, n), dtype=T, order="F") if zeroh else np.asfortranarray(rng.random((k, n)).astype(T))
+    return W, H
+
+
+_ALGS = ("multmse", "multdiv", "projals", "alspgrad")
+
+
+def nnmf(X, k, init="random", alg="multmse", maxiter=100, tol=None, replicates=1, W0=None, H0=None,
+         update_H=True, verbose=False, rng=None, track_objective=False):
+    """nnmf(X, k; ...) (src/interf.jl:3-83) for the accelerated algorithms.
+
+    Scope: alg in {multmse, multdiv, projals, alspgrad}, init in {random, custom};
+    the other algorithms / initialisers stay in Julia (the reference's defaults :greedycd / :nndsvdar are
+    outside the accelerated path and raise ArgumentError here)."""
+    T = X.dtype.type
+    if not (np.issubdtype(X.dtype, np.floating) and np.all(X >= 0)):
+        raise ArgumentError("The elements of X must be non-negative.")
+    p, n = X.shape
+    if not k <= min(p, n):
+        raise ArgumentError("The value of k should not exceed min(size(X)).")
+    if not replicates >= 1:
+        raise ArgumentError("The value of replicates must be positive.")
+    if not update_H and init != "custom":
+        warnings.warn("Only W will be updated.")
+    tol = float(np.cbrt(_eps(T) / 100)) if tol is None else tol      # src/interf.jl:8
+    if init == "custom":
+        if W0 is None or H0 is None:
+            raise ArgumentError("To use :custom initialization, set W0 and H0.")
+        if not np.all(W0 >= 0):
+            raise ArgumentError("The elements of W0 must be non-negative.")
+        if W0.shape != (p, k):
+            raise ArgumentError("Invalid size for W0.")
+        if not np.all(H0 >= 0):
+            raise ArgumentError("The elements of H0 must be non-negative.")
+        if H0.shape != (k, n):
+            raise ArgumentError("Invalid size for H0.")
+    elif W0 is not None or H0 is not None:
+        warnings.warn("Ignore W0 and H0 except for :custom initialization.")
+    initH = alg != "projals"                                          # src/interf.jl:39
+    if init == "random":
+        W, H = randinit(X, k, zeroh=not initH, normalize=True, rng=rng)
+    elif init == "custom":
+        W, H = W0, H0
+    elif init in ("nndsvd", "nndsvda", "nndsvdar", "spa"):
+        raise ArgumentError(f"init=:{init} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
+    else:
+        raise ArgumentError("Invalid value for init.")
+    W = np.asfortranarray(W, dtype=T)
+    H = np.asfortranarray(H, dtype=T)
+    if alg == "projals":
+        inst = ProjectedALS(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    elif alg == "alspgrad":
+        inst = ALSPGrad(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    elif alg == "multmse":
+        inst = MultUpdate(T, obj="mse", maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    elif alg == "multdiv":
+        inst = MultUpdate(T, obj="div", maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    elif alg in ("cd", "greedycd", "spa"):
+        raise ArgumentError(f"alg=:{alg} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
+    else:
+        raise ArgumentError("Invalid algorithm.")
+    # solve_replicates! (src/interf.jl:85-101): X is uploaded once and shared by every replicate
+    with Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        ret = solve(inst, X, W, H, ctx=ctx, track_objective=track_objective or verbose)
+        minobjv = ret.objvalue
+        for _ in range(2, replicates + 1):
+            Wr, Hr = randinit(X, k, zeroh=not initH, normalize=True, rng=rng)
+            tmp = solve(inst, X, Wr, Hr, ctx=ctx)
+            if minobjv > tmp.objvalue:
+                ret, minobjv = tmp, tmp.objvalue
+    if verbose and ret.trace is not None:
+        print(f"{'Iter':<5s}    {'objv':<13s}    {'objv.change':<13s}")
+        for t, v in enumerate(ret.trace):
+            print(f"{t:5d}    {v:13.6e}" + ("" if t == 0 else f"    {v - ret.trace[t - 1]:13.6e}"))
+    return ret

@@ -1,0 +1,431 @@
+"""CPU ORACLE (NumPy twin) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Literal CPU restatement of the NMF.jl hot path (JuliaStats/NMF.jl v1.0.3):
+the `nmf_skeleton!` driver and the `update_wh!` bodies of MultUpdate (MSE and
+KL divergence), ProjectedALS and ALSPGrad.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import
+this module; the shipped solver (libnmfx.so) never does.
+
+PARITY PINNING STATUS
+  * Julia is not installed in the build container, so the reference itself
+    cannot run here.  The oracle is pinned against every known-answer test the
+    reference's own test-suite holds for this path (test/testproblems.jl:6-13,
+    test/multupd.jl:3-22, test/alspgrad.jl:3-25, test/utils.jl:6-63,
+    test/interf.jl:33-37) -- see tests/test_oracle_kat.py -- and against an
+    independent second restatement in C (oracle/nmf_oracle.c).
+  * `Result.objvalue`: PARITY UNPINNED.  It is computed by StatsBase.sqL2dist /
+    StatsBase.gkldiv (compat 0.25-0.34, not vendored, no Manifest; call sites
+    src/multupd.jl:81,148, src/projals.jl:66, src/alspgrad.jl:398) and no
+    reference test asserts its value.  Restated from the published StatsBase
+    definitions: per-element term in T, running sum in Float64.
+  * ProjectedALS: PARITY UNPINNED beyond the interface smoke run -- the
+    reference has no projals test file (test/runtests.jl:9-16).
+
+Conventions: X is p x n, W is p x k, H is k x n, all column-major (Fortran
+order) like Julia `Matrix{T}`.  `mul!` -> BLAS gemm via `@`; sequential
+T-precision accumulations of the Julia scalar loops are reproduced with
+`np.cumsum(...)[-1]` (cumsum is a strict left-to-right recurrence in T).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+from scipy.linalg import lapack
+
+MULTMSE, MULTDIV, PROJALS, ALSPGRAD = 0, 1, 2, 3
+ALG_NAMES = {"multmse": MULTMSE, "multdiv": MULTDIV, "projals": PROJALS, "alspgrad": ALSPGRAD}
+
+
+def eps(T):
+    return float(np.finfo(T).eps)
+
+
+@dataclass
+class Opts:
+    """Union of the option structs: MultUpdate (src/multupd.jl:9-42),
+    ProjectedALS (src/projals.jl:18-34), ALSPGrad (src/alspgrad.jl:352-373)."""
+    maxiter: int = 100
+    tol: float = 0.0            # 0 -> cbrt(eps(T)) (struct default)
+    update_H: bool = True
+    lambda_w: float = -1.0      # <0 -> algorithm default
+    lambda_h: float = -1.0
+    delta: float = -1.0         # <0 -> sqrt(eps(T))          (multupd.jl:48,50)
+    maxsubiter: int = 200       # alspgrad.jl:361
+    tolg: float = -1.0          # <0 -> eps(T)^(1/4)          (alspgrad.jl:363)
+    traceiter: int = 20         # alspgrad.jl:407
+    beta: float = 0.2
+    sigma: float = 0.01
+    track_objective: bool = False   # verbose-style per-iteration objective (common.jl:76-82)
+
+
+@dataclass
+class Result:
+    """NMF.Result{T} (src/common.jl:21-35)."""
+    W: np.ndarray
+    H: np.ndarray
+    niters: int
+    converged: bool
+    objvalue: float
+    trace: list = field(default_factory=list)   # objective at t=0..niters when tracked
+    counters: dict = field(default_factory=dict)
+
+
+def resolve_opts(alg: int, T, o: Opts) -> Opts:
+    """Fill dtype-dependent defaults exactly as the reference constructors do."""
+    r = Opts(**o.__dict__)
+    e = eps(T)
+    if r.tol <= 0:
+        r.tol = float(T(np.cbrt(e)))                      # multupd.jl:21, projals.jl:28, alspgrad.jl:362
+    if alg in (MULTMSE, MULTDIV):
+        if r.lambda_w < 0:
+            r.lambda_w = 0.0                              # multupd.jl:23-24
+        if r.lambda_h < 0:
+            r.lambda_h = 0.0
+        if alg == MULTDIV:                                # multupd.jl:37-40
+            r.lambda_w = max(r.lambda_w, float(T(math.sqrt(e))))
+            r.lambda_h = max(r.lambda_h, float(T(math.sqrt(e))))
+    elif alg == PROJALS:
+        if r.lambda_w < 0:
+            r.lambda_w = float(T(np.cbrt(e)))             # projals.jl:30-31
+        if r.lambda_h < 0:
+            r.lambda_h = float(T(np.cbrt(e)))
+    else:
+        r.lambda_w = r.lambda_h = 0.0
+    if r.delta < 0:
+        r.delta = float(T(math.sqrt(e)))                  # multupd.jl:48
+    if r.tolg < 0:
+        r.tolg = float(T(e ** 0.25))                      # alspgrad.jl:363
+    return r
+
+
+# ----------------------------------------------------------------------------
+# StatsBase restatements (un-vendored dependency; see header)
+# ----------------------------------------------------------------------------
+
+def sqL2dist(a, b):
+    """StatsBase.sqL2dist: r=0.0; r += abs2(a[i]-b[i]) -- term in T, sum in Float64."""
+    d = a - b
+    return float(np.sum((d * d).astype(np.float64)))
+
+
+def gkldiv(a, b):
+    """StatsBase.gkldiv: sum(a>0 ? a*log(a/b) - a + b : b), term in T, sum in Float64."""
+    T = a.dtype.type
+    pos = a > 0
+    safe_a = np.where(pos, a, T(1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(pos, safe_a * np.log(safe_a / b) - safe_a + b, b)
+    return float(np.sum(t.astype(np.float64)))
+
+
+# ----------------------------------------------------------------------------
+# src/utils.jl
+# ----------------------------------------------------------------------------
+
+def adddiag(A, a):
+    """utils.jl:15-24 (no-op when a == 0)."""
+    if a != 0.0:
+        idx = np.arange(A.shape[0])
+        A[idx, idx] += A.dtype.type(a)
+    return A
+
+
+def projectnn(A):
+    """utils.jl:34-41: entries < 0 become 0 (NaN passes through)."""
+    A[A < 0] = 0
+    return A
+
+
+class PosDefException(Exception):
+    pass
+
+
+def _potrf(A):
+    f = lapack.spotrf if A.dtype == np.float32 else lapack.dpotrf
+    c, info = f(A, lower=0, clean=0, overwrite_a=0)
+    if info != 0:
+        raise PosDefException(f"potrf info={info}")
+    return np.asfortranarray(c)
+
+
+def pdsolve(A, x):
+    """utils.jl:63-70: x <- inv(A) x via potrf!('U') + potrs!."""
+    c = _potrf(A)
+    f = lapack.spotrs if A.dtype == np.float32 else lapack.dpotrs
+    sol, info = f(c, x, lower=0)
+    assert info == 0
+    return np.asfortranarray(sol.astype(A.dtype, copy=False))
+
+
+def pdrsolve(A, B):
+    """utils.jl:72-84: x <- A inv(B): potrf!, potri!, copytri!, then mul!."""
+    c = _potrf(B)
+    f = lapack.spotri if B.dtype == np.float32 else lapack.dpotri
+    inv, info = f(c, lower=0)
+    assert info == 0
+    inv = np.triu(inv) + np.triu(inv, 1).T          # copytri!(B, 'U')
+    return np.asfortranarray(A @ np.asfortranarray(inv))
+
+
+# ----------------------------------------------------------------------------
+# src/common.jl:92-111
+# ----------------------------------------------------------------------------
+
+def stop_condition(W, preW, H, preH, tol):
+    """Component-wise relative change test, T-precision sequential sums.
+    Early exit at the first failing component == all components pass."""
+    T = W.dtype.type
+    tol = T(tol)
+    dw = np.cumsum((W - preW) ** 2, axis=0, dtype=W.dtype)[-1, :]
+    sw = np.cumsum((W + preW) ** 2, axis=0, dtype=W.dtype)[-1, :]
+    dh = np.cumsum((H - preH) ** 2, axis=1, dtype=H.dtype)[:, -1]
+    sh = np.cumsum((H + preH) ** 2, axis=1, dtype=H.dtype)[:, -1]
+    bad = (np.sqrt(dw) > tol * np.sqrt(sw)) | (np.sqrt(dh) > tol * np.sqrt(sh))
+    return not bool(np.any(bad))
+
+
+# ----------------------------------------------------------------------------
+# updaters
+# ----------------------------------------------------------------------------
+
+class _MultMSE:
+    """src/multupd.jl:56-116."""
+
+    def __init__(self, T, o, X, W, H):
+        self.T, self.o = T, o
+        self.WH = W @ H                                           # :72
+
+    def objv(self, X, W, H):
+        return float(self.T(0.5 * sqL2dist(X, self.WH)))          # :81, rounded to T by Result{T}
+
+    def update(self, X, W, H):
+        T, o = self.T, self.o
+        lw, lh, d = T(o.lambda_w), T(o.lambda_h), T(o.delta)
+        if o.update_H:
+            WtX = W.T @ X                                         # :98
+            WtWH = W.T @ self.WH                                  # :99
+            H *= np.maximum(T(0), WtX - lh) / (WtWH + d)          # :101-103
+            self.WH = W @ H                                       # :104
+        XHt = X @ H.T                                             # :109
+        WHHt = self.WH @ H.T                                      # :110
+        W *= np.maximum(T(0), XHt - lw) / (WHHt + d)              # :112-114
+        self.WH = W @ H                                           # :115
+
+
+class _MultDiv:
+    """src/multupd.jl:121-193."""
+
+    def __init__(self, T, o, X, W, H):
+        self.T, self.o = T, o
+        self.WH = W @ H
+
+    def objv(self, X, W, H):
+        return float(self.T(gkldiv(X, self.WH)))                  # :148
+
+    def update(self, X, W, H):
+        T, o = self.T, self.o
+        lw, lh, d = T(o.lambda_w), T(o.lambda_h), T(o.delta)
+        if o.update_H:
+            Q = X / (self.WH + d)                                 # :172-174
+            WtQ = W.T @ Q                                         # :175
+            sW = np.cumsum(W, axis=0, dtype=W.dtype)[-1, :]       # :176 sum! in T
+            H *= WtQ / (sW + lh)[:, None]                         # :177-179
+            self.WH = W @ H                                       # :180
+        Q = X / (self.WH + d)                                     # :184-186
+        QHt = Q @ H.T                                             # :187
+        sH = np.cumsum(H, axis=1, dtype=H.dtype)[:, -1]           # :188
+        W *= QHt / (sH + lw)[None, :]                             # :189-191
+        self.WH = W @ H                                           # :192
+
+
+class _ProjALS:
+    """src/projals.jl:42-107."""
+
+    def __init__(self, T, o, X, W, H):
+        self.T, self.o = T, o
+        self.WH = W @ H
+
+    def objv(self, X, W, H):
+        T, o = self.T, self.o
+        r = 0.5 * sqL2dist(X, self.WH)                            # :66  (T(0.5)*Float64 -> Float64)
+        if o.lambda_w > 0:                                        # :67-69  (term in T, sum in Float64)
+            r += float((T(0.5) * T(o.lambda_w)) * T(np.linalg.norm(W.ravel())) ** 2)
+        if o.lambda_h > 0:                                        # :70-72
+            r += float((T(0.5) * T(o.lambda_h)) * T(np.linalg.norm(H.ravel())) ** 2)
+        return float(T(r))                                        # Result{T} conversion (common.jl:33)
+
+    def update(self, X, W, H):
+        T, o = self.T, self.o
+        if o.update_H:
+            WtW = adddiag(np.asfortranarray(W.T @ W), o.lambda_h)  # :92
+            H[...] = pdsolve(WtW, np.asfortranarray(W.T @ X))     # :93-94
+            projectnn(H)                                          # :95
+        HHt = adddiag(np.asfortranarray(H @ H.T), o.lambda_w)     # :100
+        XHt = X @ H.T                                             # :101
+        W[...] = pdrsolve(XHt, HHt)                               # :102
+        projectnn(W)                                              # :103
+        self.WH = W @ H                                           # :106
+
+
+def projgradnorm(g, x):
+    """src/alspgrad.jl:9-19; sequential accumulation in T."""
+    m = (g < 0) | (x > 0)
+    v = np.where(m, g * g, g.dtype.type(0)).ravel(order="F")
+    return g.dtype.type(np.sqrt(np.cumsum(v, dtype=g.dtype)[-1]))
+
+
+def _dot(a, b):
+    """BLAS.dot on the flattened (column-major) arrays."""
+    return a.dtype.type(np.dot(a.ravel(order="F"), b.ravel(order="F")))
+
+
+def _pgrad_subsolve(Z, Gram, B, left, maxiter, traceiter, tolg, beta, sigma, T, cnt):
+    """_alspgrad_updateh! (alspgrad.jl:86-191, left=True: G = Gram*Z - B) and
+    _alspgrad_updatew! (:242-347, left=False: G = Z*Gram - B).  Z is updated in
+    place; returns the number of executed iterations t."""
+    t = 0
+    converged = False
+    decr_alpha = True
+    alpha = T(1)
+    beta, sigma = T(beta), T(sigma)
+    epsT = T(eps(T))
+    Zp = None
+    while (not converged) and t < maxiter:
+        t += 1
+        G = (Gram @ Z if left else Z @ Gram) - B                  # :124-127 / :280-283
+        pgnrm = projgradnorm(G, Z)                                # :130
+        if pgnrm < T(tolg):
+            converged = True
+        it = 0
+        if not converged:
+            while it < traceiter:
+                it += 1
+                cnt["backtracks"] += 1
+                if not np.isfinite(alpha):
+                    raise FloatingPointError("alpha is not finite")   # :140
+                Zn = np.maximum(Z - alpha * G, T(0))              # :143-147
+                D = Zn - Z
+                dv1 = _dot(G, D)                                  # :150
+                GD = Gram @ D if left else D @ Gram               # :151
+                dv2 = _dot(GD, D)                                 # :152
+                suff_decr = bool(((T(1) - sigma) * dv1 + T(0.5) * dv2) < 0)   # :155
+                if it == 1:                                       # :157-160
+                    decr_alpha = not suff_decr
+                    Zp = Z.copy()
+                if decr_alpha:
+                    if suff_decr:                                 # :163-165
+                        Z[...] = Zn
+                        break
+                    alpha = T(alpha * beta)                       # :167
+                else:
+                    diff = (Zp - Zn).ravel(order="F")
+                    approx = bool(T(np.linalg.norm(diff)) <= epsT)  # isapprox atol=eps(T), rtol=0
+                    if (not suff_decr) or approx:                 # :170-172
+                        Z[...] = Zp
+                        break
+                    alpha = T(alpha / beta)                       # :174
+                    Zp = Zn.copy()                                # :175
+        cnt["inner"] += 1
+    return t
+
+
+class _ALSPGrad:
+    """src/alspgrad.jl:352-425."""
+
+    def __init__(self, T, o, X, W, H):
+        self.T, self.o = T, o
+        self.WH = W @ H
+        self.tolg = T(o.tolg)                                     # fresh ALSPGradUpd per solve! (:381-383)
+        self.cnt = {"inner": 0, "backtracks": 0}
+
+    def objv(self, X, W, H):
+        return float(self.T(0.5 * sqL2dist(X, self.WH)))          # :398
+
+    def update(self, X, W, H):
+        T, o = self.T, self.o
+        if o.update_H:
+            WtW = W.T @ W                                         # set_w! :63-67
+            WtX = W.T @ X
+            itH = _pgrad_subsolve(H, WtW, WtX, True, o.maxsubiter, o.traceiter,
+                                  self.tolg, o.beta, o.sigma, T, self.cnt)   # :406-407
+            if itH == 1:
+                self.tolg = T(np.float64(self.tolg) * 0.1)        # :409-411 (Float64 literal)
+        HHt = H @ H.T                                             # set_h! :218-222
+        XHt = X @ H.T
+        itW = _pgrad_subsolve(W, HHt, XHt, False, o.maxsubiter, o.traceiter,
+                              self.tolg, o.beta, o.sigma, T, self.cnt)       # :416-417
+        if itW == 1:
+            self.tolg = T(np.float64(self.tolg) * 0.1)            # :419-421
+        self.WH = W @ H                                           # :424
+
+
+_UPDATERS = {MULTMSE: _MultMSE, MULTDIV: _MultDiv, PROJALS: _ProjALS, ALSPGRAD: _ALSPGrad}
+
+
+def alspgrad_updateh(X, W, H, maxiter=1000, traceiter=20, tolg=None, beta=0.2, sigma=0.01):
+    """Public wrapper alspgrad_updateh! (alspgrad.jl:69-84); tolg default cbrt(eps(T))."""
+    T = H.dtype.type
+    tolg = T(np.cbrt(eps(T))) if tolg is None else T(tolg)
+    cnt = {"inner": 0, "backtracks": 0}
+    return _pgrad_subsolve(H, W.T @ W, W.T @ X, True, maxiter, traceiter, tolg, beta, sigma, T, cnt)
+
+
+def alspgrad_updatew(X, W, H, maxiter=1000, traceiter=20, tolg=None, beta=0.2, sigma=0.01):
+    """Public wrapper alspgrad_updatew! (alspgrad.jl:225-240)."""
+    T = W.dtype.type
+    tolg = T(np.cbrt(eps(T))) if tolg is None else T(tolg)
+    cnt = {"inner": 0, "backtracks": 0}
+    return _pgrad_subsolve(W, H @ H.T, X @ H.T, False, maxiter, traceiter, tolg, beta, sigma, T, cnt)
+
+
+def nmf_checksize(X, W, H):
+    """src/common.jl:5-16."""
+    p, n = X.shape
+    k = W.shape[1]
+    if not (W.shape[0] == p and H.shape == (k, n)):
+        raise ValueError("Dimensions of X, W, and H are inconsistent.")
+    return p, n, k
+
+
+def solve(alg, X, W, H, opts: Opts | None = None) -> Result:
+    """NMF.solve!(alg, X, W, H) == nmf_skeleton! (src/common.jl:45-89).
+    W and H are updated IN PLACE (they must be Fortran-ordered arrays of X's dtype)."""
+    if isinstance(alg, str):
+        alg = ALG_NAMES[alg]
+    T = X.dtype.type
+    assert W.dtype == X.dtype and H.dtype == X.dtype
+    assert W.flags.f_contiguous and H.flags.f_contiguous
+    nmf_checksize(X, W, H)
+    o = resolve_opts(alg, T, opts or Opts())
+    upd = _UPDATERS[alg](T, o, X, W, H)                           # prepare_state :51
+    trace = []
+    if o.track_objective:
+        trace.append(upd.objv(X, W, H))                           # :56
+    converged = False
+    t = 0
+    while (not converged) and t < o.maxiter:                      # :64
+        t += 1
+        preW = W.copy(order="F")                                  # :66-67
+        preH = H.copy(order="F")
+        upd.update(X, W, H)                                       # :70
+        converged = stop_condition(W, preW, H, preH, o.tol)       # :73
+        if o.track_objective:
+            trace.append(upd.objv(X, W, H))                       # :79
+    objv = trace[-1] if (o.track_objective and trace) else upd.objv(X, W, H)   # :85-87
+    return Result(W, H, t, converged, objv, trace, dict(getattr(upd, "cnt", {})))
+
+
+# ----------------------------------------------------------------------------
+# test problem (test/testproblems.jl:6-13)
+# ----------------------------------------------------------------------------
+
+def laurberg6x3(alpha, T=np.float64):
+    a = T(alpha)
+    H = np.array([[a, 1, 1, a, 0, 0],
+                  [1, a, 0, 0, a, 1],
+                  [0, 0, a, 1, 1, a]], dtype=T, order="F")
+    W = np.asfortranarray(H.T.copy())
+    X = np.asfortranarray(W @ H)
+    return X, W, H

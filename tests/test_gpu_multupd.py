@@ -1,0 +1,105 @@
+"""GPU parity: MultUpdate (MSE and divergence) through the C ABI vs the CPU oracle.
+
+Tolerances (stated per north_star): objective trajectory within 1e-5 relative (f32) /
+1e-10 (f64) iteration for iteration; final W, H within 1e-3 / 1e-8 relative to max|.|.
+The reference forms W'(WH) and (WH)H' through the p x n product, the GPU path uses the
+Gram form (W'W)H and W(HH'): algebraically identical, differs in rounding only.
+"""
+import numpy as np
+import pytest
+
+import nmf_oracle as orc
+import nmfx
+from problems import planted, rel_trace_err, uniform
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(6, 6, 3), (5, 8, 3), (200, 500, 5), (300, 260, 70), (512, 768, 64), (257, 1030, 129)]
+TOL = {np.float32: (1e-5, 1e-3), np.float64: (1e-10, 1e-8)}
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+@pytest.mark.parametrize("obj", ["mse", "div"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_trajectory_matches_oracle(built, T, obj, shape):
+    p, n, k = shape
+    X, W0, H0 = planted(p, n, k, T, seed=p * 1000 + n)
+    maxiter = 25
+    alg = nmfx.MultUpdate(T, obj=obj, maxiter=maxiter, tol=1e-30, lambda_w=1e-4, lambda_h=1e-4)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg, track_objective=True)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("mult" + obj, X, Wc, Hc, orc.Opts(maxiter=maxiter, tol=1e-30, lambda_w=1e-4, lambda_h=1e-4,
+                                                     track_objective=True))
+    assert r.niters == ro.niters == maxiter and not r.converged
+    tol_obj, tol_fac = TOL[T]
+    assert rel_trace_err(r.trace, ro.trace) < tol_obj
+    assert np.max(np.abs(Wg - Wc)) <= tol_fac * np.max(np.abs(Wc))
+    assert np.max(np.abs(Hg - Hc)) <= tol_fac * np.max(np.abs(Hc))
+    assert np.all(Wg >= 0) and np.all(Hg >= 0) and not np.isnan(Wg).any() and not np.isnan(Hg).any()
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+@pytest.mark.parametrize("obj", ["mse", "div"])
+def test_stop_rule_same_iteration(built, T, obj):
+    """converged / niters agree with the oracle when the stop rule fires (src/common.jl:92-111)."""
+    X, W0, H0 = planted(120, 90, 4, T, seed=5)
+    tol = 2e-2
+    alg = nmfx.MultUpdate(T, obj=obj, maxiter=400, tol=tol)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg, check_every=3)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("mult" + obj, X, Wc, Hc, orc.Opts(maxiter=400, tol=tol))
+    assert ro.converged and r.converged
+    assert r.niters == ro.niters
+    assert abs(r.objvalue - ro.objvalue) <= TOL[T][0] * 10 * abs(ro.objvalue)
+    assert np.max(np.abs(Wg - Wc)) <= TOL[T][1] * np.max(np.abs(Wc))
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+@pytest.mark.parametrize("obj", ["mse", "div"])
+def test_update_H_false_leaves_H_bit_identical(built, T, obj):
+    """test/interf.jl:33-37."""
+    X, W0, H0 = uniform(40, 64, 3, T, seed=3)
+    alg = nmfx.MultUpdate(T, obj=obj, maxiter=30, update_H=False)
+    W, H = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, W, H)
+    assert np.array_equal(H, H0) and r.H is H
+    assert np.any(W != W0)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("mult" + obj, X, Wc, Hc, orc.Opts(maxiter=30, update_H=False,
+                                                     tol=float(T(np.cbrt(np.finfo(T).eps)))))
+    assert r.niters == ro.niters
+    assert np.max(np.abs(W - Wc)) <= TOL[T][1] * np.max(np.abs(Wc))
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("obj", ["mse", "div"])
+@pytest.mark.parametrize("lam", [0.0, 1e-4])
+def test_reference_kat_laurberg(built, T, obj, lam):
+    """test/multupd.jl:3-22 run on the GPU path: non-negative, no NaN, ||X - W*Hg||_F <= 1e-2."""
+    X, Wg, Hg = orc.laurberg6x3(0.3, T)
+    rng = np.random.default_rng(11)
+    W = np.asfortranarray(Wg + rng.random(Wg.shape).astype(T) * T(0.1))
+    H = Hg.copy(order="F")
+    alg = nmfx.MultUpdate(T, obj=obj, maxiter=5000, tol=1e-9, lambda_w=lam, lambda_h=lam)
+    nmfx.solve(alg, X, W, H, check_every=64)
+    assert np.all(W >= 0) and np.all(H >= 0)
+    assert not np.isnan(W).any() and not np.isnan(H).any()
+    assert np.linalg.norm(X - W @ H) <= 1e-2
+
+
+def test_argument_errors(built):
+    """Constructor validation of src/multupd.jl:27-31 and the shape check of src/common.jl:5-16."""
+    T = np.float32
+    with pytest.raises(nmfx.ArgumentError):
+        nmfx.MultUpdate(T, obj="foo")
+    with pytest.raises(nmfx.ArgumentError):
+        nmfx.MultUpdate(T, maxiter=1)
+    with pytest.raises(nmfx.ArgumentError):
+        nmfx.MultUpdate(T, tol=0.0)
+    with pytest.raises(nmfx.ArgumentError):
+        nmfx.MultUpdate(T, lambda_w=-1.0)
+    X, W0, H0 = uniform(12, 10, 3, T)
+    with pytest.raises(nmfx.DimensionMismatch):
+        nmfx.solve(nmfx.MultUpdate(T), X, W0, np.asfortranarray(H0[:, :5]))

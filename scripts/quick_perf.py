@@ -1,0 +1,41 @@
+"""Quick per-kernel timing on the GPU box (development aid, not the bench contract)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nmf.jl_amd"))
+import numpy as np
+import nmfx
+
+def run(p, n, k, T, alg_name, iters=10):
+    rng = np.random.default_rng(0)
+    t0 = time.time()
+    Wg = rng.random((p, k), dtype=np.float32); Hg = rng.random((k, n), dtype=np.float32)
+    X = np.asfortranarray((Wg @ Hg).astype(T).T).T if False else np.asfortranarray((Wg @ Hg).astype(T))
+    W0 = rng.random((p, k)).astype(T); W0 /= W0.sum(0, keepdims=True); W0 = np.asfortranarray(W0)
+    H0 = np.asfortranarray(rng.random((k, n)).astype(T))
+    print(f"gen {time.time()-t0:.1f}s", flush=True)
+    algs = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3}
+    with nmfx.Context(T, p, n, k) as ctx:
+        t0 = time.time(); ctx.set_X(X); print(f"upload X {time.time()-t0:.2f}s", flush=True)
+        ctx.set_factors(W0, H0)
+        o = nmfx.make_opts(T, maxiter=3, tol=1e-30, check_every=1000,
+                           lambda_w=(3.5e-4 if alg_name == "multdiv" else 0.0), lambda_h=(3.5e-4 if alg_name == "multdiv" else 0.0))
+        ctx.iterate(algs[alg_name], o)  # warmup
+        o.maxiter = iters
+        t0 = time.time(); res, _ = ctx.iterate(algs[alg_name], o); wall = time.time() - t0
+        fl = {"multmse": 4.0*p*n*k + 4.0*k*k*(p+n), "multdiv": 8.0*p*n*k}[alg_name]
+        print(f"{alg_name} {p}x{n} k={k} {np.dtype(T).name}: {res.seconds_loop/iters*1e3:.3f} ms/iter (wall {wall/iters*1e3:.3f}) "
+              f"-> {fl*iters/res.seconds_loop/1e12:.1f} TFLOP/s alg; objv {res.objvalue:.6e}", flush=True)
+        ctx.profile_enable(True)
+        ctx.iterate(algs[alg_name], o)
+        for s in ctx.profile_get():
+            ms = s["ms_total"] / max(1, s["launches"])
+            tf = s["flops"] / max(1, s["launches"]) / (ms * 1e-3) / 1e12 if s["flops"] else 0
+            gb = s["bytes"] / max(1, s["launches"]) / (ms * 1e-3) / 1e9 if s["bytes"] else 0
+            print(f"   {s['name']:<22s} n={s['launches']:<4d} avg {ms*1e3:9.1f} us  {tf:7.1f} TF/s {gb:8.0f} GB/s")
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c3"]
+    if "c2" in which: run(4096, 4096, 64, np.float32, "multmse", 20)
+    if "c3" in which: run(16384, 16384, 256, np.float32, "multmse", 10)
+    if "c3div" in which: run(16384, 16384, 256, np.float32, "multdiv", 5)
+    if "c3f64" in which: run(8192, 8192, 256, np.float64, "multmse", 5)

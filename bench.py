@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- the headline benchmark of BASELINE.json on MI355X.
+
+metric   : NMF MultUpdate-MSE outer iterations per second (and GFLOP/s) on X = 16384 x 16384, k = 256, fp32
+step     : ONE outer iteration of update_wh!(::MultUpdMSE) (src/multupd.jl:83-116) + stop_condition statistics
+           (src/common.jl:92-111), on synthetic dense X already resident in HBM.
+N GPUs   : X and H are column-sharded over the ranks (same global X: strong scaling), W replicated, one packed RCCL
+           all-reduce of [XH' | HH' | H statistics] per iteration.  One process per GPU (torch.distributed.run).
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     : dominant kernel (the two p*n*k MFMA GEMMs), algorithmic flops per launch / hipEvent-measured
+                 average launch duration inside the timed region, vs the 157.3 TFLOP/s fp32 MFMA peak.
+  cpu_baseline : the NumPy restatement of the reference (oracle/nmf_oracle.py, "port", executes the reference's
+                 6-GEMM sequence with multithreaded OpenBLAS like stock Julia) timed on the host cores on a bounded
+                 column sample of the same workload; rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "nmf.jl_amd"))
+
+import numpy as np
+import torch
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+SEED = 20240910
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--p", type=int, default=16384)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--k", type=int, default=256)
+    ap.add_argument("--alg", default="multmse", choices=["multmse", "multdiv", "projals"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cols", type=int, default=1024)
+    return ap.parse_args()
+
+
+def shard_range(n, rank, world):
+    """Contiguous column shard [c0, c1) of rank `rank`; remainders go to the first ranks."""
+    base, rem = divmod(n, world)
+    c0 = rank * base + min(rank, rem)
+    return c0, c0 + base + (1 if rank < rem else 0)
+
+
+def synth(p, n, k, c0, c1, tdtype, device):
+    """Planted-rank dense X >= 0: X = Wg Hg + 0.01 U, generated on the device.
+    Returns X^T shard as an (n_local, p) row-major tensor == column-major p x n_local, plus host W0, H0 shard."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(SEED)
+    Wg = torch.rand((p, k), generator=g, dtype=torch.float32)
+    Hg = torch.rand((k, n), generator=g, dtype=torch.float32)
+    W0 = torch.rand((p, k), generator=g, dtype=torch.float64)
+    W0 = W0 / W0.sum(dim=0, keepdim=True)                      # randinit(...; normalize=true), src/interf.jl:43
+    H0 = torch.rand((k, n), generator=g, dtype=torch.float64)
+    Wg_d = Wg.to(device=device, dtype=tdtype)
+    Hg_d = Hg[:, c0:c1].to(device=device, dtype=tdtype)
+    Xt = Hg_d.t().contiguous() @ Wg_d.t().contiguous()        # (n_local, p): data generation only (rocBLAS)
+    gd = torch.Generator(device=device)
+    gd.manual_seed(SEED + 1 + c0)
+    Xt.add_(torch.rand(Xt.shape, generator=gd, device=device, dtype=tdtype), alpha=0.01)
+    npdt = np.float32 if tdtype == torch.float32 else np.float64
+    W0h = np.asfortranarray(W0.numpy().astype(npdt))
+    H0h = np.asfortranarray(H0[:, c0:c1].numpy().astype(npdt))
+    return Xt, W0h, H0h
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    import nmfx
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    T = np.float32 if a.dtype == "f32" else np.float64
+    tdtype = torch.float32 if a.dtype == "f32" else torch.float64
+    p, n, k = a.p, a.n, a.k
+    c0, c1 = shard_range(n, rank, world)
+    nl = c1 - c0
+    Xt, W0, H0 = synth(p, n, k, c0, c1, tdtype, device)
+    torch.cuda.synchronize()
+
+    algid = {"multmse": 0, "multdiv": 1, "projals": 2}[a.alg]
+    ctx = nmfx.Context(T, p, nl, k, device=local_rank)
+    ctx.set_X_device(Xt.data_ptr(), p)
+    if world > 1:
+        import torch.distributed as dist
+        uid = [nmfx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
+    ctx.set_factors(W0, H0)
+    eps = float(np.finfo(T).eps)
+    lam = float(np.sqrt(eps)) if a.alg == "multdiv" else (float(np.cbrt(eps)) if a.alg == "projals" else 0.0)
+    tiny = float(np.finfo(T).tiny)      # stop rule can never fire: exactly K iterations are executed
+
+    def opts(iters):
+        return nmfx.make_opts(T, maxiter=iters, tol=tiny, lambda_w=lam, lambda_h=lam, check_every=1 << 30)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if a.warmup > 0:
+        ctx.iterate(algid, opts(a.warmup))
+    ctx.profile_enable(True)            # hipEvent pair around every launch on the solver stream
+    barrier()
+    t0 = time.perf_counter()
+    res, _ = ctx.iterate(algid, opts(a.steps))
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert res.niters == a.steps, (res.niters, a.steps)
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        if a.alg == "multmse":
+            f_alg = 4.0 * p * n * k + 4.0 * k * k * (p + n)
+        elif a.alg == "multdiv":
+            f_alg = 8.0 * p * n * k
+        else:
+            f_alg = 4.0 * p * n * k + 2.0 * k * k * (p + n) + 2.0 * k * k * n + 2.0 * p * k * k + float(k) ** 3
+        # dominant kernel = the GEMM family with the largest summed time
+        gemms = [s for s in prof if s["flops"] > 0]
+        dom = max(gemms, key=lambda s: s["ms_total"]) if gemms else None
+        roof = None
+        if dom is not None:
+            avg_s = dom["ms_total"] / dom["launches"] * 1e-3
+            ach = dom["flops"] / dom["launches"] / avg_s / 1e12
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get(dom["name"])
+                except Exception:
+                    traffic = None
+            roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2),
+                    "peak": PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6, "unit": "TFLOP/s",
+                    "frac": round(ach / (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6), 4),
+                    "traffic": traffic,
+                    "flops_per_launch": dom["flops"] / dom["launches"],
+                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches": dom["launches"]}
+        out = {
+            "metric": "nmf_multupdate_mse_iters_per_sec" if a.alg == "multmse" else f"nmf_{a.alg}_iters_per_sec",
+            "value": round(a.steps / dt, 4), "unit": "iters/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"X={p}x{n} k={k} {a.dtype} alg=:{a.alg} (planted-rank dense X, seed {SEED}), "
+                                   f"column-sharded over {world} GPU(s)", "p": p, "n": n, "k": k,
+                       "parallelism": f"colshard{world}"},
+            "gflops_algorithmic": round(f_alg * a.steps / dt / 1e9, 1),
+            "frac_of_fp32_mfma_peak": round(f_alg * a.steps / dt / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+            "objvalue": res.objvalue,
+            "roofline": roof,
+            "kernels": [{"name": s["name"], "launches": s["launches"],
+                         "avg_us": round(s["ms_total"] / s["launches"] * 1e3, 2)} for s in prof],
+        }
+        if world == 1 and not a.no_cpu_baseline and a.alg == "multmse":
+            out["cpu_baseline"] = cpu_baseline(p, n, k, T, Xt, W0, H0, a.cpu_sample_cols)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(p, n, k, T, Xt, W0, H0, ns):
+    """NMF.jl's CPU path = the NumPy restatement executing the reference's operation sequence, on the first `ns`
+    columns of the same X (per-iteration cost is linear in n); value is scaled to the full problem."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nmf_oracle as orc
+    ns = min(ns, n)
+    Xs = np.asfortranarray(Xt[:ns, :].cpu().numpy().T)            # p x ns, column-major
+    Ws, Hs = W0.copy(order="F"), np.asfortranarray(H0[:, :ns].copy())
+    tiny = float(np.finfo(T).tiny)
+    orc.solve("multmse", Xs, Ws, Hs, orc.Opts(maxiter=1, tol=tiny))      # warm-up (BLAS threads, page faults)
+    iters, t_used = 0, 0.0
+    while iters < 5 and t_used < 15.0:
+        t0 = time.perf_counter()
+        orc.solve("multmse", Xs, Ws, Hs, orc.Opts(maxiter=1, tol=tiny))
+        t_used += time.perf_counter() - t0
+        iters += 1
+    # each solve() call = WH GEMM (prepare_state) + 1 iteration (6 GEMMs) + objective pass; count it as one iteration
+    t_iter_full = t_used / iters * (n / ns)
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [(d.get("internal_api"), d.get("version"), d.get("num_threads")) for d in threadpool_info()]
+    except Exception:
+        blas = None
+    return {"value": round(1.0 / t_iter_full, 5), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"first {ns} of {n} columns of the same X (p={p}, k={k}), {iters} timed single-iteration solves of "
+                      f"oracle/nmf_oracle.py (reference's 6-GEMM sequence, OpenBLAS threads = all cores), "
+                      f"time scaled by n/{ns}", "seconds_per_iter_full_est": round(t_iter_full, 3),
+            "gflops_reference_equiv": round(12.0 * p * n * k / t_iter_full / 1e9, 1), "blas": blas}
+
+
+if __name__ == "__main__":
+    main()

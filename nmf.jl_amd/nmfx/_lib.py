@@ -51,6 +51,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64/librccl
+    # (same SONAMEs as /opt/rocm).  Whichever is loaded first serves both; loading /opt/rocm's first and torch's
+    # extensions afterwards mixes runtime versions (observed: abort at exit).  If torch is installed, let it load
+    # first -- it is only plumbing here (device tensors / torch.distributed in bench.py and the tests).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = os.path.abspath(LIB_PATH)
     if not os.path.exists(path):
         raise ImportError(f"libnmfx.so not found at {path}: build it with `python __graft_entry__.py` "

@@ -97,3 +97,33 @@ def alspgrad_updatew(X, W, H, maxiter=1000, traceiter=20, tolg=None, beta=0.2, s
     return fn(C.c_long(p), C.c_long(n), C.c_long(k), X.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p),
               H.ctypes.data_as(C.c_void_p), C.c_long(maxiter), C.c_long(traceiter), C.c_double(tolg),
               C.c_double(float(T(beta))), C.c_double(float(T(sigma))))
+
+
+def pdsolve(A, B):
+    """pdsolve!(A, x) (src/utils.jl:63-70) through the C restatement; returns inv(A) B."""
+    A = np.asfortranarray(A.copy()); B = np.asfortranarray(B.copy())
+    fn = getattr(lib(), f"nmf_oracle_pdsolve_{_sfx(A.dtype)}")
+    st = fn(C.c_long(A.shape[0]), A.ctypes.data_as(C.c_void_p), C.c_long(B.shape[1]), B.ctypes.data_as(C.c_void_p))
+    if st:
+        raise np.linalg.LinAlgError("not positive definite")
+    return B
+
+
+def pdrsolve(A, B):
+    """pdrsolve!(A, B, x) (src/utils.jl:72-84) through the C restatement; returns A inv(B)."""
+    A = np.asfortranarray(A.copy()); B = np.asfortranarray(B.copy())
+    Xo = np.zeros_like(A, order="F")
+    fn = getattr(lib(), f"nmf_oracle_pdrsolve_{_sfx(A.dtype)}")
+    st = fn(C.c_long(A.shape[0]), C.c_long(B.shape[0]), A.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p),
+            Xo.ctypes.data_as(C.c_void_p))
+    if st:
+        raise np.linalg.LinAlgError("not positive definite")
+    return Xo
+
+
+def stop_condition(W, preW, H, preH, tol):
+    fn = getattr(lib(), f"nmf_oracle_stop_condition_{_sfx(W.dtype)}")
+    p, k = W.shape
+    n = H.shape[1]
+    return bool(fn(C.c_long(p), C.c_long(n), C.c_long(k), W.ctypes.data_as(C.c_void_p), preW.ctypes.data_as(C.c_void_p),
+                   H.ctypes.data_as(C.c_void_p), preH.ctypes.data_as(C.c_void_p), C.c_double(tol)))

@@ -2,6 +2,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  first: pins ONE HIP runtime for the process (see nmfx/_lib.py)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for sub in ("nmf.jl_amd", "oracle", "tests"):

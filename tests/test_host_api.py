@@ -1,0 +1,80 @@
+"""Host-side mirror of the reference interface: validation and error vocabulary (no GPU needed:
+every check below fires before a device context is created).  src/interf.jl:15-33,55,79; src/multupd.jl:27-40;
+src/common.jl:5-16,29-31; test/utils.jl:65-69 (Result ==/hash)."""
+import numpy as np
+import pytest
+
+import nmfx
+
+
+def test_nnmf_argument_errors():
+    X = np.asfortranarray(np.random.default_rng(0).random((6, 8)))
+    Xneg = X.copy()
+    Xneg[0, 0] = -1
+    with pytest.raises(nmfx.ArgumentError, match="non-negative"):
+        nmfx.nnmf(Xneg, 2)
+    with pytest.raises(nmfx.ArgumentError, match="should not exceed"):
+        nmfx.nnmf(X, 7)
+    with pytest.raises(nmfx.ArgumentError, match="replicates"):
+        nmfx.nnmf(X, 2, replicates=0)
+    with pytest.raises(nmfx.ArgumentError, match="set W0 and H0"):
+        nmfx.nnmf(X, 2, init="custom")
+    W0 = np.ones((6, 2), order="F")
+    H0 = np.ones((2, 8), order="F")
+    with pytest.raises(nmfx.ArgumentError, match="Invalid size for W0"):
+        nmfx.nnmf(X, 2, init="custom", W0=np.ones((5, 2)), H0=H0)
+    with pytest.raises(nmfx.ArgumentError, match="Invalid size for H0"):
+        nmfx.nnmf(X, 2, init="custom", W0=W0, H0=np.ones((2, 7)))
+    with pytest.raises(nmfx.ArgumentError, match="W0 must be non-negative"):
+        nmfx.nnmf(X, 2, init="custom", W0=-W0, H0=H0)
+    with pytest.raises(nmfx.ArgumentError, match="Invalid value for init"):
+        nmfx.nnmf(X, 2, init="bogus")
+    with pytest.raises(nmfx.ArgumentError, match="Invalid algorithm"):
+        nmfx.nnmf(X, 2, alg="bogus")
+    with pytest.raises(nmfx.ArgumentError, match="outside the accelerated hot path"):
+        nmfx.nnmf(X, 2, alg="greedycd")
+
+
+def test_option_struct_defaults_and_validation():
+    m = nmfx.MultUpdate(np.float32)
+    assert m.maxiter == 100 and abs(m.tol - 4.92e-3) < 1e-5 and m.lambda_w == 0 and m.update_H
+    d = nmfx.MultUpdate(np.float64, obj="div")
+    assert abs(d.lambda_w - 1.4901161193847656e-08) < 1e-20 and d.lambda_h == d.lambda_w       # max(lambda, sqrt(eps))
+    assert abs(d._opts()["delta"] - 1.4901161193847656e-08) < 1e-20
+    for bad in (dict(obj="x"), dict(maxiter=1), dict(tol=0), dict(lambda_w=-1), dict(lambda_h=-1)):
+        with pytest.raises(nmfx.ArgumentError):
+            nmfx.MultUpdate(np.float32, **bad)
+    with pytest.warns(UserWarning, match="deprecated"):
+        dep = nmfx.MultUpdate(np.float64, lambda_=0.5)
+    assert dep.lambda_w == 0.5 and dep.lambda_h == 0.5
+    pa = nmfx.ProjectedALS(np.float32)
+    assert abs(pa.lambda_w - 4.92e-3) < 1e-5 and abs(pa.tol - 4.92e-3) < 1e-5
+    ag = nmfx.ALSPGrad(np.float64)
+    assert ag.maxsubiter == 200 and abs(ag.tolg - 1.2207e-4) < 1e-8
+
+
+def test_result_struct():
+    W = np.ones((4, 2), order="F")
+    H = np.ones((2, 5), order="F")
+    a = nmfx.Result(W, H, 3, True, 0.5)
+    b = nmfx.Result(W.copy(), H.copy(), 3, True, 0.5)
+    assert a == b and hash(a) == hash(b)
+    assert not (a == nmfx.Result(W, H, 4, True, 0.5))
+    with pytest.raises(nmfx.DimensionMismatch, match="Inner dimensions"):
+        nmfx.Result(W, np.ones((3, 5)), 1, False, 0.0)
+
+
+def test_checksize():
+    X = np.zeros((5, 7))
+    assert nmfx.nmf_checksize(X, np.zeros((5, 2)), np.zeros((2, 7))) == (5, 7, 2)
+    with pytest.raises(nmfx.DimensionMismatch, match="inconsistent"):
+        nmfx.nmf_checksize(X, np.zeros((5, 2)), np.zeros((2, 6)))
+
+
+def test_randinit_properties():
+    X = np.zeros((9, 11), dtype=np.float32)
+    W, H = nmfx.randinit(X, 3, normalize=True, rng=np.random.default_rng(0))
+    assert W.dtype == np.float32 and W.flags.f_contiguous and np.allclose(W.sum(axis=0), 1, atol=1e-6)
+    assert H.shape == (3, 11) and (H >= 0).all() and (H < 1).all()
+    _, Hz = nmfx.randinit(X, 3, zeroh=True)
+    assert not Hz.any()

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <string>
 #include <vector>
@@ -20,6 +21,7 @@
 #include "kernels.hpp"
 
 namespace nmfx {
+struct PgState;
 
 struct HipError {
     hipError_t e;
@@ -141,6 +143,8 @@ template <typename T> class Solver : public SolverBase {
         (void)hipStreamSynchronize(stream);
         if (comm) (void)ncclCommDestroy(comm);
         for (auto &e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (pg_state) (void)hipFree(pg_state);
+        if (pg_host) (void)hipHostFree(pg_host);
         if (ctrl) (void)hipFree(ctrl);
         if (ctrl_host) (void)hipHostFree(ctrl_host);
         (void)hipEventDestroy(ev_beg);
@@ -400,6 +404,11 @@ template <typename T> class Solver : public SolverBase {
     const int *done_flag() const { return &ctrl->done; }
 
     void run_alspgrad(const nmfx_opts &o, nmfx_result *out, double *trace);
+    long long pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int maxiter, int traceiter, T tolg, T beta, T sigma,
+                          long long *inner_total);
+    struct PgState *pg_state = nullptr, *pg_host = nullptr;
+    DevBuf<double> pg_part;
+    long long pg_backtracks = 0;
 };
 
 }  // namespace nmfx

@@ -1,0 +1,111 @@
+"""GPU parity: ProjectedALS and ALSPGrad through the C ABI vs the CPU oracle.
+
+Stated tolerances.  projals: objective trajectory 1e-7 (f64) / 2e-3 (f32) relative -- the f32 figure is the
+conditioning of the reference algorithm itself (two CPU implementations of it differ by ~2e-4, see
+tests/golden/make_golden.py); the device H-solve uses Uinv*(Uinv'*B) instead of two substitutions.
+alspgrad: 1e-7 (f64) / 2e-3 (f32); its suff_decr / isapprox branches are discontinuous in the data, so
+trajectories (not branch traces) are compared, as SURVEY.md section 7 prescribes.
+"""
+import numpy as np
+import pytest
+
+import c_oracle as co
+import nmf_oracle as orc
+import nmfx
+from problems import planted, rel_trace_err
+
+pytestmark = pytest.mark.gpu
+TOL = {np.float64: 1e-7, np.float32: 2e-3}
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(64, 96, 5), (300, 260, 70), (130, 515, 8)])
+def test_projals_trajectory(built, T, shape):
+    p, n, k = shape
+    X, W0, H0 = planted(p, n, k, T, seed=9 + p, normalize=False, zeroh=True)
+    lam = 0.05
+    alg = nmfx.ProjectedALS(T, maxiter=15, tol=1e-30, lambda_w=lam, lambda_h=lam)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg, track_objective=True)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=15, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+    assert r.niters == ro.niters == 15
+    # conditioning yardstick: how far the two independent CPU restatements of the SAME algorithm drift apart on
+    # this input (cond(HH'+lambda I) reaches 4e4 for k=70 in f32).  The GPU may not deviate from the reference by
+    # more than 3x that, nor is it asked to beat it.
+    rc = co.solve("projals", X, W0.copy(order="F"), H0.copy(order="F"),
+                  orc.Opts(maxiter=15, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+    tol = max(TOL[T], 3 * rel_trace_err(rc.trace, ro.trace))
+    assert rel_trace_err(r.trace, ro.trace) < tol
+    assert np.max(np.abs(Wg - Wc)) <= 50 * tol * np.max(np.abs(Wc))
+    assert np.max(np.abs(Hg - Hc)) <= 50 * tol * np.max(np.abs(Hc))
+    assert np.all(Wg >= 0) and np.all(Hg >= 0)
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_projals_default_options_and_stop(built, T):
+    """Default lambda = cbrt(eps(T)) (src/projals.jl:30-31), H0 = 0 as nnmf passes it (src/interf.jl:39,43)."""
+    X, W0, H0 = planted(80, 120, 4, T, seed=21, normalize=False, zeroh=True)
+    alg = nmfx.ProjectedALS(T, maxiter=200)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=200))
+    assert r.converged == ro.converged
+    assert abs(r.niters - ro.niters) <= (0 if T == np.float64 else 2)
+    assert abs(r.objvalue - ro.objvalue) <= 20 * TOL[T] * abs(ro.objvalue)
+
+
+def test_projals_not_posdef_raises(built):
+    """potrf! on a singular Gram with lambda = 0 -> PosDefException (src/utils.jl:68)."""
+    T = np.float64
+    X, W0, H0 = planted(20, 30, 3, T, seed=2, normalize=False)
+    W0[:, 1] = 0.0
+    alg = nmfx.ProjectedALS(T, maxiter=5, lambda_w=0.0, lambda_h=0.0)
+    with pytest.raises(nmfx.PosDefException):
+        nmfx.solve(alg, X, W0, H0)
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_alspgrad_subsolver_kat(built, T):
+    """test/alspgrad.jl:10-20 on the GPU path."""
+    X, Wg, Hg = orc.laurberg6x3(0.3, T)
+    rng = np.random.default_rng(1)
+    eps = np.finfo(T).eps
+    H = np.asfortranarray(rng.random(Hg.shape).astype(T))
+    nmfx.alspgrad_updateh(X, Wg, H, maxiter=1000, tolg=eps)
+    assert np.all(H >= 0) and np.linalg.norm(H - Hg) <= eps ** 0.25
+    W = np.asfortranarray(rng.random(Wg.shape).astype(T))
+    nmfx.alspgrad_updatew(X, W, Hg, maxiter=1000, tolg=eps)
+    assert np.all(W >= 0) and np.linalg.norm(W - Wg) <= eps ** 0.25
+    r = nmfx.solve(nmfx.ALSPGrad(T), X, W, H)             # smoke: NMF.solve!(NMF.ALSPGrad{T}(), X, W, H)
+    assert r.niters >= 1 and np.isfinite(r.objvalue)
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(40, 56, 4), (140, 300, 9)])
+def test_alspgrad_trajectory(built, T, shape):
+    p, n, k = shape
+    X, W0, H0 = planted(p, n, k, T, seed=31 + n)
+    alg = nmfx.ALSPGrad(T, maxiter=8, tol=1e-30)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg, track_objective=True)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("alspgrad", X, Wc, Hc, orc.Opts(maxiter=8, tol=1e-30, track_objective=True))
+    assert r.niters == ro.niters == 8
+    assert rel_trace_err(r.trace, ro.trace) < TOL[T]
+    assert np.all(Wg >= 0) and np.all(Hg >= 0)
+    if T == np.float64:
+        assert r.info["inner_iters"] == ro.counters["inner"]
+        assert r.info["backtracks"] == ro.counters["backtracks"]
+        assert np.max(np.abs(Wg - Wc)) <= 1e-6 * np.max(np.abs(Wc))
+
+
+@pytest.mark.parametrize("alg_name", ["projals", "alspgrad"])
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_update_H_false(built, alg_name, T):
+    X, W0, H0 = planted(30, 44, 3, T, seed=3, normalize=False)
+    alg = nmfx.ProjectedALS(T, maxiter=10, update_H=False) if alg_name == "projals" else nmfx.ALSPGrad(T, maxiter=10, update_H=False)
+    W, H = W0.copy(order="F"), H0.copy(order="F")
+    nmfx.solve(alg, X, W, H)
+    assert np.array_equal(H, H0) and np.any(W != W0)

@@ -48,13 +48,6 @@ def parse():
     return ap.parse_args()
 
 
-def shard_range(n, rank, world):
-    """Contiguous column shard [c0, c1) of rank `rank`; remainders go to the first ranks."""
-    base, rem = divmod(n, world)
-    c0 = rank * base + min(rank, rem)
-    return c0, c0 + base + (1 if rank < rem else 0)
-
-
 def synth(p, n, k, c0, c1, tdtype, device):
     """Planted-rank dense X >= 0: X = Wg Hg + 0.01 U, generated on the device.
     Returns X^T shard as an (n_local, p) row-major tensor == column-major p x n_local, plus host W0, H0 shard."""
@@ -94,7 +87,7 @@ def main():
     T = np.float32 if a.dtype == "f32" else np.float64
     tdtype = torch.float32 if a.dtype == "f32" else torch.float64
     p, n, k = a.p, a.n, a.k
-    c0, c1 = shard_range(n, rank, world)
+    c0, c1 = nmfx.dist.shard_range(n, rank, world)
     nl = c1 - c0
     Xt, W0, H0 = synth(p, n, k, c0, c1, tdtype, device)
     torch.cuda.synchronize()
@@ -103,10 +96,7 @@ def main():
     ctx = nmfx.Context(T, p, nl, k, device=local_rank)
     ctx.set_X_device(Xt.data_ptr(), p)
     if world > 1:
-        import torch.distributed as dist
-        uid = [nmfx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], rank, world)
+        nmfx.dist.init_comm(ctx)
     ctx.set_factors(W0, H0)
     eps = float(np.finfo(T).eps)
     lam = float(np.sqrt(eps)) if a.alg == "multdiv" else (float(np.cbrt(eps)) if a.alg == "projals" else 0.0)

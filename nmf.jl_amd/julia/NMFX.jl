@@ -1,0 +1,128 @@
+# NMFX.jl -- the Julia side of the drop-in: NMF.solve! methods that run on MI355X through libnmfx.so.
+#
+# Host code stays in Julia (north_star): `nnmf`, argument validation, initialisation and `solve_replicates!`
+# are NMF.jl's own code (src/interf.jl:3-101), untouched.  This file only adds `solve!`-compatible entry
+# points that `ccall` the C ABI of include/nmfx.h and hand back an `NMF.Result{T}` holding the SAME W and H
+# arrays, updated in place, exactly like `nmf_skeleton!` does (src/common.jl:88).
+#
+# NOTE: the build image has no Julia toolchain, so this shim is untested there; it is kept trivially thin
+# (one ccall per C entry point, no logic beyond marshalling and status -> exception mapping).  The Python
+# twin nmf.jl_amd/nmfx/api.py exercises the same C entry points in the test-suite.
+module NMFX
+
+using NMF
+using LinearAlgebra: PosDefException
+
+const libnmfx = get(ENV, "NMFX_LIB", joinpath(@__DIR__, "..", "lib", "libnmfx.so"))
+
+# struct nmfx_opts (include/nmfx.h) -- field order and types must match the C header
+struct COpts
+    maxiter::Int32
+    update_H::Int32
+    track_objective::Int32
+    maxsubiter::Int32
+    traceiter::Int32
+    check_every::Int32
+    tol::Float64
+    lambda_w::Float64
+    lambda_h::Float64
+    delta::Float64
+    tolg::Float64
+    beta::Float64
+    sigma::Float64
+end
+
+# struct nmfx_result
+struct CResult
+    niters::Int64
+    converged::Int32
+    status::Int32
+    objvalue::Float64
+    seconds_loop::Float64
+    inner_iters::Int64
+    backtracks::Int64
+    final_tolg::Float64
+end
+
+const ALG_MULTMSE, ALG_MULTDIV, ALG_PROJALS, ALG_ALSPGRAD = Int32(0), Int32(1), Int32(2), Int32(3)
+dtype_code(::Type{Float32}) = Int32(0)
+dtype_code(::Type{Float64}) = Int32(1)
+
+last_error(h::Ptr{Cvoid}) = unsafe_string(ccall((:nmfx_last_error, libnmfx), Cstring, (Ptr{Cvoid},), h))
+
+# status codes of include/nmfx.h -> the exceptions the reference throws
+function check(status::Integer, h::Ptr{Cvoid}=C_NULL)
+    status == 0 && return
+    msg = last_error(h)
+    status == 1 && throw(ArgumentError(msg))                     # src/multupd.jl:27-31
+    status == 2 && throw(DimensionMismatch(msg))                 # src/common.jl:12
+    status == 3 && throw(PosDefException(1))                     # potrf!, src/utils.jl:68,78
+    status == 4 && error("α is not finite")                      # src/alspgrad.jl:140,296
+    error("nmfx status $status: $msg")
+end
+
+"""
+    Context{T}(X; device=0)
+
+Device-resident copy of `X` plus all solver temporaries (replaces the `prepare_state` objects).
+Create once and reuse across `replicates` (src/interf.jl:85-101 calls `solve!` repeatedly on the same `X`).
+"""
+mutable struct Context{T}
+    h::Ptr{Cvoid}
+    p::Int
+    n::Int
+    k::Int
+    function Context{T}(X::Matrix{T}, k::Integer; device::Integer=0) where {T<:Union{Float32,Float64}}
+        p, n = size(X)
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:nmfx_create, libnmfx), Cint, (Ref{Ptr{Cvoid}}, Cint, Int64, Int64, Int64, Cint),
+                    ref, dtype_code(T), p, n, k, device))
+        ctx = new{T}(ref[], p, n, k)
+        finalizer(c -> (c.h != C_NULL && ccall((:nmfx_destroy, libnmfx), Cvoid, (Ptr{Cvoid},), c.h); c.h = C_NULL), ctx)
+        check(ccall((:nmfx_set_X, libnmfx), Cint, (Ptr{Cvoid}, Ptr{T}, Int64), ctx.h, X, stride(X, 2)), ctx.h)
+        return ctx
+    end
+end
+
+function run!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, H::Matrix{T}) where T
+    (size(W) == (ctx.p, ctx.k) && size(H) == (ctx.k, ctx.n)) ||
+        throw(DimensionMismatch("Dimensions of X, W, and H are inconsistent."))   # nmf_checksize, src/common.jl:5-16
+    res = Ref{CResult}()
+    st = ccall((:nmfx_solve, libnmfx), Cint,
+               (Ptr{Cvoid}, Cint, Ref{COpts}, Ptr{T}, Ptr{T}, Ref{CResult}, Ptr{Float64}),
+               ctx.h, alg, o, W, H, res, C_NULL)
+    check(st, ctx.h)
+    r = res[]
+    return NMF.Result{T}(W, H, Int(r.niters), r.converged != 0, T(r.objvalue))     # src/common.jl:21-35
+end
+
+opts(T; maxiter, tol, update_H, lambda_w=0.0, lambda_h=0.0, maxsubiter=200, tolg=eps(T)^(1/4)) =
+    COpts(maxiter, update_H, 0, maxsubiter, 20, 4, tol, lambda_w, lambda_h, sqrt(eps(T)), tolg, T(0.2), T(0.01))
+
+# ---- solve! methods: same signatures as src/multupd.jl:45, src/projals.jl:37, src/alspgrad.jl:381, with a
+# ---- leading device Context.  `solve!(alg, X, W, H)` without a Context creates one for the call.
+function solve!(ctx::Context{T}, alg::NMF.MultUpdate{T}, W::Matrix{T}, H::Matrix{T}) where T
+    a = alg.obj == :mse ? ALG_MULTMSE : ALG_MULTDIV
+    run!(ctx, a, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
+                      lambda_w=alg.lambda_w, lambda_h=alg.lambda_h), W, H)
+end
+
+solve!(ctx::Context{T}, alg::NMF.ProjectedALS{T}, W::Matrix{T}, H::Matrix{T}) where T =
+    run!(ctx, ALG_PROJALS, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
+                                lambda_w=alg.lambda_w, lambda_h=alg.lambda_h), W, H)
+
+solve!(ctx::Context{T}, alg::NMF.ALSPGrad{T}, W::Matrix{T}, H::Matrix{T}) where T =
+    run!(ctx, ALG_ALSPGRAD, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
+                                 maxsubiter=alg.maxsubiter, tolg=alg.tolg), W, H)
+
+function solve!(alg::Union{NMF.MultUpdate{T},NMF.ProjectedALS{T},NMF.ALSPGrad{T}},
+                X::Matrix{T}, W::Matrix{T}, H::Matrix{T}; device::Integer=0) where T
+    ctx = Context{T}(X, size(W, 2); device=device)
+    try
+        return solve!(ctx, alg, W, H)
+    finally
+        finalize(ctx)
+    end
+end
+
+end # module

@@ -2,8 +2,8 @@
 from .api import (ALSPGrad, ArgumentError, Context, DimensionMismatch, MultUpdate, NMFXError, PosDefException,
                   ProjectedALS, Result, alspgrad_updateh, alspgrad_updatew, comm_unique_id, make_opts, nmf_checksize,
                   nnmf, randinit, solve)
-from . import _lib
+from . import _lib, dist
 
 __all__ = ["ALSPGrad", "ArgumentError", "Context", "DimensionMismatch", "MultUpdate", "NMFXError", "PosDefException",
            "ProjectedALS", "Result", "alspgrad_updateh", "alspgrad_updatew", "comm_unique_id", "make_opts",
-           "nmf_checksize", "nnmf", "randinit", "solve", "_lib"]
+           "nmf_checksize", "nnmf", "randinit", "solve", "_lib", "dist"]

@@ -1,0 +1,41 @@
+"""Column-sharded multi-GPU plumbing (one process per GPU, torch.distributed for rendezvous only).
+
+The data path collective itself (one packed sum all-reduce per outer iteration) runs inside libnmfx.so on
+RCCL; this module only (a) decides which columns a rank owns and (b) ships rank 0's RCCL unique id to the
+other ranks.  The reference has no distributed path."""
+from __future__ import annotations
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous column shard [c0, c1) of `rank`; the first n % world ranks get one extra column."""
+    if not (0 <= rank < world) or n < world:
+        raise ValueError("need 0 <= rank < world <= n")
+    base, rem = divmod(n, world)
+    c0 = rank * base + min(rank, rem)
+    return c0, c0 + base + (1 if rank < rem else 0)
+
+
+def packed_layout(P: int, K: int) -> dict:
+    """Offsets (in elements of T) of the per-iteration all-reduce payload  [ X_g H_g' | H_g H_g' | rowsum(H_g) ]."""
+    return {"XHt": (0, P * K), "HHt": (P * K, P * K + K * K), "sH": (P * K + K * K, P * K + K * K + K),
+            "count": P * K + K * K + K}
+
+
+def broadcast_unique_id(make_id, group=None) -> bytes:
+    """rank 0 calls make_id() (-> 128 bytes from nmfx_comm_get_unique_id); every rank returns the same bytes."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    box = [make_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    uid = box[0]
+    if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
+        raise RuntimeError("unique id broadcast failed")
+    return bytes(uid)
+
+
+def init_comm(ctx, group=None):
+    """Attach an RCCL communicator spanning `group` (default: world) to a Context."""
+    import torch.distributed as dist
+    from .api import comm_unique_id
+    uid = broadcast_unique_id(comm_unique_id, group)
+    ctx.comm_init(uid, dist.get_rank(group), dist.get_world_size(group))

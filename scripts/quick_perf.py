@@ -5,24 +5,29 @@ sys.path.insert(0, os.path.join(ROOT, "nmf.jl_amd"))
 import numpy as np
 import nmfx
 
-def run(p, n, k, T, alg_name, iters=10):
+def run(p, n, k, T, alg_name, iters=10, maxsub=200):
     rng = np.random.default_rng(0)
     t0 = time.time()
     Wg = rng.random((p, k), dtype=np.float32); Hg = rng.random((k, n), dtype=np.float32)
     X = np.asfortranarray((Wg @ Hg).astype(T).T).T if False else np.asfortranarray((Wg @ Hg).astype(T))
-    W0 = rng.random((p, k)).astype(T); W0 /= W0.sum(0, keepdims=True); W0 = np.asfortranarray(W0)
+    W0 = rng.random((p, k)).astype(T)
+    if alg_name != 'projals': W0 /= W0.sum(0, keepdims=True)
+    W0 = np.asfortranarray(W0)
     H0 = np.asfortranarray(rng.random((k, n)).astype(T))
     print(f"gen {time.time()-t0:.1f}s", flush=True)
     algs = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3}
     with nmfx.Context(T, p, n, k) as ctx:
         t0 = time.time(); ctx.set_X(X); print(f"upload X {time.time()-t0:.2f}s", flush=True)
         ctx.set_factors(W0, H0)
-        o = nmfx.make_opts(T, maxiter=3, tol=1e-30, check_every=1000,
-                           lambda_w=(3.5e-4 if alg_name == "multdiv" else 0.0), lambda_h=(3.5e-4 if alg_name == "multdiv" else 0.0))
+        lam = {"multdiv": 3.5e-4, "projals": 4.9e-3}.get(alg_name, 0.0)
+        o = nmfx.make_opts(T, maxiter=3, tol=1e-30, check_every=1000, lambda_w=lam, lambda_h=lam, maxsubiter=maxsub)
         ctx.iterate(algs[alg_name], o)  # warmup
         o.maxiter = iters
         t0 = time.time(); res, _ = ctx.iterate(algs[alg_name], o); wall = time.time() - t0
-        fl = {"multmse": 4.0*p*n*k + 4.0*k*k*(p+n), "multdiv": 8.0*p*n*k}[alg_name]
+        fl = {"multmse": 4.0*p*n*k + 4.0*k*k*(p+n), "multdiv": 8.0*p*n*k,
+              "projals": 4.0*p*n*k + 2.0*k*k*(p+n) + 2.0*k*k*n + 2.0*p*k*k + float(k)**3,
+              "alspgrad": 4.0*p*n*k + 2.0*k*k*(p+n)}[alg_name]
+        print(f"   inner={res.inner_iters} backtracks={res.backtracks}")
         print(f"{alg_name} {p}x{n} k={k} {np.dtype(T).name}: {res.seconds_loop/iters*1e3:.3f} ms/iter (wall {wall/iters*1e3:.3f}) "
               f"-> {fl*iters/res.seconds_loop/1e12:.1f} TFLOP/s alg; objv {res.objvalue:.6e}", flush=True)
         ctx.profile_enable(True)
@@ -39,3 +44,6 @@ if __name__ == "__main__":
     if "c3" in which: run(16384, 16384, 256, np.float32, "multmse", 10)
     if "c3div" in which: run(16384, 16384, 256, np.float32, "multdiv", 5)
     if "c3f64" in which: run(8192, 8192, 256, np.float64, "multmse", 5)
+    if "c4shard" in which: run(16384, 16384, 256, np.float32, "projals", 5)
+    if "c5shard" in which: run(8192, 4096, 512, np.float64, "alspgrad", 2, maxsub=10)
+    if "alsf32" in which: run(4096, 4096, 64, np.float32, "alspgrad", 2, maxsub=20)

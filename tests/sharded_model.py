@@ -1,0 +1,61 @@
+"""NumPy model of the column-sharded formulation the GPU path implements (test infrastructure).
+
+Rank g owns X_g = X[:, c0:c1], H_g; W is replicated.  Per outer iteration ONE sum all-reduce of the packed
+buffer [X_g H_g' | H_g H_g' | rowsum(H_g)] (+ the 2k stop statistics of H) -- see nmfx/dist.py.
+The algebra is the Gram form used on the device:  (W'W) H  instead of W'(WH),  W (HH') instead of (WH) H'.
+`allreduce(np_array) -> np_array` is injected (gloo in the tests, identity for world = 1)."""
+import numpy as np
+
+
+def _stats(new, old, axis):
+    d = ((new - old) ** 2).sum(axis=axis, dtype=np.float64)
+    s = ((new + old) ** 2).sum(axis=axis, dtype=np.float64)
+    return d, s
+
+
+def step(alg, Xg, W, Hg, lam_w, lam_h, delta, allreduce, update_H=True):
+    T = Xg.dtype.type
+    k = W.shape[1]
+    preW, preH = W.copy(), Hg.copy()
+    if alg == "multmse":
+        if update_H:
+            Hg *= np.maximum(T(0), W.T @ Xg - T(lam_h)) / ((W.T @ W) @ Hg + T(delta))
+        pack = np.concatenate([(Xg @ Hg.T).ravel(order="F"), (Hg @ Hg.T).ravel(order="F"), np.zeros(k, T)])
+        pack = allreduce(pack)
+        XHt = pack[: W.size].reshape(W.shape, order="F")
+        HHt = pack[W.size: W.size + k * k].reshape((k, k), order="F")
+        W *= np.maximum(T(0), XHt - T(lam_w)) / (W @ HHt + T(delta))
+    elif alg == "multdiv":
+        if update_H:
+            Q = Xg / (W @ Hg + T(delta))
+            Hg *= (W.T @ Q) / (W.sum(axis=0, dtype=np.float64).astype(T) + T(lam_h))[:, None]
+        Q = Xg / (W @ Hg + T(delta))
+        pack = np.concatenate([(Q @ Hg.T).ravel(order="F"), np.zeros(k * k, T), Hg.sum(axis=1, dtype=np.float64).astype(T)])
+        pack = allreduce(pack)
+        QHt = pack[: W.size].reshape(W.shape, order="F")
+        sH = pack[W.size + k * k:]
+        W *= QHt / (sH + T(lam_w))[None, :]
+    elif alg == "projals":
+        if update_H:
+            A = W.T @ W + T(lam_h) * np.eye(k, dtype=T)
+            Hg[...] = np.maximum(np.linalg.solve(A.astype(np.float64), (W.T @ Xg).astype(np.float64)), 0).astype(T)
+        pack = np.concatenate([(Xg @ Hg.T).ravel(order="F"), (Hg @ Hg.T).ravel(order="F"), np.zeros(k, T)])
+        pack = allreduce(pack)
+        XHt = pack[: W.size].reshape(W.shape, order="F")
+        HHt = pack[W.size: W.size + k * k].reshape((k, k), order="F") + T(lam_w) * np.eye(k, dtype=T)
+        W[...] = np.maximum(XHt.astype(np.float64) @ np.linalg.inv(HHt.astype(np.float64)), 0).astype(T)
+    else:
+        raise ValueError(alg)
+    dh, sh = _stats(Hg, preH, 1)
+    hs = allreduce(np.concatenate([dh, sh]))
+    dw, sw = _stats(W, preW, 0)
+    return dw, sw, hs[:k], hs[k:]
+
+
+def objective(alg, Xg, W, Hg, allreduce):
+    WH = W @ Hg
+    if alg == "multdiv":
+        pos = Xg > 0
+        t = np.where(pos, Xg * np.log(np.where(pos, Xg, 1) / WH) - Xg + WH, WH)
+        return float(allreduce(np.array([t.sum(dtype=np.float64)]))[0])
+    return 0.5 * float(allreduce(np.array([((Xg - WH) ** 2).sum(dtype=np.float64)]))[0])

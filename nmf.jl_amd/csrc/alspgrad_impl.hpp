@@ -95,12 +95,10 @@ template <typename T> void Solver<T>::subsolve(int which, const nmfx_opts &o, nm
     pg_backtracks = 0;
     long long inner = 0;
     if (which == 0) {                                                      // alspgrad_updateh! (:69-84)
-        gram_w(W[wcur].p, nullptr);                                        // set_w! (:63-67)
-        wt_times(W[wcur].p, X.p, numH.p, nullptr);
-        out->niters = pg_subsolve(true, H[hcur].p, gramW.p, numH.p, o.maxsubiter, o.traceiter, (T)o.tolg, (T)o.beta, (T)o.sigma, &inner);
+        wt_times(W[wcur].p, X.p, true, nullptr);                           // set_w! (:63-67)
+        out->niters = pg_subsolve(true, H[hcur].p, gramW_p, numH_p, o.maxsubiter, o.traceiter, (T)o.tolg, (T)o.beta, (T)o.sigma, &inner);
     } else {                                                               // alspgrad_updatew! (:225-240)
-        gram_h(H[hcur].p, gramH_p, nullptr);                               // set_h! (:218-222)
-        times_ht(X.p, H[hcur].p, numW_p, nullptr);
+        times_ht(X.p, H[hcur].p, true, nullptr);                           // set_h! (:218-222)
         allreduce_w_side(false, nullptr);
         out->niters = pg_subsolve(false, W[wcur].p, gramH_p, numW_p, o.maxsubiter, o.traceiter, (T)o.tolg, (T)o.beta, (T)o.sigma, &inner);
     }
@@ -135,13 +133,11 @@ template <typename T> void Solver<T>::run_alspgrad(const nmfx_opts &o, nmfx_resu
         HIP_TRY(hipMemcpyAsync(preW, Wc, W[0].count * sizeof(T), hipMemcpyDeviceToDevice, stream));
         if (o.update_H) {
             HIP_TRY(hipMemcpyAsync(preH, Hc, H[0].count * sizeof(T), hipMemcpyDeviceToDevice, stream));
-            gram_w(Wc, nullptr);                                           // set_w! (:405)
-            wt_times(Wc, X.p, numH.p, nullptr);
-            const long long itH = pg_subsolve(true, Hc, gramW.p, numH.p, o.maxsubiter, o.traceiter, tolg, (T)o.beta, (T)o.sigma, &inner);
+            wt_times(Wc, X.p, true, nullptr);                              // set_w! (:405)
+            const long long itH = pg_subsolve(true, Hc, gramW_p, numH_p, o.maxsubiter, o.traceiter, tolg, (T)o.beta, (T)o.sigma, &inner);
             if (itH == 1) tolg = (T)((double)tolg * 0.1);                  // :409-411
         }
-        gram_h(Hc, gramH_p, nullptr);                                      // set_h! (:415)
-        times_ht(X.p, Hc, numW_p, nullptr);
+        times_ht(X.p, Hc, true, nullptr);                                  // set_h! (:415)
         allreduce_w_side(false, nullptr);
         const long long itW = pg_subsolve(false, Wc, gramH_p, numW_p, o.maxsubiter, o.traceiter, tolg, (T)o.beta, (T)o.sigma, &inner);
         if (itW == 1) tolg = (T)((double)tolg * 0.1);                      // :419-421

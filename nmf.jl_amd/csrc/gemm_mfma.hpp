@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <limits.h>
 
 namespace nmfx {
 
@@ -61,6 +62,12 @@ template <typename T> struct GemmArgs {
     int kchunk;             // contraction length handled by one split (multiple of BK)
     int c_fastest;          // 1: consecutive blocks walk c-tiles first (they share the A tile)
     const int *done;        // device stop flag: kernels of iterations past the stop are no-ops
+    // Optional second segment of an operand (fuses the k x k Gram into the big GEMM launch):
+    // rows r >= r_split come from A2 (ld lda2), rows c >= c_split from B2 (ld ldb2).  Splits are tile-aligned.
+    const T *A2 = nullptr;
+    const T *B2 = nullptr;
+    int64_t lda2 = 0, ldb2 = 0;
+    int64_t r_split = INT64_MAX, c_split = INT64_MAX;
 };
 
 // XOR swizzle of the 16-byte chunk position inside a KCONTIG LDS row (8 chunks/row):
@@ -157,6 +164,10 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     const int64_t r0 = (int64_t)tr * BR, c0 = (int64_t)tc * BC;
     const int64_t kbeg = (int64_t)split * g.kchunk;
     const int nk = g.kchunk / BK;
+    const T *Ab = g.A, *Bb = g.B;
+    int64_t lda = g.lda, ldb = g.ldb, ra0 = r0, cb0 = c0;
+    if (r0 >= g.r_split) { Ab = g.A2; lda = g.lda2; ra0 = r0 - g.r_split; }
+    if (c0 >= g.c_split) { Bb = g.B2; ldb = g.ldb2; cb0 = c0 - g.c_split; }
 
     typename M::acc_t acc[TR][TC];
 #pragma unroll
@@ -167,8 +178,8 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
             for (int r = 0; r < M::NACC; ++r) acc[i][j][r] = (T)0;
 
     typename M::vec_t ra[LoadA::PER_THREAD], rb[LoadB::PER_THREAD];
-    LoadA::load(ra, g.A, g.lda, r0, kbeg, tid);
-    LoadB::load(rb, g.B, g.ldb, c0, kbeg, tid);
+    LoadA::load(ra, Ab, lda, ra0, kbeg, tid);
+    LoadB::load(rb, Bb, ldb, cb0, kbeg, tid);
     LoadA::store(ra, smem, tid);
     LoadB::store(rb, smem + BR * BK, tid);
     __syncthreads();
@@ -176,8 +187,8 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) {   // prefetch the next k-tile into registers; lands while the MFMAs run
-            LoadA::load(ra, g.A, g.lda, r0, kbeg + (int64_t)(t + 1) * BK, tid);
-            LoadB::load(rb, g.B, g.ldb, c0, kbeg + (int64_t)(t + 1) * BK, tid);
+            LoadA::load(ra, Ab, lda, ra0, kbeg + (int64_t)(t + 1) * BK, tid);
+            LoadB::load(rb, Bb, ldb, cb0, kbeg + (int64_t)(t + 1) * BK, tid);
         }
         const T *a_s = smem + cur * STAGE, *b_s = a_s + BR * BK;
 #pragma unroll
@@ -232,6 +243,21 @@ template <typename T> struct EpiStore {
     T *dst;
     __device__ __forceinline__ void begin(int split) { dst = C + (int64_t)split * slab_stride; }
     __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) { dst[c + r * ld] = v; }
+    __device__ __forceinline__ void finish(double *, int, int, int) {}
+};
+
+// Split-K slab store with two destinations: columns c < c_split go to the main output (ld), columns
+// c >= c_split to a second matrix (ld2) placed right behind it inside the same slab.  Used by the fused
+// [X ; H] * H' launch: slab = [ XH' (c_split x R, ld = c_split) | HH' (ld2 x R, ld2) ].
+template <typename T> struct EpiStore2 {
+    T *C;
+    int64_t ld, c_split, ld2, off2, slab_stride;
+    T *dst;
+    __device__ __forceinline__ void begin(int split) { dst = C + (int64_t)split * slab_stride; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) {
+        if (c < c_split) dst[c + r * ld] = v;
+        else dst[off2 + (c - c_split) + r * ld2] = v;
+    }
     __device__ __forceinline__ void finish(double *, int, int, int) {}
 };
 

@@ -95,14 +95,19 @@ __global__ void row_stats_kernel(const T *Hn, const T *Ho, int64_t cols, int64_t
     }
 }
 
-// out[j*2 + {0,1}] = sum over chunks (ascending) of partial -- final per-component statistics
-__global__ void finalize_stats_kernel(const double *partial, int nchunks, int K, double *out, const int *done) {
+// out[e] = sum over chunks of partial[c*stride + e], e < count.  One wave per output: lane l adds chunks
+// l, l+64, ... then a fixed shuffle tree -- deterministic, and not a serial chain of `nchunks` dependent loads.
+template <typename OutT>
+__global__ void finalize_partials_kernel(const double *partial, int nchunks, int stride, int count, OutT *out,
+                                         const int *done) {
     NMFX_DONE_GUARD(done);
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * K) return;
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (e >= count) return;
+    const int lane = threadIdx.x & 63;
     double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * 2 * K + e];
-    out[e] = s;
+    for (int c = lane; c < nchunks; c += 64) s += partial[(int64_t)c * stride + e];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) out[e] = (OutT)s;
 }
 
 // stop_condition decision (src/common.jl:105-110) + iteration bookkeeping.
@@ -186,17 +191,6 @@ __global__ void row_sum_kernel(const T *H, int64_t cols, int64_t ld, int K, doub
         for (int64_t i = beg; i < end; ++i) s += (double)H[j + i * ld];
         partial[(int64_t)chunk * K + j] = s;
     }
-}
-
-// out[j] = T(sum over chunks of partial[chunk*K + j])
-template <typename T>
-__global__ void finalize_sum_kernel(const double *partial, int nchunks, int K, T *out, const int *done) {
-    NMFX_DONE_GUARD(done);
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= K) return;
-    double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * K + j];
-    out[j] = (T)s;
 }
 
 // multdiv scalings (src/multupd.jl:177-179, 189-191):

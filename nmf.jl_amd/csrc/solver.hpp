@@ -107,8 +107,10 @@ template <typename T> class Solver : public SolverBase {
         HIP_TRY(hipEventCreate(&ev_end));
         X.alloc((size_t)P * N);
         for (int i = 0; i < 2; ++i) { W[i].alloc((size_t)P * K); H[i].alloc((size_t)K * N); }
-        numH.alloc((size_t)K * N);
-        gramW.alloc((size_t)K * K);
+        // H-side numerator and Gram are ONE K x (N+K) matrix: [ W'X | W'W ] is produced by a single GEMM launch
+        hside.alloc((size_t)K * (N + K));
+        numH_p = hside.p;
+        gramW_p = hside.p + (size_t)K * N;
         // W-side numerator, Gram and multdiv's rowsum(H) live in ONE buffer: it is the packed
         // all-reduce payload of the column-sharded path  [ X_g H_g' | H_g H_g' | rowsum(H_g) ]
         pack.alloc((size_t)P * K + (size_t)K * K + (size_t)K);
@@ -120,7 +122,7 @@ template <typename T> class Solver : public SolverBase {
         s_w = pick_splits((int)(P / 128) * (int)((K + 127) / 128), N);
         s_gw = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), P);
         s_gh = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), N);
-        size_t slab_elems = std::max(std::max((size_t)s_h * K * N, (size_t)s_w * P * K),
+        size_t slab_elems = std::max(std::max((size_t)s_h * K * (N + K), (size_t)s_w * (P * K + K * K)),
                                      std::max((size_t)s_gw * K * K, (size_t)s_gh * K * K));
         slabs.alloc(slab_elems);
         stat_chunks_w = (int)std::max<int64_t>(1, std::min<int64_t>(64, P / 1024));
@@ -246,7 +248,8 @@ template <typename T> class Solver : public SolverBase {
     int device, num_cu = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev_beg = nullptr, ev_end = nullptr;
-    DevBuf<T> X, Q, W[2], H[2], numH, gramW, slabs, svec, pack;
+    DevBuf<T> X, Q, W[2], H[2], hside, slabs, svec, pack;
+    T *numH_p = nullptr, *gramW_p = nullptr;
     T *numW_p = nullptr, *gramH_p = nullptr, *sH_p = nullptr;
     DevBuf<T> work[8];   // algorithm-specific scratch (projals factor/inverse, alspgrad G/Zn/Zp/D/GD)
     DevBuf<double> stat_part, wstat, hstat, obj_part, obj_extra, obj_final, trace_dev;
@@ -255,6 +258,10 @@ template <typename T> class Solver : public SolverBase {
     int s_h = 1, s_w = 1, s_gw = 1, s_gh = 1;
     int stat_chunks_w = 1, stat_chunks_h = 1;
     bool have_X = false, have_F = false;
+    // Fusing the k x k Gram into the big GEMM launch adds (K/128)^2 tiles to a grid that otherwise fills the 512
+    // block slots exactly (256 tiles x 2 splits @C3): the 8 extra blocks form a second wave and cost +50 % (measured
+    // 1584 vs 1053+27 us).  Kept behind a flag until the grid is stream-K balanced.
+    bool fuse_gram = false;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
 
@@ -304,11 +311,17 @@ template <typename T> class Solver : public SolverBase {
     }
 
     // D(R x C) = sum_k A(r,k) B(c,k); R, C, Kdim are padded sizes.  Picks the block tile from R, C.
+    struct Seg {   // optional second operand segment (see GemmArgs)
+        const T *A2 = nullptr; int64_t lda2 = 0, r_split = INT64_MAX;
+        const T *B2 = nullptr; int64_t ldb2 = 0, c_split = INT64_MAX;
+    };
     template <int LA, int LB, typename Epi>
     void gemm(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim,
-              int splits, bool c_fastest, const Epi &epi, const int *done, double bytes = 0.0) {
+              int splits, bool c_fastest, const Epi &epi, const int *done, double bytes = 0.0, const Seg &seg = Seg()) {
         GemmArgs<T> g;
         g.A = A; g.B = B; g.lda = lda; g.ldb = ldb;
+        g.A2 = seg.A2; g.lda2 = seg.lda2; g.r_split = seg.r_split;
+        g.B2 = seg.B2; g.ldb2 = seg.ldb2; g.c_split = seg.c_split;
         g.splits = splits;
         g.kchunk = (int)(Kdim / splits);
         g.c_fastest = c_fastest ? 1 : 0;
@@ -343,39 +356,61 @@ template <typename T> class Solver : public SolverBase {
     }
 
     // ---- shared building blocks ------------------------------------------------
-    // numH = W' * Bmat   (K x N, ld K);  Bmat is X or Q (P x N).   src/multupd.jl:98,175; projals.jl:93
-    void wt_times(const T *Wp, const T *Bmat, T *dst, const int *done) {
+    void reduce_to(const char *name, T *dst, int64_t count, int nslab, const int *done) { reduce_slabs(name, dst, count, nslab, done); }
+
+    // numH = W' * Bmat  (K x N, ld K), Bmat = X or Q (P x N)      src/multupd.jl:98,175; projals.jl:93; alspgrad.jl:66
+    // with_gram: also gramW = W'W (src/projals.jl:92, alspgrad.jl:65) in the SAME launch: the A operand is the
+    // row-concatenation [Bmat ; W], the output the K x (N+K) matrix [numH | gramW].
+    void wt_times(const T *Wp, const T *Bmat, bool with_gram, const int *done) {
+        if (with_gram && fuse_gram && K % 128 == 0) {
+            EpiStore<T> e{slabs.p, K, (int64_t)K * (N + K), nullptr};
+            Seg sg;
+            sg.A2 = Wp; sg.lda2 = P; sg.r_split = N;
+            gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N + K, Wp, P, K, P, s_h, true, e, done,
+                                   (double)(P * N + 2 * P * K) * sizeof(T), sg);
+            reduce_slabs("reduce_WtX", hside.p, (int64_t)K * (N + K), s_h, done);
+            return;
+        }
         EpiStore<T> e{slabs.p, K, (int64_t)K * N, nullptr};
         gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                (double)(P * N + P * K) * sizeof(T));
-        reduce_slabs("reduce_WtX", dst, (int64_t)K * N, s_h, done);
+        reduce_slabs("reduce_WtX", numH_p, (int64_t)K * N, s_h, done);
+        if (with_gram) {
+            EpiStore<T> eg{slabs.p, K, (int64_t)K * K, nullptr};
+            gemm<KCONTIG, KCONTIG>("gemm_WtW", Wp, P, K, Wp, P, K, P, s_gw, true, eg, done, (double)(P * K) * sizeof(T));
+            reduce_slabs("reduce_WtW", gramW_p, (int64_t)K * K, s_gw, done);
+        }
     }
-    // gramW = W'W  (K x K).   src/projals.jl:92, src/alspgrad.jl:65
-    void gram_w(const T *Wp, const int *done) {
-        EpiStore<T> e{slabs.p, K, (int64_t)K * K, nullptr};
-        gemm<KCONTIG, KCONTIG>("gemm_WtW", Wp, P, K, Wp, P, K, P, s_gw, true, e, done, (double)(P * K) * sizeof(T));
-        reduce_slabs("reduce_WtW", gramW.p, (int64_t)K * K, s_gw, done);
-    }
-    // numW = Amat * H'  (P x K, ld P);  Amat is X or Q.   src/multupd.jl:109,187; projals.jl:101
-    void times_ht(const T *Amat, const T *Hp, T *dst, const int *done) {
+    // numW = Amat * H'  (P x K, ld P), Amat = X or Q              src/multupd.jl:109,187; projals.jl:101; alspgrad.jl:221
+    // with_gram: also gramH = HH' (src/projals.jl:100, alspgrad.jl:220) in the same launch: B operand = [Amat ; H],
+    // slab = [ numW (ld P) | gramH (ld K) ] = the layout of the packed all-reduce buffer.
+    void times_ht(const T *Amat, const T *Hp, bool with_gram, const int *done) {
+        if (with_gram && fuse_gram && K % 128 == 0) {
+            EpiStore2<T> e{slabs.p, P, P, K, (int64_t)P * K, (int64_t)P * K + (int64_t)K * K, nullptr};
+            Seg sg;
+            sg.B2 = Hp; sg.ldb2 = K; sg.c_split = P;
+            gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P + K, N, s_w, false, e, done,
+                                     (double)(P * N + 2 * K * N) * sizeof(T), sg);
+            reduce_slabs("reduce_XHt", pack.p, (int64_t)P * K + (int64_t)K * K, s_w, done);
+            return;
+        }
         EpiStore<T> e{slabs.p, P, (int64_t)P * K, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                  (double)(P * N + K * N) * sizeof(T));
-        reduce_slabs("reduce_XHt", dst, (int64_t)P * K, s_w, done);
-    }
-    // gramH = HH'  (K x K).   src/projals.jl:100, src/alspgrad.jl:220
-    void gram_h(const T *Hp, T *dst, const int *done) {
-        EpiStore<T> e{slabs.p, K, (int64_t)K * K, nullptr};
-        gemm<KSTRIDED, KSTRIDED>("gemm_HHt", Hp, K, K, Hp, K, K, N, s_gh, true, e, done, (double)(K * N) * sizeof(T));
-        reduce_slabs("reduce_HHt", dst, (int64_t)K * K, s_gh, done);
+        reduce_slabs("reduce_XHt", numW_p, (int64_t)P * K, s_w, done);
+        if (with_gram) {
+            EpiStore<T> eg{slabs.p, K, (int64_t)K * K, nullptr};
+            gemm<KSTRIDED, KSTRIDED>("gemm_HHt", Hp, K, K, Hp, K, K, N, s_gh, true, eg, done, (double)(K * N) * sizeof(T));
+            reduce_slabs("reduce_HHt", gramH_p, (int64_t)K * K, s_gh, done);
+        }
     }
 
     void stats_w(const T *Wn, const T *Wo, const int *done) {
         timed("stats_W", 0.0, 2.0 * P * K * sizeof(T), [&] {
             hipLaunchKernelGGL(col_stats_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wn, Wo, P, P,
                                (int)K, stat_part.p, done);
-            hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)((2 * K + 255) / 256)), dim3(256), 0, stream,
-                               stat_part.p, stat_chunks_w, (int)K, wstat.p, done);
+            hipLaunchKernelGGL(finalize_partials_kernel<double>, dim3((unsigned)((2 * K + 3) / 4)), dim3(256), 0, stream,
+                               stat_part.p, stat_chunks_w, (int)(2 * K), (int)(2 * K), wstat.p, done);
             HIP_TRY(hipGetLastError());
         });
     }
@@ -383,8 +418,8 @@ template <typename T> class Solver : public SolverBase {
         timed("stats_H", 0.0, 2.0 * K * N * sizeof(T), [&] {
             hipLaunchKernelGGL(row_stats_kernel<T>, dim3(stat_chunks_h), dim3(256), 0, stream, Hn, Ho, N, K, (int)K,
                                stat_part.p, done);
-            hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)((2 * K + 255) / 256)), dim3(256), 0, stream,
-                               stat_part.p, stat_chunks_h, (int)K, hstat.p, done);
+            hipLaunchKernelGGL(finalize_partials_kernel<double>, dim3((unsigned)((2 * K + 3) / 4)), dim3(256), 0, stream,
+                               stat_part.p, stat_chunks_h, (int)(2 * K), (int)(2 * K), hstat.p, done);
             HIP_TRY(hipGetLastError());
         });
     }

@@ -81,18 +81,16 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
         const T *Wp = W[wcur].p;
         const T *Ho = H[hcur].p;
         T *Hn = H[hcur ^ 1].p;
-        wt_times(Wp, X.p, numH.p, done);                                   // :98
-        gram_w(Wp, done);
-        EpiMultUpdate<T> e{numH.p, Ho, Hn, K, (T)o.lambda_h, (T)o.delta};  // :99-103
-        gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW.p, K, K, K, 1, true, e, done, 3.0 * K * N * sizeof(T));
+        wt_times(Wp, X.p, true, done);                                     // :98  (+ W'W in the same launch)
+        EpiMultUpdate<T> e{numH_p, Ho, Hn, K, (T)o.lambda_h, (T)o.delta};  // :99-103
+        gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, 3.0 * K * N * sizeof(T));
         stats_h(Hn, Ho, done);
         hcur ^= 1;
     }
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
-    times_ht(X.p, Hp, numW_p, done);                                       // :109
-    gram_h(Hp, gramH_p, done);
+    times_ht(X.p, Hp, true, done);                                         // :109 (+ HH' in the same launch)
     allreduce_w_side(o.update_H != 0, done);
     EpiMultUpdate<T> e{numW_p, Wo, Wn, P, (T)o.lambda_w, (T)o.delta};      // :110-114
     gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo, P, P, K, 1, false, e, done, 3.0 * P * K * sizeof(T));
@@ -115,16 +113,16 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
         T *Hn = H[hcur ^ 1].p;
         EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                           // :172-174
         gemm<KCONTIG, KSTRIDED>("gemm_WH_ratio", Ho, K, N, Wp, P, P, K, 1, true, er, done, qbytes);
-        wt_times(Wp, Q.p, numH.p, done);                                   // :175
+        wt_times(Wp, Q.p, false, done);                                    // :175
         timed("colsum_W", 0.0, (double)P * K * sizeof(T), [&] {            // :176
             hipLaunchKernelGGL(col_sum_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wp, P, P, (int)K,
                                stat_part.p, done);
-            hipLaunchKernelGGL(finalize_sum_kernel<T>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, stream, stat_part.p,
-                               stat_chunks_w, (int)K, svec.p, done);
+            hipLaunchKernelGGL(finalize_partials_kernel<T>, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, stream, stat_part.p,
+                               stat_chunks_w, (int)K, (int)K, svec.p, done);
         });
         timed("div_update_H", 0.0, 3.0 * K * N * sizeof(T), [&] {           // :177-179
             hipLaunchKernelGGL(div_update_kernel<T>, dim3((unsigned)((K + 255) / 256), (unsigned)N), dim3(256), 0, stream, Hn,
-                               Ho, numH.p, svec.p, K, N, K, (T)o.lambda_h, 1, done);
+                               Ho, numH_p, svec.p, K, N, K, (T)o.lambda_h, 1, done);
         });
         stats_h(Hn, Ho, done);
         hcur ^= 1;
@@ -134,12 +132,12 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
     T *Wn = W[wcur ^ 1].p;
     EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                               // :184-186
     gemm<KCONTIG, KSTRIDED>("gemm_WH_ratio", Hp, K, N, Wo, P, P, K, 1, true, er, done, qbytes);
-    times_ht(Q.p, Hp, numW_p, done);                                       // :187
+    times_ht(Q.p, Hp, false, done);                                        // :187
     T *sH = sH_p;                                                          // tail of the packed buffer
     timed("rowsum_H", 0.0, (double)K * N * sizeof(T), [&] {                // :188
         hipLaunchKernelGGL(row_sum_kernel<T>, dim3(stat_chunks_h), dim3(256), 0, stream, Hp, N, K, (int)K, stat_part.p, done);
-        hipLaunchKernelGGL(finalize_sum_kernel<T>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, stream, stat_part.p,
-                           stat_chunks_h, (int)K, sH, done);
+        hipLaunchKernelGGL(finalize_partials_kernel<T>, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, stream, stat_part.p,
+                           stat_chunks_h, (int)K, (int)K, sH, done);
     });
     allreduce_w_side(o.update_H != 0, done);
     timed("div_update_W", 0.0, 3.0 * P * K * sizeof(T), [&] {               // :189-191

@@ -9,7 +9,7 @@ def run(p, n, k, T, alg_name, iters=10, maxsub=200):
     rng = np.random.default_rng(0)
     t0 = time.time()
     Wg = rng.random((p, k), dtype=np.float32); Hg = rng.random((k, n), dtype=np.float32)
-    X = np.asfortranarray((Wg @ Hg).astype(T).T).T if False else np.asfortranarray((Wg @ Hg).astype(T))
+    X = np.asfortranarray(rng.random((p, n), dtype=np.float32).astype(T)) if alg_name == "projals" else np.asfortranarray((Wg @ Hg).astype(T))
     W0 = rng.random((p, k)).astype(T)
     if alg_name != 'projals': W0 /= W0.sum(0, keepdims=True)
     W0 = np.asfortranarray(W0)
@@ -19,7 +19,7 @@ def run(p, n, k, T, alg_name, iters=10, maxsub=200):
     with nmfx.Context(T, p, n, k) as ctx:
         t0 = time.time(); ctx.set_X(X); print(f"upload X {time.time()-t0:.2f}s", flush=True)
         ctx.set_factors(W0, H0)
-        lam = {"multdiv": 3.5e-4, "projals": 4.9e-3}.get(alg_name, 0.0)
+        lam = {"multdiv": 3.5e-4, "projals": 0.5}.get(alg_name, 0.0)
         o = nmfx.make_opts(T, maxiter=3, tol=1e-30, check_every=1000, lambda_w=lam, lambda_h=lam, maxsubiter=maxsub)
         ctx.iterate(algs[alg_name], o)  # warmup
         o.maxiter = iters

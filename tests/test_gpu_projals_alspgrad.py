@@ -12,7 +12,7 @@ import pytest
 import c_oracle as co
 import nmf_oracle as orc
 import nmfx
-from problems import planted, rel_trace_err
+from problems import planted, rel_trace_err, uniform
 
 pytestmark = pytest.mark.gpu
 TOL = {np.float64: 1e-7, np.float32: 2e-3}
@@ -109,3 +109,23 @@ def test_update_H_false(built, alg_name, T):
     W, H = W0.copy(order="F"), H0.copy(order="F")
     nmfx.solve(alg, X, W, H)
     assert np.array_equal(H, H0) and np.any(W != W0)
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("k", [96, 256])
+def test_projals_large_k(built, T, k):
+    """k = 256 exercises every block step of the LDS-blocked potrf/trtri (8 panels of 32) and the K%128 GEMM tiles."""
+    p, n = 640, 900
+    X, W0, H0 = uniform(p, n, k, T, seed=k)      # X ~ U[0,1): Grams stay well conditioned in f32 (CPU pair drift 6e-5)
+    lam = 0.5
+    alg = nmfx.ProjectedALS(T, maxiter=6, tol=1e-30, lambda_w=lam, lambda_h=lam)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg, track_objective=True)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=6, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+    rc = co.solve("projals", X, W0.copy(order="F"), H0.copy(order="F"),
+                  orc.Opts(maxiter=6, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+    tol = max(TOL[T], 3 * rel_trace_err(rc.trace, ro.trace))
+    assert r.niters == ro.niters
+    assert rel_trace_err(r.trace, ro.trace) < tol
+    assert np.max(np.abs(Wg - Wc)) <= 50 * tol * np.max(np.abs(Wc))

@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "gemm_mfma.hpp"
 #include "kernels.hpp"
 
 namespace nmfx {
@@ -20,92 +21,163 @@ namespace nmfx {
 __device__ __forceinline__ float nmfx_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double nmfx_sqrt(double x) { return sqrt(x); }
 
-template <typename T> __device__ __forceinline__ T wave_bcast(T v, int src) { return __shfl(v, src, 64); }
+// wave-uniform broadcast of lane `src` (compile-time constant): v_readlane, no LDS crossbar round trip
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 
 // A: k x k leading block of a column-major matrix with leading dimension ld.  On a non-positive pivot sets
 // ctrl->status = posdef_status and ctrl->done = 1 (PosDefException of potrf!, src/utils.jl:68,78).
-// Dynamic LDS: NB*NB (diagonal block) + NB*k (row panel) elements of T + 16 bytes.
-template <typename T, int NB>
+// Dynamic LDS: 32*32 (diagonal block) + 32*kp (row panel, kp = k rounded up to 32) elements of T + 16 bytes.
+// Per 32-column panel:  (1) wave 0 factors the diagonal block in registers (lane = column, v_readlane
+// broadcasts);  (2) the 32 x m row panel is staged through LDS with coalesced loads and solved one column per
+// thread;  (3) the trailing update A22 -= R'R runs on the matrix cores (MFMA 32x32x2 f32 / 16x16x4 f64) with
+// both operands read from the LDS panel -- the same [k][row] image the GEMM template calls KSTRIDED.
+template <typename T>
 __global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int k, Ctrl *ctrl, int posdef_status) {
     if (ctrl != nullptr && ctrl->done) return;
+    using M = Mfma<T>;
+    constexpr int NB = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
-    T *U11 = reinterpret_cast<T *>(chol_smem);          // U11[l*NB + i] = U(jb+l, jb+i)
-    T *Rp = U11 + NB * NB;                              // Rp[l*k + c]   = U(jb+l, jb+nb+c)
-    int *failp = reinterpret_cast<int *>(chol_smem + (((size_t)(NB * NB + NB * (size_t)k) * sizeof(T) + 15) / 16) * 16);
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int kp = (k + 31) / 32 * 32;
+    T *U11 = reinterpret_cast<T *>(chol_smem);          // U11[i*NB + l] = U(jb+l, jb+i)  (transposed copy)
+    T *Rp = U11 + NB * NB;                              // Rp[l*kp + c]  = U(jb+l, jb+nb+c), zero for c >= m
+    int *failp = reinterpret_cast<int *>(chol_smem + (((size_t)(NB * NB + NB * (size_t)kp) * sizeof(T) + 15) / 16) * 16);
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
     if (tid == 0) *failp = 0;
     __syncthreads();
+#ifdef NMFX_POTRF_TIMING
+    extern __device__ long long nmfx_potrf_dbg[];
+#define PT(i) if (tid == 0) nmfx_potrf_dbg[(jb / NB) * 8 + (i)] = (long long)__builtin_readcyclecounter();
+#else
+#define PT(i)
+#endif
     for (int jb = 0; jb < k; jb += NB) {
         const int nb = (k - jb < NB) ? (k - jb) : NB;
         const int m = k - jb - nb;
+        const int mp = (m + 31) / 32 * 32;
+        PT(0)
+        // stage the row panel (nb x m) into LDS, zero-padded to (NB x mp): thread <-> (l = tid%32, c = tid/32 + ...)
+        for (int e = tid; e < NB * mp; e += nt) {
+            const int l = e % NB, c = e / NB;
+            Rp[l * kp + c] = (l < nb && c < m) ? A[(jb + l) + (int64_t)(jb + nb + c) * ld] : (T)0;
+        }
         if (wave == 0) {
-            // lane c holds column c of the diagonal block (rows 0..c)
+            // lane c holds column c of the diagonal block (rows 0..c); a partial block is padded with the identity so
+            // the 32 elimination steps below are branch-free straight-line code (entries with r > lane are never
+            // used: they may hold garbage).
             T col[NB];
 #pragma unroll
-            for (int r = 0; r < NB; ++r)
-                col[r] = (lane < nb && r <= lane) ? A[(jb + r) + (int64_t)(jb + lane) * ld] : (T)0;
+            for (int r = 0; r < NB; ++r) {
+                const bool in = (lane < nb) && (r <= lane);
+                col[r] = in ? A[(jb + r) + (int64_t)(jb + (in ? lane : 0)) * ld] : ((r == lane) ? (T)1 : (T)0);
+            }
             bool bad = false;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if (j < nb && !bad) {
-                    const T d = wave_bcast(col[j], j);
-                    if (!(d > (T)0)) {
-                        bad = true;
-                    } else {
-                        const T dj = nmfx_sqrt(d);
-                        if (lane == j) col[j] = dj;
-                        else if (lane > j) col[j] = col[j] / dj;
+                const T d = lane_bcast(col[j], j);
+                bad = bad || !(d > (T)0);
+                const T dj = nmfx_sqrt(d);
+                col[j] = (lane == j) ? dj : col[j] / dj;
 #pragma unroll
-                        for (int r = j + 1; r < NB; ++r) {
-                            const T ujr = wave_bcast(col[j], r);
-                            if (lane >= r) col[r] -= ujr * col[j];
-                        }
-                    }
-                }
+                for (int r = j + 1; r < NB; ++r) col[r] -= lane_bcast(col[j], r) * col[j];
             }
 #pragma unroll
             for (int r = 0; r < NB; ++r)
                 if (lane < nb && r <= lane) {
                     A[(jb + r) + (int64_t)(jb + lane) * ld] = col[r];
-                    U11[r * NB + lane] = col[r];
+                    U11[lane * NB + r] = col[r];       // TRANSPOSED: U11[i*NB + l] = U(jb+l, jb+i), l contiguous
                 }
             if (bad && lane == 0) *failp = 1;
+            PT(1)
         }
         __syncthreads();
+        PT(2)
         if (*failp) break;
-        // row panel: solve U11' R' = R, one column per thread
+        // row panel: solve U11' R' = R in LDS, one column per thread (consecutive threads -> consecutive LDS words);
+        // the factor is read as 16-byte broadcast vectors along l (4 f32 / 2 f64 per ds_read_b128)
         for (int c = tid; c < m; c += nt) {
+            using vec_t = typename M::vec_t;
+            constexpr int V = M::VEC;
             T x[NB];
-            T *colp = A + jb + (int64_t)(jb + nb + c) * ld;
 #pragma unroll
-            for (int l = 0; l < NB; ++l) x[l] = (l < nb) ? colp[l] : (T)0;
+            for (int l = 0; l < NB; ++l) x[l] = Rp[l * kp + c];
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                if (i < nb) {
-                    T s = x[i];
+                T s = x[i];
 #pragma unroll
-                    for (int l = 0; l < i; ++l) s -= U11[l * NB + i] * x[l];
-                    x[i] = s / U11[i * NB + i];
+                for (int l0 = 0; l0 < i; l0 += V) {
+                    const vec_t u = *reinterpret_cast<const vec_t *>(U11 + i * NB + l0);
+#pragma unroll
+                    for (int q = 0; q < V; ++q)
+                        if (l0 + q < i) s -= u[q] * x[l0 + q];
                 }
+                const T dii = U11[i * NB + i];
+                x[i] = (i < nb) ? s / dii : s;
             }
 #pragma unroll
-            for (int l = 0; l < NB; ++l)
-                if (l < nb) {
-                    colp[l] = x[l];
-                    Rp[l * k + c] = x[l];
-                }
+            for (int l = 0; l < NB; ++l) Rp[l * kp + c] = x[l];
         }
         __syncthreads();
-        // trailing update A22 -= R'R (upper part)
-        for (int idx = tid; idx < m * m; idx += nt) {
-            const int r = idx % m, c = idx / m;
-            if (r <= c) {
-                T s = (T)0;
-                for (int l = 0; l < nb; ++l) s += Rp[l * k + r] * Rp[l * k + c];
-                A[(jb + nb + r) + (int64_t)(jb + nb + c) * ld] -= s;
+        PT(3)
+        // write the solved panel back (coalesced along l) ...
+        for (int e = tid; e < NB * m; e += nt) {
+            const int l = e % NB, c = e / NB;
+            if (l < nb) A[(jb + l) + (int64_t)(jb + nb + c) * ld] = Rp[l * kp + c];
+        }
+        // ... and update the trailing matrix on the matrix cores: for tiles (ti <= tj) of size MT x MT
+        //   A22(ri, cj) -= sum_l R'(l, ri) R'(l, cj).   MFMA lanes run along the matrix ROW index (contiguous in memory).
+        {
+            constexpr int MT = M::MT, KS = M::KS;
+            const int nt_t = mp / MT;
+            const int ntiles = nt_t * (nt_t + 1) / 2;
+            for (int tile = wave; tile < ntiles; tile += nwaves) {
+                // unrank (ti <= tj) from the linear index over the upper triangle, row by row of tj
+                int tj = 0, rem = tile;
+                while (rem > tj) { rem -= tj + 1; ++tj; }
+                const int ti = rem;
+                typename M::acc_t acc;
+#pragma unroll
+                for (int r = 0; r < M::NACC; ++r) acc[r] = (T)0;
+                const int ks = lane / MT, li = lane % MT;
+#pragma unroll
+                for (int kk = 0; kk < NB / KS; ++kk) {
+                    const T a = Rp[(kk * KS + ks) * kp + tj * MT + li];   // D rows <-> matrix column index cj
+                    const T b = Rp[(kk * KS + ks) * kp + ti * MT + li];   // D cols (lanes) <-> matrix row index ri
+                    acc = M::mma(a, b, acc);
+                }
+                const int ri = ti * MT + li;
+                // read-modify-write of the tile: all loads first, then all stores (A aliases itself, so an
+                // interleaved load/sub/store chain would serialise 16 global round trips)
+                T oldv[M::NACC];
+                T *base = A + (jb + nb + ri) + (int64_t)(jb + nb) * ld;
+#pragma unroll
+                for (int reg = 0; reg < M::NACC; ++reg) {
+                    int rr;
+                    if constexpr (sizeof(T) == 4) rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    else rr = (lane >> 4) + 4 * reg;
+                    const int cj = tj * MT + rr;
+                    oldv[reg] = (ri <= cj && cj < m) ? base[(int64_t)cj * ld] : (T)0;
+                }
+#pragma unroll
+                for (int reg = 0; reg < M::NACC; ++reg) {
+                    int rr;
+                    if constexpr (sizeof(T) == 4) rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    else rr = (lane >> 4) + 4 * reg;
+                    const int cj = tj * MT + rr;
+                    if (ri <= cj && cj < m) base[(int64_t)cj * ld] = oldv[reg] - acc[reg];
+                }
             }
         }
+        PT(4)
         __syncthreads();
+        PT(5)
     }
     if (*failp && tid == 0 && ctrl != nullptr) {
         ctrl->status = posdef_status;

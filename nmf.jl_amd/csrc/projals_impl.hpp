@@ -18,24 +18,21 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     work[1].ensure(kk);              // Uinv
     work[2].ensure(kk);              // inv(HH' + lw I)
     T *Y = work[0].p, *Uinv = work[1].p, *invA = work[2].p;
-    // potrf: NB x NB diagonal block + NB x k row panel in LDS; pick the widest panel that fits 160 KiB
-    const size_t lds32 = ((size_t)(32 * 32 + 32 * (size_t)k) * sizeof(T) + 15) / 16 * 16 + 16;
-    const size_t lds8 = ((size_t)(8 * 8 + 8 * (size_t)k) * sizeof(T) + 15) / 16 * 16 + 16;
+    // potrf: 32 x 32 diagonal block + 32 x kp row panel in LDS (kp = k rounded up to 32)
+    const size_t kp32 = (size_t)(k + 31) / 32 * 32;
+    const size_t lds32 = ((size_t)(32 * 32 + 32 * kp32) * sizeof(T) + 15) / 16 * 16 + 16;
     const size_t lds_tri = ((size_t)((k + 3) / 4 * 4 + 32 * 32 + 32) * sizeof(T) + 15) / 16 * 16;
-    if (lds8 > 160 * 1024) throw StatusError{NMFX_ERR_UNSUPPORTED, "projals: k too large for the single-workgroup Cholesky"};
-    auto factor = [&](T *A, T lambda, const char *tag) {
-        timed(tag, (double)k * k * k / 3.0, 0.0, [&] {
+    if (lds32 > 160 * 1024) throw StatusError{NMFX_ERR_UNSUPPORTED, "projals: k too large for the single-workgroup Cholesky panel (k <= 1248 f32 / 608 f64)"};
+    auto factor = [&](T *A, T lambda, const char *tag_potrf, const char *tag_trtri) {
+        timed(tag_potrf, (double)k * k * k / 3.0, 0.0, [&] {
             if (lambda != (T)0)   // adddiag! skips lambda == 0 (src/utils.jl:18)
                 hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, A, K, (int)k, lambda, done);
-            if (lds32 <= 150 * 1024) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_upper_kernel<T, 32>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
-                hipLaunchKernelGGL((potrf_upper_kernel<T, 32>), dim3(1), dim3(1024), lds32, stream, A, K, (int)k, ctrl, (int)NMFX_ERR_NOT_POSDEF);
-            } else {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_upper_kernel<T, 8>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-                hipLaunchKernelGGL((potrf_upper_kernel<T, 8>), dim3(1), dim3(1024), lds8, stream, A, K, (int)k, ctrl, (int)NMFX_ERR_NOT_POSDEF);
-            }
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_upper_kernel<T>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+            hipLaunchKernelGGL((potrf_upper_kernel<T>), dim3(1), dim3(1024), lds32, stream, A, K, (int)k, ctrl, (int)NMFX_ERR_NOT_POSDEF);
+            HIP_TRY(hipGetLastError());
+        });
+        timed(tag_trtri, (double)k * k * k / 3.0, 0.0, [&] {
             HIP_TRY(hipMemsetAsync(Uinv, 0, kk * sizeof(T), stream));
             hipLaunchKernelGGL((trtri_upper_kernel<T, 32>), dim3((unsigned)k), dim3(64), lds_tri, stream, A, Uinv, K, (int)k, done);
             HIP_TRY(hipGetLastError());
@@ -46,7 +43,7 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
         const T *Ho = H[hcur].p;
         T *Hn = H[hcur ^ 1].p;
         wt_times(Wp, X.p, true, done);                                     // :92 W'W, :93 H <- W'X (one launch)
-        factor(gramW_p, (T)o.lambda_h, "potrf_trtri_WtW");                 // :92 adddiag!, :94 potrf!
+        factor(gramW_p, (T)o.lambda_h, "potrf_WtW", "trtri_WtW");                 // :92 adddiag!, :94 potrf!
         {   // :94 potrs!:  Y = Uinv' B ;  H = max(0, Uinv Y)   (:95 projectnn!)
             EpiStore<T> e1{Y, K, 0, nullptr};
             gemm<KCONTIG, KCONTIG>("gemm_UinvtB", numH_p, K, N, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * N * sizeof(T));
@@ -61,7 +58,7 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     T *Wn = W[wcur ^ 1].p;
     times_ht(X.p, Hp, true, done);                                         // :100 HH', :101 XH' (one launch)
     allreduce_w_side(o.update_H != 0, done);
-    factor(gramH_p, (T)o.lambda_w, "potrf_trtri_HHt");                     // :100 adddiag!, :102 potrf!
+    factor(gramH_p, (T)o.lambda_w, "potrf_HHt", "trtri_HHt");                     // :100 adddiag!, :102 potrf!
     {   // :102 potri! + copytri!: inv = Uinv Uinv' ; then W = max(0, XHt * inv)   (:103 projectnn!)
         EpiStore<T> e1{invA, K, 0, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_potri", Uinv, K, K, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * K * sizeof(T));

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include <type_traits>
+#include <utility>
 
 namespace nmfx {
 
@@ -68,6 +70,8 @@ template <typename T> struct GemmArgs {
     const T *B2 = nullptr;
     int64_t lda2 = 0, ldb2 = 0;
     int64_t r_split = INT64_MAX, c_split = INT64_MAX;
+    int stagger = 0;        // >0: waves in odd SIMD slots sleep 64*stagger cycles at entry (de-phases the two co-resident blocks)
+    int prio = 0;           // 1: raise wave priority around MFMA groups
 };
 
 // XOR swizzle of the 16-byte chunk position inside a KCONTIG LDS row (8 chunks/row):
@@ -130,6 +134,23 @@ __device__ __forceinline__ void read_frag(T (&out)[Mfma<T>::VEC], const T *lds, 
     }
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl<N>(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+// N x { 2 MFMA, 1 instruction of class MASK } in issue order (LLVM sched_group_barrier)
+template <int MASK, int N> __device__ __forceinline__ void sched_pairs() {
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(MASK, 1, 0);
+        sched_pairs<MASK, N - 1>();
+    }
+}
+
 template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi>
 __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g, Epi epi) {
     using M = Mfma<T>;
@@ -142,6 +163,12 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     using LoadB = TileLoader<T, LB, BC, NT>;
 
     if (g.done != nullptr && *reinterpret_cast<const volatile int *>(g.done) != 0) return;
+    if (g.stagger > 0) {
+        // HW_REG_HW_ID (id 4): bits [3:0] = wave slot within the SIMD
+        const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
+        if (slot & 1)
+            for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
 
     __shared__ __attribute__((aligned(16))) T smem[2 * (BR + BC) * BK];
     constexpr int STAGE = (BR + BC) * BK;   // stage s: A tile at smem + s*STAGE, B tile right behind it
@@ -177,38 +204,63 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) acc[i][j][r] = (T)0;
 
+    // Software pipeline (one barrier per k-tile, no MFMA-free phase besides it):
+    //   registers hold k-tile t+1 while the MFMAs of tile t run out of LDS stage t&1;
+    //   first half of the k-groups : registers -> LDS stage (t+1)&1   (ds_write interleaved with MFMAs)
+    //   second half                : global   -> registers, tile t+2  (loads interleaved with MFMAs)
+    // Stage (t+1)&1 was last read during tile t-1, i.e. before the barrier that ended iteration t-1.
     typename M::vec_t ra[LoadA::PER_THREAD], rb[LoadB::PER_THREAD];
     LoadA::load(ra, Ab, lda, ra0, kbeg, tid);
     LoadB::load(rb, Bb, ldb, cb0, kbeg, tid);
     LoadA::store(ra, smem, tid);
     LoadB::store(rb, smem + BR * BK, tid);
+    {
+        const int64_t k1 = kbeg + (int64_t)((nk > 1) ? 1 : 0) * BK;
+        LoadA::load(ra, Ab, lda, ra0, k1, tid);
+        LoadB::load(rb, Bb, ldb, cb0, k1, tid);
+    }
     __syncthreads();
 
+    constexpr int NG = BK / 8;   // k-groups per tile
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nk) {   // prefetch the next k-tile into registers; lands while the MFMAs run
-            LoadA::load(ra, Ab, lda, ra0, kbeg + (int64_t)(t + 1) * BK, tid);
-            LoadB::load(rb, Bb, ldb, cb0, kbeg + (int64_t)(t + 1) * BK, tid);
-        }
         const T *a_s = smem + cur * STAGE, *b_s = a_s + BR * BK;
-#pragma unroll
-        for (int kg = 0; kg < BK / 8; ++kg) {
+        T *a_n = smem + (cur ^ 1) * STAGE, *b_n = a_n + BR * BK;
+        const int tn = (t + 2 < nk) ? t + 2 : nk - 1;   // clamped: the last iterations re-load the final tile (never used)
+        const int64_t kn = kbeg + (int64_t)tn * BK;
+        static_for<NG>([&](auto KGC) {
+            constexpr int kg = decltype(KGC)::value;
             T af[TR][M::VEC], bf[TC][M::VEC];
 #pragma unroll
             for (int i = 0; i < TR; ++i) read_frag<T, LA, BR>(af[i], a_s, wr * WTR + i * MT, kg, lane);
 #pragma unroll
             for (int j = 0; j < TC; ++j) read_frag<T, LB, BC>(bf[j], b_s, wc * WTC + j * MT, kg, lane);
+            constexpr bool stA = (kg == 0), stB = (kg == (NG > 2 ? 1 : 0));
+            constexpr bool ldA = (kg == NG / 2), ldB = (kg == (NG > 2 ? NG / 2 + 1 : NG / 2));
+            if constexpr (stA) LoadA::store(ra, a_n, tid);
+            if constexpr (stB) LoadB::store(rb, b_n, tid);
+            if constexpr (ldA) LoadA::load(ra, Ab, lda, ra0, kn, tid);
+            if constexpr (ldB) LoadB::load(rb, Bb, ldb, cb0, kn, tid);
 #pragma unroll
             for (int q = 0; q < M::VEC; ++q)
 #pragma unroll
                 for (int i = 0; i < TR; ++i)
 #pragma unroll
                     for (int j = 0; j < TC; ++j) acc[i][j] = M::mma(af[i][q], bf[j][q], acc[i][j]);
-        }
-        if (t + 1 < nk) {
-            LoadA::store(ra, smem + (cur ^ 1) * STAGE, tid);
-            LoadB::store(rb, smem + (cur ^ 1) * STAGE + BR * BK, tid);
-        }
+            // Issue-order template for this k-group (LLVM sched_group_barrier; masks: MFMA 0x8, VMEM read 0x20,
+            // DS read 0x100, DS write 0x200): fragment reads first, then the staging traffic of this group spread
+            // one instruction per MFMA pair, so neither the LDS writes nor the global loads open an MFMA-free window.
+            constexpr int NMFMA = M::VEC * TR * TC;
+            constexpr int NFRAG = (LA == KCONTIG ? TR : TR * M::VEC) + (LB == KCONTIG ? TC : TC * M::VEC);
+            constexpr int NW0 = (stA ? LoadA::PER_THREAD : 0) + (stB ? LoadB::PER_THREAD : 0);
+            constexpr int NL0 = (ldA ? LoadA::PER_THREAD : 0) + (ldB ? LoadB::PER_THREAD : 0);
+            constexpr int NW = (2 * NW0 <= NMFMA) ? NW0 : NMFMA / 2;
+            constexpr int NL = (2 * (NW + NL0) <= NMFMA) ? NL0 : (NMFMA / 2 - NW);
+            __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
+            sched_pairs<0x200, NW>();
+            sched_pairs<0x20, NL>();
+            if constexpr (NMFMA - 2 * (NW + NL) > 0) __builtin_amdgcn_sched_group_barrier(0x8, NMFMA - 2 * (NW + NL), 0);
+        });
         __syncthreads();
     }
 

@@ -1,0 +1,82 @@
+// Development micro-benchmark for the MFMA GEMM template at the bench shapes (not part of the product build).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I nmf.jl_amd/csrc scripts/kbench/gemm_bench.hip -o scripts/kbench/gemm_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include "gemm_mfma.hpp"
+using namespace nmfx;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+static int g_mode = 0, g_stagger = 0;
+template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC>
+double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool c_fastest, int reps) {
+    // A: R rows, B: C rows; KCONTIG -> ld = Kd, KSTRIDED -> ld = rows
+    const int64_t lda = (LA == KCONTIG) ? Kd : R, ldb = (LB == KCONTIG) ? Kd : C;
+    T *A, *B, *D;
+    CK(hipMalloc(&A, (size_t)R * Kd * sizeof(T))); CK(hipMalloc(&B, (size_t)C * Kd * sizeof(T)));
+    CK(hipMalloc(&D, (size_t)R * C * splits * sizeof(T)));
+    std::vector<T> h((size_t)std::max(R, C) * Kd);
+    // g_mode 0: signed U[-.5,.5) both; 1: U[0,1) both; 2: solver-like (big operand ~64*U, small operand ~U/16384)
+    const bool a_big = R >= C;
+    for (auto &v : h) { double u = rand() / (double)RAND_MAX; v = (T)(g_mode == 0 ? u - 0.5 : g_mode == 1 ? u : (a_big ? 64.0 * u : u / 16384.0)); }
+    CK(hipMemcpy(A, h.data(), (size_t)R * Kd * sizeof(T), hipMemcpyHostToDevice));
+    for (auto &v : h) { double u = rand() / (double)RAND_MAX; v = (T)(g_mode == 0 ? u - 0.5 : g_mode == 1 ? u : (a_big ? u / 16384.0 : 64.0 * u)); }
+    CK(hipMemcpy(B, h.data(), (size_t)C * Kd * sizeof(T), hipMemcpyHostToDevice));
+    GemmArgs<T> g;
+    g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.tiles_r = (int)(R / BR); g.tiles_c = (int)(C / BC);
+    g.splits = splits; g.kchunk = (int)(Kd / splits); g.c_fastest = c_fastest; g.done = nullptr; g.stagger = 0; g.prio = g_stagger;
+    EpiStore<T> e{D, C, R * C, nullptr};
+    const int blocks = g.tiles_r * g.tiles_c * splits;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, EpiStore<T>>), dim3(blocks), dim3(WGR * WGC * 64), 0, 0, g, e);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (i > 0) best = std::min(best, ms);
+    }
+    CK(hipGetLastError());
+    // spot check a few entries against fp64
+    std::vector<T> hA((size_t)R * Kd), hB((size_t)C * Kd), hD((size_t)R * C * splits);
+    CK(hipMemcpy(hA.data(), A, hA.size() * sizeof(T), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hB.data(), B, hB.size() * sizeof(T), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hD.data(), D, hD.size() * sizeof(T), hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int s = 0; s < 64; ++s) {
+        const int64_t r = (rand() % R), c = (rand() % C);
+        double ref = 0;
+        for (int64_t kk = 0; kk < Kd; ++kk) {
+            const double a = (LA == KCONTIG) ? hA[r * lda + kk] : hA[kk * lda + r];
+            const double b = (LB == KCONTIG) ? hB[c * ldb + kk] : hB[kk * ldb + c];
+            ref += a * b;
+        }
+        double got = 0;
+        for (int sp = 0; sp < splits; ++sp) got += hD[(size_t)sp * R * C + c + r * C];
+        maxerr = std::max(maxerr, std::fabs(got - ref) / (std::fabs(ref) + 1e-30));
+    }
+    const double tf = 2.0 * R * C * Kd / (best * 1e-3) / 1e12;
+    printf("%-28s R=%lld C=%lld K=%lld splits=%d blocks=%d: %.1f us  %.1f TF/s  maxerr %.2e\n", name, (long long)R, (long long)C,
+           (long long)Kd, splits, blocks, best * 1e3, tf, maxerr);
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(D));
+    return tf;
+}
+
+int main(int argc, char **argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 6;
+    g_mode = 1;
+    for (int st : {0}) {
+    g_stagger = st;
+    printf("--- ablate bits %d (2: no global loads, 4: same frags every k-group (1 ds_read set/tile still per group), 8: no ds_write, 16: no barrier)\n", st);
+    run<float, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN big (WtX) 128x128", 16384, 256, 16384, 2, true, reps);
+    run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT big (XHt) 128x128", 256, 16384, 16384, 2, false, reps);
+    run<float, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN shard/8 128x128", 2048, 256, 16384, 16, true, reps);
+    run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT shard/8 128x128", 256, 16384, 2048, 2, false, reps);
+    run<float, KCONTIG, KCONTIG, 256, 64, 4, 1>("TN C2 (k=64) 256x64", 4096, 64, 4096, 8, true, reps);
+    run<float, KSTRIDED, KSTRIDED, 64, 256, 1, 4>("NT C2 (k=64) 64x256", 64, 4096, 4096, 8, false, reps);
+    run<double, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN f64 128x128", 8192, 256, 8192, 4, true, reps);
+    run<double, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT f64 128x128", 256, 8192, 8192, 4, false, reps);
+    }
+    return 0;
+}

@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--alg", default="multmse", choices=["multmse", "multdiv", "projals"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket launches with hipEvents (no roofline object)")
+    ap.add_argument("--all-events", action="store_true", help="hipEvent pair around every launch (per-kernel table; slows the loop ~4%%)")
     ap.add_argument("--cpu-sample-cols", type=int, default=1024)
     return ap.parse_args()
 
@@ -113,14 +115,15 @@ def main():
 
     if a.warmup > 0:
         ctx.iterate(algid, opts(a.warmup))
-    ctx.profile_enable(True)            # hipEvent pair around every launch on the solver stream
+    # hipEvent pairs on the solver stream around the dominant GEMM launches (1 in 4 sampled: a pair costs ~10 us)
+    ctx.profile_enable(0 if a.no_events else (1 if a.all_events else 2))
     barrier()
     t0 = time.perf_counter()
     res, _ = ctx.iterate(algid, opts(a.steps))
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_get()
-    ctx.profile_enable(False)
+    ctx.profile_enable(0)
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=device, dtype=torch.float64)

@@ -70,8 +70,17 @@ template <typename T> struct GemmArgs {
     const T *B2 = nullptr;
     int64_t lda2 = 0, ldb2 = 0;
     int64_t r_split = INT64_MAX, c_split = INT64_MAX;
-    int stagger = 0;        // >0: waves in odd SIMD slots sleep 64*stagger cycles at entry (de-phases the two co-resident blocks)
-    int prio = 0;           // 1: raise wave priority around MFMA groups
+    // An operand may itself be a split-K result that has not been reduced yet: element = sum over
+    // a_nslab (b_nslab) slabs, slab s at base + s*a_slab_stride.  (Used for the k x k Gram operand of the
+    // update GEMMs, whose 8 k-tiles are all L2 hits; saves a reduction launch.)
+    int a_nslab = 1, b_nslab = 1;
+    int64_t a_slab_stride = 0, b_slab_stride = 0;
+};
+
+// what an epilogue may need to know about the block / wave it runs in
+struct TileCtx {
+    int tr, tc, wr, wc, lane, tid, nthreads, bid;
+    int64_t r0, c0;
 };
 
 // XOR swizzle of the 16-byte chunk position inside a KCONTIG LDS row (8 chunks/row):
@@ -88,7 +97,7 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
 
     // global -> registers
     static __device__ __forceinline__ void load(vec_t (&r)[PER_THREAD], const T *base, int64_t ld,
-                                                int64_t row0, int64_t k0, int tid) {
+                                                int64_t row0, int64_t k0, int tid, int nslab = 1, int64_t slab_stride = 0) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int s = tid + NTHREADS * i;
@@ -104,6 +113,7 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
                 p = base + (k0 + kk) * ld + row0 + r4 * VEC;
             }
             r[i] = *reinterpret_cast<const vec_t *>(p);
+            for (int sl = 1; sl < nslab; ++sl) r[i] += *reinterpret_cast<const vec_t *>(p + (int64_t)sl * slab_stride);
         }
     }
     // registers -> LDS (linear image: chunk s at byte 16*s)
@@ -163,13 +173,6 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     using LoadB = TileLoader<T, LB, BC, NT>;
 
     if (g.done != nullptr && *reinterpret_cast<const volatile int *>(g.done) != 0) return;
-    if (g.stagger > 0) {
-        // HW_REG_HW_ID (id 4): bits [3:0] = wave slot within the SIMD
-        const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
-        if (slot & 1)
-            for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-
     __shared__ __attribute__((aligned(16))) T smem[2 * (BR + BC) * BK];
     constexpr int STAGE = (BR + BC) * BK;   // stage s: A tile at smem + s*STAGE, B tile right behind it
 
@@ -210,14 +213,14 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     //   second half                : global   -> registers, tile t+2  (loads interleaved with MFMAs)
     // Stage (t+1)&1 was last read during tile t-1, i.e. before the barrier that ended iteration t-1.
     typename M::vec_t ra[LoadA::PER_THREAD], rb[LoadB::PER_THREAD];
-    LoadA::load(ra, Ab, lda, ra0, kbeg, tid);
-    LoadB::load(rb, Bb, ldb, cb0, kbeg, tid);
+    LoadA::load(ra, Ab, lda, ra0, kbeg, tid, g.a_nslab, g.a_slab_stride);
+    LoadB::load(rb, Bb, ldb, cb0, kbeg, tid, g.b_nslab, g.b_slab_stride);
     LoadA::store(ra, smem, tid);
     LoadB::store(rb, smem + BR * BK, tid);
     {
         const int64_t k1 = kbeg + (int64_t)((nk > 1) ? 1 : 0) * BK;
-        LoadA::load(ra, Ab, lda, ra0, k1, tid);
-        LoadB::load(rb, Bb, ldb, cb0, k1, tid);
+        LoadA::load(ra, Ab, lda, ra0, k1, tid, g.a_nslab, g.a_slab_stride);
+        LoadB::load(rb, Bb, ldb, cb0, k1, tid, g.b_nslab, g.b_slab_stride);
     }
     __syncthreads();
 
@@ -239,8 +242,8 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
             constexpr bool ldA = (kg == NG / 2), ldB = (kg == (NG > 2 ? NG / 2 + 1 : NG / 2));
             if constexpr (stA) LoadA::store(ra, a_n, tid);
             if constexpr (stB) LoadB::store(rb, b_n, tid);
-            if constexpr (ldA) LoadA::load(ra, Ab, lda, ra0, kn, tid);
-            if constexpr (ldB) LoadB::load(rb, Bb, ldb, cb0, kn, tid);
+            if constexpr (ldA) LoadA::load(ra, Ab, lda, ra0, kn, tid, g.a_nslab, g.a_slab_stride);
+            if constexpr (ldB) LoadB::load(rb, Bb, ldb, cb0, kn, tid, g.b_nslab, g.b_slab_stride);
 #pragma unroll
             for (int q = 0; q < M::VEC; ++q)
 #pragma unroll
@@ -266,7 +269,8 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
 
     // Epilogue.  MFMA C/D layout: f32 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
     // f64 16x16: col = lane&15, row = (lane>>4) + 4*reg.  col <-> c (contiguous), row <-> r.
-    epi.begin(split);
+    const TileCtx tctx{tr, tc, wr, wc, lane, tid, NT, (int)blockIdx.x, r0, c0};
+    epi.begin(split, tctx);
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
@@ -278,10 +282,10 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
                 int64_t r;
                 if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                 else r = rbase + (lane >> 4) + 4 * reg;
-                epi.apply(r, c, acc[i][j][reg]);
+                epi.apply(r, c, acc[i][j][reg], j);
             }
         }
-    epi.finish(reinterpret_cast<double *>(smem), tid, NT, blockIdx.x);
+    epi.template finish<MT, TC, WGR, WGC>(reinterpret_cast<double *>(smem), tctx);
 }
 
 // ---------------------------------------------------------------------------
@@ -293,9 +297,9 @@ template <typename T> struct EpiStore {
     T *C;
     int64_t ld, slab_stride;
     T *dst;
-    __device__ __forceinline__ void begin(int split) { dst = C + (int64_t)split * slab_stride; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) { dst[c + r * ld] = v; }
-    __device__ __forceinline__ void finish(double *, int, int, int) {}
+    __device__ __forceinline__ void begin(int split, const TileCtx &) { dst = C + (int64_t)split * slab_stride; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) { dst[c + r * ld] = v; }
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
 // Split-K slab store with two destinations: columns c < c_split go to the main output (ld), columns
@@ -305,39 +309,85 @@ template <typename T> struct EpiStore2 {
     T *C;
     int64_t ld, c_split, ld2, off2, slab_stride;
     T *dst;
-    __device__ __forceinline__ void begin(int split) { dst = C + (int64_t)split * slab_stride; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) {
+    __device__ __forceinline__ void begin(int split, const TileCtx &) { dst = C + (int64_t)split * slab_stride; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) {
         if (c < c_split) dst[c + r * ld] = v;
         else dst[off2 + (c - c_split) + r * ld2] = v;
     }
-    __device__ __forceinline__ void finish(double *, int, int, int) {}
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
 // Multiplicative update (src/multupd.jl:101-103, 112-114):
 //   out = old * ( max(0, num - lambda) / (acc + delta) ),  acc = Gram-form denominator
-template <typename T> struct EpiMultUpdate {
+// num may still be split-K slabs (summed here in ascending slab order, like reduce_slabs_kernel).
+// STATS = 1 additionally accumulates the stop_condition sums of the component that runs along c
+// (src/common.jl:100-104: dev = sum (new-old)^2, sum = sum (new+old)^2; term in T, sum in Float64) and writes
+// one partial per r-tile:  stat_partial[(tr*ncomp + c)*2 + {0,1}]  -- the layout finalize_partials_kernel reduces.
+template <typename T, int STATS> struct EpiMultUpdate {
     const T *num;
+    int nslab;
+    int64_t slab_stride;
     const T *old;
     T *out;
     int64_t ld;
     T lambda, delta;
-    __device__ __forceinline__ void begin(int) {}
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) {
-        const int64_t o = c + r * ld;
-        T t = num[o] - lambda;
-        t = (t > (T)0) ? t : ((t != t) ? t : (T)0);   // max(zero(T), t); NaN propagates like Julia's max
-        out[o] = old[o] * (t / (v + delta));
+    double *stat_partial;
+    int ncomp;
+    double dev[STATS ? 8 : 1], sm[STATS ? 8 : 1];
+    __device__ __forceinline__ void begin(int, const TileCtx &) {
+        if constexpr (STATS != 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dev[j] = 0.0; sm[j] = 0.0; }
+        }
     }
-    __device__ __forceinline__ void finish(double *, int, int, int) {}
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int jt) {
+        const int64_t o = c + r * ld;
+        T nu = num[o];
+        for (int s = 1; s < nslab; ++s) nu += num[(int64_t)s * slab_stride + o];
+        T t = nu - lambda;
+        t = (t > (T)0) ? t : ((t != t) ? t : (T)0);   // max(zero(T), t); NaN propagates like Julia's max
+        const T ov = old[o];
+        const T nv = ov * (t / (v + delta));
+        out[o] = nv;
+        if constexpr (STATS != 0) {
+            const T d = nv - ov, sp = nv + ov;
+            dev[jt] += (double)(T)(d * d);
+            sm[jt] += (double)(T)(sp * sp);
+        }
+    }
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *smem, const TileCtx &t) {
+        if constexpr (STATS != 0) {
+            static_assert(TC <= 8, "statistics accumulators");
+            constexpr int WTC = TC * MT, BCW = WGC * WTC;   // columns per wave / per block
+            __syncthreads();                               // smem aliases the GEMM staging buffers
+#pragma unroll
+            for (int j = 0; j < TC; ++j) {
+                double d = dev[j], q = sm[j];
+#pragma unroll
+                for (int off = 32; off >= MT; off >>= 1) { d += __shfl_down(d, off, 64); q += __shfl_down(q, off, 64); }
+                if (t.lane < MT) {
+                    const int cl = t.wc * WTC + j * MT + t.lane;
+                    smem[(t.wr * BCW + cl) * 2] = d;
+                    smem[(t.wr * BCW + cl) * 2 + 1] = q;
+                }
+            }
+            __syncthreads();
+            for (int e = t.tid; e < BCW * 2; e += t.nthreads) {
+                double s = 0.0;
+                for (int w = 0; w < WGR; ++w) s += smem[w * BCW * 2 + e];
+                stat_partial[((int64_t)t.tr * ncomp) * 2 + (t.c0) * 2 + e] = s;
+            }
+        }
+    }
 };
 
 // out = max(acc, 0)   (projectnn!, src/utils.jl:34-41; NaN passes through)
 template <typename T> struct EpiClampStore {
     T *out;
     int64_t ld;
-    __device__ __forceinline__ void begin(int) {}
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) { out[c + r * ld] = (v < (T)0) ? (T)0 : v; }
-    __device__ __forceinline__ void finish(double *, int, int, int) {}
+    __device__ __forceinline__ void begin(int, const TileCtx &) {}
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) { out[c + r * ld] = (v < (T)0) ? (T)0 : v; }
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
 // out = acc - sub   (projected-gradient G = Gram*Z - B, src/alspgrad.jl:124-127, 280-283)
@@ -345,12 +395,12 @@ template <typename T> struct EpiSubStore {
     const T *sub;
     T *out;
     int64_t ld;
-    __device__ __forceinline__ void begin(int) {}
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) {
+    __device__ __forceinline__ void begin(int, const TileCtx &) {}
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) {
         const int64_t o = c + r * ld;
         out[o] = v - sub[o];
     }
-    __device__ __forceinline__ void finish(double *, int, int, int) {}
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
 // Q = X ./ (acc + delta)   (src/multupd.jl:172-174, 184-186), acc = (W*H) tile kept in registers
@@ -359,12 +409,12 @@ template <typename T> struct EpiRatio {
     T *Q;
     int64_t ld;
     T delta;
-    __device__ __forceinline__ void begin(int) {}
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) {
+    __device__ __forceinline__ void begin(int, const TileCtx &) {}
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) {
         const int64_t o = c + r * ld;
         Q[o] = X[o] / (v + delta);
     }
-    __device__ __forceinline__ void finish(double *, int, int, int) {}
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
 // block-level sum of per-thread doubles in a fixed order -> *dst
@@ -392,8 +442,8 @@ template <typename T, int KL> struct EpiObjective {
     int64_t ld;
     double *partial;   // one per block
     double sum;
-    __device__ __forceinline__ void begin(int) { sum = 0.0; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v) {
+    __device__ __forceinline__ void begin(int, const TileCtx &) { sum = 0.0; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) {
         const T x = X[c + r * ld];
         T t;
         if constexpr (KL == 0) {
@@ -405,8 +455,8 @@ template <typename T, int KL> struct EpiObjective {
         }
         sum += (double)t;
     }
-    __device__ __forceinline__ void finish(double *smem, int tid, int nthreads, int bid) {
-        block_sum_store(sum, smem, tid, nthreads, partial + bid);
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *smem, const TileCtx &t) {
+        block_sum_store(sum, smem, t.tid, t.nthreads, partial + t.bid);
     }
 };
 

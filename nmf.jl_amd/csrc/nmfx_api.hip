@@ -141,7 +141,7 @@ int nmfx_objective(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, double *out) {
 
 int nmfx_profile_enable(nmfx_ctx *ctx, int on) {
     if (!ctx) return NMFX_ERR_BAD_ARG;
-    return guarded(ctx, [&] { ctx->impl->profile_enable(on != 0); });
+    return guarded(ctx, [&] { ctx->impl->profile_enable(on); });
 }
 
 int nmfx_profile_get(nmfx_ctx *ctx, nmfx_kernel_stat *out, int max_entries, int *n_entries) {

@@ -63,7 +63,7 @@ struct SolverBase {
     virtual void subsolve(int which, const nmfx_opts &o, nmfx_result *out) = 0;
     virtual void comm_init(const void *uid, int rank, int nranks) = 0;
     virtual double objective(int alg, const nmfx_opts &o) = 0;
-    virtual void profile_enable(bool on) = 0;
+    virtual void profile_enable(int mode) = 0;
     virtual int profile_get(nmfx_kernel_stat *out, int max_entries) = 0;
 };
 
@@ -122,16 +122,17 @@ template <typename T> class Solver : public SolverBase {
         s_w = pick_splits((int)(P / 128) * (int)((K + 127) / 128), N);
         s_gw = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), P);
         s_gh = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), N);
-        size_t slab_elems = std::max(std::max((size_t)s_h * K * (N + K), (size_t)s_w * (P * K + K * K)),
-                                     std::max((size_t)s_gw * K * K, (size_t)s_gh * K * K));
-        slabs.alloc(slab_elems);
+        // slab buffer = [ big-GEMM slabs | Gram slabs ]: the two live side by side so the update GEMM can consume
+        // the un-reduced numerator slabs directly in its epilogue
+        gram_slab_off = std::max((size_t)s_h * K * (N + K), (size_t)s_w * (P * K + K * K));
+        slabs.alloc(gram_slab_off + std::max((size_t)s_gw * K * K, (size_t)s_gh * K * K));
         stat_chunks_w = (int)std::max<int64_t>(1, std::min<int64_t>(64, P / 1024));
         stat_chunks_h = (int)std::max<int64_t>(1, std::min<int64_t>(256, N / 64));
-        stat_part.alloc((size_t)std::max(stat_chunks_w, stat_chunks_h) * 2 * K);
+        stat_part.alloc((size_t)std::max<int64_t>(std::max(stat_chunks_w, stat_chunks_h), N / 64) * 2 * K);
         wstat.alloc((size_t)2 * K);
         hstat.alloc((size_t)2 * K);
         svec.alloc((size_t)K);
-        obj_part.alloc((size_t)(P / 128) * (N / 128) + 4096);
+        obj_part.alloc((size_t)2 * (P / 128) * (N / 128) + 4096);
         obj_extra.alloc(4);
         obj_final.alloc(1);
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
@@ -195,10 +196,14 @@ template <typename T> class Solver : public SolverBase {
         nranks = nranks_;
     }
 
-    void profile_enable(bool on) override {
-        profiling = on;
+    // mode 0: off; 1: hipEvent pair around EVERY launch (each pair costs ~10 us of stream time: use for
+    // per-kernel breakdowns, not for throughput); 2: only the dominant GEMM launches (>= 1e10 flop), every 4th
+    // one -- the live roofline measurement of bench.py, < 0.5 % overhead on the timed region.
+    void profile_enable(int mode) override {
+        profiling = mode;
         records.clear();
         ev_used = 0;
+        prof_tick = 0;
     }
 
     int profile_get(nmfx_kernel_stat *out, int max_entries) override {
@@ -257,6 +262,9 @@ template <typename T> class Solver : public SolverBase {
     int wcur = 0, hcur = 0;
     int s_h = 1, s_w = 1, s_gw = 1, s_gh = 1;
     int stat_chunks_w = 1, stat_chunks_h = 1;
+    size_t gram_slab_off = 0;
+    int last_tiles_r = 1;   // r-tiles of the most recent GEMM launch (= chunks of its statistics partials)
+    int last_blocks = 1;    // blocks of the most recent GEMM launch (= number of its objective partials)
     bool have_X = false, have_F = false;
     // Fusing the k x k Gram into the big GEMM launch adds (K/128)^2 tiles to a grid that otherwise fills the 512
     // block slots exactly (256 tiles x 2 splits @C3): the 8 extra blocks form a second wave and cost +50 % (measured
@@ -267,7 +275,8 @@ template <typename T> class Solver : public SolverBase {
 
     // profiling (hipEvent pair per launch, resolved lazily)
     struct Rec { const char *name; int ev; double flops, bytes; };
-    bool profiling = false;
+    int profiling = 0;
+    long long prof_tick = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<Rec> records;
     int ev_used = 0;
@@ -289,6 +298,7 @@ template <typename T> class Solver : public SolverBase {
 
     template <typename F> void timed(const char *name, double flops, double bytes, F &&launch) {
         if (!profiling) { launch(); return; }
+        if (profiling == 2 && (flops < 1e10 || (prof_tick++ & 3) != 0)) { launch(); return; }
         if (ev_used == (int)ev_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));
@@ -314,6 +324,7 @@ template <typename T> class Solver : public SolverBase {
     struct Seg {   // optional second operand segment (see GemmArgs)
         const T *A2 = nullptr; int64_t lda2 = 0, r_split = INT64_MAX;
         const T *B2 = nullptr; int64_t ldb2 = 0, c_split = INT64_MAX;
+        int a_nslab = 1, b_nslab = 1; int64_t a_slab_stride = 0, b_slab_stride = 0;
     };
     template <int LA, int LB, typename Epi>
     void gemm(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim,
@@ -322,13 +333,24 @@ template <typename T> class Solver : public SolverBase {
         g.A = A; g.B = B; g.lda = lda; g.ldb = ldb;
         g.A2 = seg.A2; g.lda2 = seg.lda2; g.r_split = seg.r_split;
         g.B2 = seg.B2; g.ldb2 = seg.ldb2; g.c_split = seg.c_split;
+        g.a_nslab = seg.a_nslab; g.b_nslab = seg.b_nslab; g.a_slab_stride = seg.a_slab_stride; g.b_slab_stride = seg.b_slab_stride;
         g.splits = splits;
         g.kchunk = (int)(Kdim / splits);
         g.c_fastest = c_fastest ? 1 : 0;
         g.done = done;
         const double flops = 2.0 * (double)R * (double)C * (double)Kdim;
+        auto note = [&] { last_tiles_r = g.tiles_r; last_blocks = g.tiles_r * g.tiles_c * g.splits; };
+        // Short contractions (the k x k Gram products: 8 k-tiles) are dominated by prologue/epilogue latency; give
+        // them half-size tiles so >= 2 blocks per CU are resident and one block's epilogue overlaps another's MFMAs.
+        const bool small_k = (Kdim <= 1024) && splits == 1 && ((R / 128) * (C / 128) < 2 * (int64_t)num_cu);
         timed(name, flops, bytes, [&] {
-            if (R % 128 == 0 && C % 128 == 0) {
+            if (small_k && R % 64 == 0 && C % 128 == 0 && R >= C) {
+                g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 128);
+                launch_gemm_cfg<LA, LB, 64, 128, 1, 4>(g, epi);
+            } else if (small_k && R % 128 == 0 && C % 64 == 0 && C > R) {
+                g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 64);
+                launch_gemm_cfg<LA, LB, 128, 64, 4, 1>(g, epi);
+            } else if (R % 128 == 0 && C % 128 == 0) {
                 g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 128);
                 launch_gemm_cfg<LA, LB, 128, 128, 2, 2>(g, epi);
             } else if (C == 64 && R % 256 == 0) {
@@ -344,15 +366,19 @@ template <typename T> class Solver : public SolverBase {
                 throw StatusError{NMFX_ERR_UNSUPPORTED, "internal: no tile configuration for this GEMM shape"};
             }
         });
+        note();
     }
 
-    void reduce_slabs(const char *name, T *dst, int64_t count, int nslab, const int *done) {
+    void reduce_slabs_from(const char *name, T *dst, const T *src, int64_t count, int nslab, const int *done) {
         timed(name, 0.0, (double)count * (nslab + 1) * sizeof(T), [&] {
             const int bs = 256;
             hipLaunchKernelGGL(reduce_slabs_kernel<T>, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, stream, dst,
-                               slabs.p, count, nslab, count, done);
+                               src, count, nslab, count, done);
             HIP_TRY(hipGetLastError());
         });
+    }
+    void reduce_slabs(const char *name, T *dst, int64_t count, int nslab, const int *done) {
+        reduce_slabs_from(name, dst, slabs.p, count, nslab, done);
     }
 
     // ---- shared building blocks ------------------------------------------------
@@ -361,7 +387,7 @@ template <typename T> class Solver : public SolverBase {
     // numH = W' * Bmat  (K x N, ld K), Bmat = X or Q (P x N)      src/multupd.jl:98,175; projals.jl:93; alspgrad.jl:66
     // with_gram: also gramW = W'W (src/projals.jl:92, alspgrad.jl:65) in the SAME launch: the A operand is the
     // row-concatenation [Bmat ; W], the output the K x (N+K) matrix [numH | gramW].
-    void wt_times(const T *Wp, const T *Bmat, bool with_gram, const int *done) {
+    void wt_times(const T *Wp, const T *Bmat, bool with_gram, const int *done, bool keep_slabs = false) {
         if (with_gram && fuse_gram && K % 128 == 0) {
             EpiStore<T> e{slabs.p, K, (int64_t)K * (N + K), nullptr};
             Seg sg;
@@ -374,17 +400,17 @@ template <typename T> class Solver : public SolverBase {
         EpiStore<T> e{slabs.p, K, (int64_t)K * N, nullptr};
         gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                (double)(P * N + P * K) * sizeof(T));
-        reduce_slabs("reduce_WtX", numH_p, (int64_t)K * N, s_h, done);
+        if (!keep_slabs) reduce_slabs("reduce_WtX", numH_p, (int64_t)K * N, s_h, done);
         if (with_gram) {
-            EpiStore<T> eg{slabs.p, K, (int64_t)K * K, nullptr};
+            EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
             gemm<KCONTIG, KCONTIG>("gemm_WtW", Wp, P, K, Wp, P, K, P, s_gw, true, eg, done, (double)(P * K) * sizeof(T));
-            reduce_slabs("reduce_WtW", gramW_p, (int64_t)K * K, s_gw, done);
+            reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gw, done);
         }
     }
     // numW = Amat * H'  (P x K, ld P), Amat = X or Q              src/multupd.jl:109,187; projals.jl:101; alspgrad.jl:221
     // with_gram: also gramH = HH' (src/projals.jl:100, alspgrad.jl:220) in the same launch: B operand = [Amat ; H],
     // slab = [ numW (ld P) | gramH (ld K) ] = the layout of the packed all-reduce buffer.
-    void times_ht(const T *Amat, const T *Hp, bool with_gram, const int *done) {
+    void times_ht(const T *Amat, const T *Hp, bool with_gram, const int *done, bool keep_slabs = false) {
         if (with_gram && fuse_gram && K % 128 == 0) {
             EpiStore2<T> e{slabs.p, P, P, K, (int64_t)P * K, (int64_t)P * K + (int64_t)K * K, nullptr};
             Seg sg;
@@ -397,11 +423,11 @@ template <typename T> class Solver : public SolverBase {
         EpiStore<T> e{slabs.p, P, (int64_t)P * K, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                  (double)(P * N + K * N) * sizeof(T));
-        reduce_slabs("reduce_XHt", numW_p, (int64_t)P * K, s_w, done);
+        if (!keep_slabs) reduce_slabs("reduce_XHt", numW_p, (int64_t)P * K, s_w, done);
         if (with_gram) {
-            EpiStore<T> eg{slabs.p, K, (int64_t)K * K, nullptr};
+            EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
             gemm<KSTRIDED, KSTRIDED>("gemm_HHt", Hp, K, K, Hp, K, K, N, s_gh, true, eg, done, (double)(K * N) * sizeof(T));
-            reduce_slabs("reduce_HHt", gramH_p, (int64_t)K * K, s_gh, done);
+            reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gh, done);
         }
     }
 
@@ -411,6 +437,14 @@ template <typename T> class Solver : public SolverBase {
                                (int)K, stat_part.p, done);
             hipLaunchKernelGGL(finalize_partials_kernel<double>, dim3((unsigned)((2 * K + 3) / 4)), dim3(256), 0, stream,
                                stat_part.p, stat_chunks_w, (int)(2 * K), (int)(2 * K), wstat.p, done);
+            HIP_TRY(hipGetLastError());
+        });
+    }
+    // H statistics whose per-r-tile partials were produced by the update GEMM's epilogue (EpiMultUpdate<T,1>)
+    void stats_h_finalize(int chunks, const int *done) {
+        timed("stats_H", 0.0, (double)chunks * 2 * K * sizeof(double), [&] {
+            hipLaunchKernelGGL(finalize_partials_kernel<double>, dim3((unsigned)((2 * K + 3) / 4)), dim3(256), 0, stream,
+                               stat_part.p, chunks, (int)(2 * K), (int)(2 * K), hstat.p, done);
             HIP_TRY(hipGetLastError());
         });
     }

@@ -12,7 +12,6 @@ namespace nmfx {
 template <typename T>
 void Solver<T>::enqueue_objective(int alg, const nmfx_opts &o, double *dst, const int *done) {
     const T *Wp = W[wcur].p, *Hp = H[hcur].p;
-    const int nblk = (int)((P / 128) * (N / 128));
     const double bytes = (double)(P * N) * sizeof(T);
     if (alg == NMFX_ALG_MULTDIV) {
         EpiObjective<T, 1> e{X.p, P, obj_part.p, 0.0};
@@ -21,6 +20,7 @@ void Solver<T>::enqueue_objective(int alg, const nmfx_opts &o, double *dst, cons
         EpiObjective<T, 0> e{X.p, P, obj_part.p, 0.0};
         gemm<KCONTIG, KSTRIDED>("gemm_WH_sqdist", Hp, K, N, Wp, P, P, K, 1, true, e, done, bytes);
     }
+    const int nblk = last_blocks;   // one Float64 partial per block of the launch above
     int nextra = 0;
     if (alg == NMFX_ALG_PROJALS) {   // + 0.5*lambda_w*||W||^2 + 0.5*lambda_h*||H||^2   (projals.jl:67-72)
         const int nb = 1024;
@@ -81,18 +81,24 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
         const T *Wp = W[wcur].p;
         const T *Ho = H[hcur].p;
         T *Hn = H[hcur ^ 1].p;
-        wt_times(Wp, X.p, true, done);                                     // :98  (+ W'W in the same launch)
-        EpiMultUpdate<T> e{numH_p, Ho, Hn, K, (T)o.lambda_h, (T)o.delta};  // :99-103
-        gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, 3.0 * K * N * sizeof(T));
-        stats_h(Hn, Ho, done);
+        // :98 W'X stays as split-K slabs: the update GEMM's epilogue sums them (ascending slab order, identical to
+        // reduce_slabs_kernel) and also produces the stop_condition statistics of H -- two launches less per iteration
+        wt_times(Wp, X.p, true, done, /*keep_slabs=*/true);
+        EpiMultUpdate<T, 1> e{slabs.p, s_h, (int64_t)K * N, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};  // :99-103
+        gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (3.0 + s_h) * K * N * sizeof(T));
+        stats_h_finalize(last_tiles_r, done);
         hcur ^= 1;
     }
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
-    times_ht(X.p, Hp, true, done);                                         // :109 (+ HH' in the same launch)
+    // :109 XH': single GPU -> slabs are consumed by the update GEMM's epilogue; sharded -> reduce into the packed
+    // buffer first, because the all-reduce needs the rank-local sum
+    const bool w_slabs = (nranks == 1);
+    times_ht(X.p, Hp, true, done, /*keep_slabs=*/w_slabs);
     allreduce_w_side(o.update_H != 0, done);
-    EpiMultUpdate<T> e{numW_p, Wo, Wn, P, (T)o.lambda_w, (T)o.delta};      // :110-114
+    EpiMultUpdate<T, 0> e{w_slabs ? slabs.p : numW_p, w_slabs ? s_w : 1, (int64_t)P * K, Wo, Wn, P, (T)o.lambda_w, (T)o.delta,
+                          nullptr, 0};                                     // :110-114
     gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo, P, P, K, 1, false, e, done, 3.0 * P * K * sizeof(T));
     stats_w(Wn, Wo, done);
     wcur ^= 1;

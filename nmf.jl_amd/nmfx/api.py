@@ -257,8 +257,9 @@ class Context:
         buf = C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)
         self._ck(self.lib.nmfx_comm_init(self.h, buf, rank, nranks))
 
-    def profile_enable(self, on=True):
-        self._ck(self.lib.nmfx_profile_enable(self.h, int(on)))
+    def profile_enable(self, mode=1):
+        """0 off, 1 every launch (slow), 2 dominant GEMMs sampled 1-in-4 (bench roofline)."""
+        self._ck(self.lib.nmfx_profile_enable(self.h, int(mode)))
 
     def profile_get(self):
         arr = (L.KernelStat * 64)()

@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket launches with hipEvents (no roofline object)")
     ap.add_argument("--all-events", action="store_true", help="hipEvent pair around every launch (per-kernel table; slows the loop ~4%%)")
-    ap.add_argument("--cpu-sample-cols", type=int, default=1024)
+    ap.add_argument("--cpu-sample-cols", type=int, default=2048)
     return ap.parse_args()
 
 
@@ -63,9 +63,18 @@ def synth(p, n, k, c0, c1, tdtype, device):
     Wg_d = Wg.to(device=device, dtype=tdtype)
     Hg_d = Hg[:, c0:c1].to(device=device, dtype=tdtype)
     Xt = Hg_d.t().contiguous() @ Wg_d.t().contiguous()        # (n_local, p): data generation only (rocBLAS)
+    # noise: every rank draws the SAME full (n, p) field and keeps its rows, so the global X is identical for
+    # every world size (strong scaling on one fixed problem); generated in row blocks to bound the temporary.
     gd = torch.Generator(device=device)
-    gd.manual_seed(SEED + 1 + c0)
-    Xt.add_(torch.rand(Xt.shape, generator=gd, device=device, dtype=tdtype), alpha=0.01)
+    gd.manual_seed(SEED + 1)
+    blk = 2048
+    for j0 in range(0, n, blk):
+        j1 = min(n, j0 + blk)
+        noise = torch.rand((j1 - j0, p), generator=gd, device=device, dtype=tdtype)
+        lo, hi = max(j0, c0), min(j1, c1)
+        if lo < hi:
+            Xt[lo - c0:hi - c0].add_(noise[lo - j0:hi - j0], alpha=0.01)
+    del noise
     npdt = np.float32 if tdtype == torch.float32 else np.float64
     W0h = np.asfortranarray(W0.numpy().astype(npdt))
     H0h = np.asfortranarray(H0[:, c0:c1].numpy().astype(npdt))

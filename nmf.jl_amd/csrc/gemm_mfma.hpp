@@ -75,6 +75,7 @@ template <typename T> struct GemmArgs {
     // update GEMMs, whose 8 k-tiles are all L2 hits; saves a reduction launch.)
     int a_nslab = 1, b_nslab = 1;
     int64_t a_slab_stride = 0, b_slab_stride = 0;
+    int group = 1;          // >1: super-tile rasterisation (see the block -> tile mapping)
 };
 
 // what an epilogue may need to know about the block / wave it runs in
@@ -189,8 +190,18 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     const int split = bid / tiles;
     const int trem = bid % tiles;
     int tr, tc;
-    if (g.c_fastest) { tc = trem % g.tiles_c; tr = trem / g.tiles_c; }
-    else             { tr = trem % g.tiles_r; tc = trem / g.tiles_r; }
+    if (g.group > 1) {
+        // 2-D super-tiles of group x group block tiles (both tile counts are multiples of `group`): the blocks of
+        // one super-tile are consecutive logical ids, i.e. they run on ONE XCD at about the same time, so each
+        // operand tile is fetched into that XCD's 4 MiB L2 once and re-used `group` times (outputs that are large
+        // in both dimensions -- W*H for the objective / the ratio pass -- otherwise re-stream one operand per tile row).
+        const int G = g.group, per = G * G;
+        const int st = trem / per, in = trem % per;
+        const int sr = st / (g.tiles_c / G), sc = st % (g.tiles_c / G);
+        tr = sr * G + in / G;
+        tc = sc * G + in % G;
+    } else if (g.c_fastest) { tc = trem % g.tiles_c; tr = trem / g.tiles_c; }
+    else                    { tr = trem % g.tiles_r; tc = trem / g.tiles_r; }
     const int64_t r0 = (int64_t)tr * BR, c0 = (int64_t)tc * BC;
     const int64_t kbeg = (int64_t)split * g.kchunk;
     const int nk = g.kchunk / BK;
@@ -277,19 +288,31 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
         for (int j = 0; j < TC; ++j) {
             const int64_t c = c0 + wc * WTC + j * MT + (lane % MT);
             const int64_t rbase = r0 + wr * WTR + i * MT;
+            // two phases per MFMA tile: issue every global load of the epilogue first, then compute and store.
+            // (Inputs and outputs of an epilogue may alias as far as the compiler knows, so a fused
+            // load-compute-store per element serialises one memory round trip per element.)
+            typename Epi::Pre pre[M::NACC];
 #pragma unroll
             for (int reg = 0; reg < M::NACC; ++reg) {
                 int64_t r;
                 if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                 else r = rbase + (lane >> 4) + 4 * reg;
-                epi.apply(r, c, acc[i][j][reg], j);
+                pre[reg] = epi.prefetch(r, c);
+            }
+#pragma unroll
+            for (int reg = 0; reg < M::NACC; ++reg) {
+                int64_t r;
+                if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                else r = rbase + (lane >> 4) + 4 * reg;
+                epi.apply(r, c, acc[i][j][reg], j, pre[reg]);
             }
         }
     epi.template finish<MT, TC, WGR, WGC>(reinterpret_cast<double *>(smem), tctx);
 }
 
 // ---------------------------------------------------------------------------
-// Epilogues: apply(r, c, v) receives D(r, c); the element lives at  base[c + r*ld].
+// Epilogues: pre = prefetch(r, c) loads whatever the epilogue needs from memory for element (r, c);
+// apply(r, c, v, jt, pre) receives D(r, c) and stores.  The element lives at  base[c + r*ld].
 // ---------------------------------------------------------------------------
 
 // C (or split-K slab `split`) = acc
@@ -297,8 +320,10 @@ template <typename T> struct EpiStore {
     T *C;
     int64_t ld, slab_stride;
     T *dst;
+    struct Pre {};
     __device__ __forceinline__ void begin(int split, const TileCtx &) { dst = C + (int64_t)split * slab_stride; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) { dst[c + r * ld] = v; }
+    __device__ __forceinline__ Pre prefetch(int64_t, int64_t) const { return Pre{}; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &) { dst[c + r * ld] = v; }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
@@ -310,7 +335,9 @@ template <typename T> struct EpiStore2 {
     int64_t ld, c_split, ld2, off2, slab_stride;
     T *dst;
     __device__ __forceinline__ void begin(int split, const TileCtx &) { dst = C + (int64_t)split * slab_stride; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) {
+    struct Pre {};
+    __device__ __forceinline__ Pre prefetch(int64_t, int64_t) const { return Pre{}; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &) {
         if (c < c_split) dst[c + r * ld] = v;
         else dst[off2 + (c - c_split) + r * ld2] = v;
     }
@@ -340,13 +367,18 @@ template <typename T, int STATS> struct EpiMultUpdate {
             for (int j = 0; j < 8; ++j) { dev[j] = 0.0; sm[j] = 0.0; }
         }
     }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int jt) {
+    struct Pre { T nu, ov; };
+    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const {
         const int64_t o = c + r * ld;
         T nu = num[o];
         for (int s = 1; s < nslab; ++s) nu += num[(int64_t)s * slab_stride + o];
-        T t = nu - lambda;
+        return Pre{nu, old[o]};
+    }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int jt, const Pre &pre) {
+        const int64_t o = c + r * ld;
+        T t = pre.nu - lambda;
         t = (t > (T)0) ? t : ((t != t) ? t : (T)0);   // max(zero(T), t); NaN propagates like Julia's max
-        const T ov = old[o];
+        const T ov = pre.ov;
         const T nv = ov * (t / (v + delta));
         out[o] = nv;
         if constexpr (STATS != 0) {
@@ -386,7 +418,9 @@ template <typename T> struct EpiClampStore {
     T *out;
     int64_t ld;
     __device__ __forceinline__ void begin(int, const TileCtx &) {}
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) { out[c + r * ld] = (v < (T)0) ? (T)0 : v; }
+    struct Pre {};
+    __device__ __forceinline__ Pre prefetch(int64_t, int64_t) const { return Pre{}; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &) { out[c + r * ld] = (v < (T)0) ? (T)0 : v; }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
@@ -396,10 +430,9 @@ template <typename T> struct EpiSubStore {
     T *out;
     int64_t ld;
     __device__ __forceinline__ void begin(int, const TileCtx &) {}
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) {
-        const int64_t o = c + r * ld;
-        out[o] = v - sub[o];
-    }
+    struct Pre { T s; };
+    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const { return Pre{sub[c + r * ld]}; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &pre) { out[c + r * ld] = v - pre.s; }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
@@ -410,10 +443,9 @@ template <typename T> struct EpiRatio {
     int64_t ld;
     T delta;
     __device__ __forceinline__ void begin(int, const TileCtx &) {}
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) {
-        const int64_t o = c + r * ld;
-        Q[o] = X[o] / (v + delta);
-    }
+    struct Pre { T x; };
+    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const { return Pre{X[c + r * ld]}; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &pre) { Q[c + r * ld] = pre.x / (v + delta); }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
@@ -443,8 +475,10 @@ template <typename T, int KL> struct EpiObjective {
     double *partial;   // one per block
     double sum;
     __device__ __forceinline__ void begin(int, const TileCtx &) { sum = 0.0; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/) {
-        const T x = X[c + r * ld];
+    struct Pre { T x; };
+    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const { return Pre{X[c + r * ld]}; }
+    __device__ __forceinline__ void apply(int64_t, int64_t, T v, int /*jt*/, const Pre &pre) {
+        const T x = pre.x;
         T t;
         if constexpr (KL == 0) {
             const T d = x - v;

@@ -352,6 +352,7 @@ template <typename T> class Solver : public SolverBase {
                 launch_gemm_cfg<LA, LB, 128, 64, 4, 1>(g, epi);
             } else if (R % 128 == 0 && C % 128 == 0) {
                 g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 128);
+                if (splits == 1 && g.tiles_r >= 16 && g.tiles_c >= 16 && g.tiles_r % 8 == 0 && g.tiles_c % 8 == 0) g.group = 8;
                 launch_gemm_cfg<LA, LB, 128, 128, 2, 2>(g, epi);
             } else if (C == 64 && R % 256 == 0) {
                 g.tiles_r = (int)(R / 256); g.tiles_c = 1;

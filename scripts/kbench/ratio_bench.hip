@@ -1,0 +1,52 @@
+// Development micro-benchmark: the short-K, large-output GEMMs (W*H with ratio / objective / plain-store epilogues).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "gemm_mfma.hpp"
+using namespace nmfx;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int BR, int BC, int WGR, int WGC, typename Epi>
+void run(const char *name, GemmArgs<float> g, Epi e, int64_t R, int64_t C, int64_t Kd, int group, int reps) {
+    g.tiles_r = (int)(R / BR); g.tiles_c = (int)(C / BC); g.group = group;
+    const int blocks = g.tiles_r * g.tiles_c;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((gemm_mfma_kernel<float, KCONTIG, KSTRIDED, BR, BC, WGR, WGC, Epi>), dim3(blocks), dim3(WGR * WGC * 64), 0, 0, g, e);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (i > 1) best = std::min(best, ms);
+    }
+    CK(hipGetLastError());
+    printf("%-40s blocks=%6d group=%d: %.1f us  %.1f TF/s\n", name, blocks, group, best * 1e3, 2.0 * R * C * Kd / (best * 1e-3) / 1e12);
+}
+
+int main(int argc, char **argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 12;
+    const int64_t P = 16384, N = 16384, K = 256;
+    float *H, *W, *X, *Q; double *part;
+    CK(hipMalloc(&H, K * N * 4)); CK(hipMalloc(&W, P * K * 4)); CK(hipMalloc(&X, P * N * 4)); CK(hipMalloc(&Q, P * N * 4));
+    CK(hipMalloc(&part, 8 * 65536 * 8));
+    std::vector<float> h((size_t)P * N);
+    for (auto &v : h) v = (float)(rand() / (double)RAND_MAX);
+    CK(hipMemcpy(X, h.data(), (size_t)P * N * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(H, h.data(), (size_t)K * N * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(W, h.data(), (size_t)P * K * 4, hipMemcpyHostToDevice));
+    GemmArgs<float> g;
+    g.A = H; g.lda = K; g.B = W; g.ldb = P; g.splits = 1; g.kchunk = (int)K; g.c_fastest = 1; g.done = nullptr;
+    EpiStore<float> es{Q, P, 0, nullptr};
+    EpiRatio<float> er{X, Q, P, 3.4e-4f};
+    EpiObjective<float, 0> eo{X, P, part, 0.0};
+    for (int group : {1, 8}) {
+        run<128, 128, 2, 2>("store   128x128", g, es, N, P, K, group, reps);
+        run<128, 128, 2, 2>("ratio   128x128", g, er, N, P, K, group, reps);
+        run<128, 128, 2, 2>("sqdist  128x128", g, eo, N, P, K, group, reps);
+    }
+    run<64, 128, 1, 4>("ratio   64x128 (1x4 waves)", g, er, N, P, K, 1, reps);
+    run<128, 64, 4, 1>("ratio   128x64 (4x1 waves)", g, er, N, P, K, 1, reps);
+    run<256, 64, 4, 1>("ratio   256x64 (4x1 waves)", g, er, N, P, K, 1, reps);
+    run<64, 256, 1, 4>("ratio   64x256 (1x4 waves)", g, er, N, P, K, 1, reps);
+    return 0;
+}

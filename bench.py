@@ -36,8 +36,8 @@ SEED = 20240910
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--p", type=int, default=16384)
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--k", type=int, default=256)

@@ -76,6 +76,8 @@ template <typename T> struct GemmArgs {
     int a_nslab = 1, b_nslab = 1;
     int64_t a_slab_stride = 0, b_slab_stride = 0;
     int group = 1;          // >1: super-tile rasterisation (see the block -> tile mapping)
+    int streamk = 0;        // 1: stream-K decomposition over gridDim.x blocks (see the kernel)
+    int nkt = 0;            // stream-K: k-tiles per output tile (= Kdim / BK)
 };
 
 // what an epilogue may need to know about the block / wave it runs in
@@ -187,126 +189,156 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     int bid = blockIdx.x;
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int tiles = g.tiles_r * g.tiles_c;
-    const int split = bid / tiles;
-    const int trem = bid % tiles;
-    int tr, tc;
-    if (g.group > 1) {
-        // 2-D super-tiles of group x group block tiles (both tile counts are multiples of `group`): the blocks of
-        // one super-tile are consecutive logical ids, i.e. they run on ONE XCD at about the same time, so each
-        // operand tile is fetched into that XCD's 4 MiB L2 once and re-used `group` times (outputs that are large
-        // in both dimensions -- W*H for the objective / the ratio pass -- otherwise re-stream one operand per tile row).
-        const int G = g.group, per = G * G;
-        const int st = trem / per, in = trem % per;
-        const int sr = st / (g.tiles_c / G), sc = st % (g.tiles_c / G);
-        tr = sr * G + in / G;
-        tc = sc * G + in % G;
-    } else if (g.c_fastest) { tc = trem % g.tiles_c; tr = trem / g.tiles_c; }
-    else                    { tr = trem % g.tiles_r; tc = trem / g.tiles_r; }
-    const int64_t r0 = (int64_t)tr * BR, c0 = (int64_t)tc * BC;
-    const int64_t kbeg = (int64_t)split * g.kchunk;
-    const int nk = g.kchunk / BK;
-    const T *Ab = g.A, *Bb = g.B;
-    int64_t lda = g.lda, ldb = g.ldb, ra0 = r0, cb0 = c0;
-    if (r0 >= g.r_split) { Ab = g.A2; lda = g.lda2; ra0 = r0 - g.r_split; }
-    if (c0 >= g.c_split) { Bb = g.B2; ldb = g.ldb2; cb0 = c0 - g.c_split; }
-
-    typename M::acc_t acc[TR][TC];
-#pragma unroll
-    for (int i = 0; i < TR; ++i)
-#pragma unroll
-        for (int j = 0; j < TC; ++j)
-#pragma unroll
-            for (int r = 0; r < M::NACC; ++r) acc[i][j][r] = (T)0;
-
-    // Software pipeline (one barrier per k-tile, no MFMA-free phase besides it):
-    //   registers hold k-tile t+1 while the MFMAs of tile t run out of LDS stage t&1;
-    //   first half of the k-groups : registers -> LDS stage (t+1)&1   (ds_write interleaved with MFMAs)
-    //   second half                : global   -> registers, tile t+2  (loads interleaved with MFMAs)
-    // Stage (t+1)&1 was last read during tile t-1, i.e. before the barrier that ended iteration t-1.
-    typename M::vec_t ra[LoadA::PER_THREAD], rb[LoadB::PER_THREAD];
-    LoadA::load(ra, Ab, lda, ra0, kbeg, tid, g.a_nslab, g.a_slab_stride);
-    LoadB::load(rb, Bb, ldb, cb0, kbeg, tid, g.b_nslab, g.b_slab_stride);
-    LoadA::store(ra, smem, tid);
-    LoadB::store(rb, smem + BR * BK, tid);
-    {
-        const int64_t k1 = kbeg + (int64_t)((nk > 1) ? 1 : 0) * BK;
-        LoadA::load(ra, Ab, lda, ra0, k1, tid, g.a_nslab, g.a_slab_stride);
-        LoadB::load(rb, Bb, ldb, cb0, k1, tid, g.b_nslab, g.b_slab_stride);
-    }
-    __syncthreads();
-
-    constexpr int NG = BK / 8;   // k-groups per tile
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        const T *a_s = smem + cur * STAGE, *b_s = a_s + BR * BK;
-        T *a_n = smem + (cur ^ 1) * STAGE, *b_n = a_n + BR * BK;
-        const int tn = (t + 2 < nk) ? t + 2 : nk - 1;   // clamped: the last iterations re-load the final tile (never used)
-        const int64_t kn = kbeg + (int64_t)tn * BK;
-        static_for<NG>([&](auto KGC) {
-            constexpr int kg = decltype(KGC)::value;
-            T af[TR][M::VEC], bf[TC][M::VEC];
-#pragma unroll
-            for (int i = 0; i < TR; ++i) read_frag<T, LA, BR>(af[i], a_s, wr * WTR + i * MT, kg, lane);
-#pragma unroll
-            for (int j = 0; j < TC; ++j) read_frag<T, LB, BC>(bf[j], b_s, wc * WTC + j * MT, kg, lane);
-            constexpr bool stA = (kg == 0), stB = (kg == (NG > 2 ? 1 : 0));
-            constexpr bool ldA = (kg == NG / 2), ldB = (kg == (NG > 2 ? NG / 2 + 1 : NG / 2));
-            if constexpr (stA) LoadA::store(ra, a_n, tid);
-            if constexpr (stB) LoadB::store(rb, b_n, tid);
-            if constexpr (ldA) LoadA::load(ra, Ab, lda, ra0, kn, tid, g.a_nslab, g.a_slab_stride);
-            if constexpr (ldB) LoadB::load(rb, Bb, ldb, cb0, kn, tid, g.b_nslab, g.b_slab_stride);
-#pragma unroll
-            for (int q = 0; q < M::VEC; ++q)
-#pragma unroll
-                for (int i = 0; i < TR; ++i)
-#pragma unroll
-                    for (int j = 0; j < TC; ++j) acc[i][j] = M::mma(af[i][q], bf[j][q], acc[i][j]);
-            // Issue-order template for this k-group (LLVM sched_group_barrier; masks: MFMA 0x8, VMEM read 0x20,
-            // DS read 0x100, DS write 0x200): fragment reads first, then the staging traffic of this group spread
-            // one instruction per MFMA pair, so neither the LDS writes nor the global loads open an MFMA-free window.
-            constexpr int NMFMA = M::VEC * TR * TC;
-            constexpr int NFRAG = (LA == KCONTIG ? TR : TR * M::VEC) + (LB == KCONTIG ? TC : TC * M::VEC);
-            constexpr int NW0 = (stA ? LoadA::PER_THREAD : 0) + (stB ? LoadB::PER_THREAD : 0);
-            constexpr int NL0 = (ldA ? LoadA::PER_THREAD : 0) + (ldB ? LoadB::PER_THREAD : 0);
-            constexpr int NW = (2 * NW0 <= NMFMA) ? NW0 : NMFMA / 2;
-            constexpr int NL = (2 * (NW + NL0) <= NMFMA) ? NL0 : (NMFMA / 2 - NW);
-            __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
-            sched_pairs<0x200, NW>();
-            sched_pairs<0x20, NL>();
-            if constexpr (NMFMA - 2 * (NW + NL) > 0) __builtin_amdgcn_sched_group_barrier(0x8, NMFMA - 2 * (NW + NL), 0);
-        });
-        __syncthreads();
-    }
-
-    // Epilogue.  MFMA C/D layout: f32 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
-    // f64 16x16: col = lane&15, row = (lane>>4) + 4*reg.  col <-> c (contiguous), row <-> r.
-    const TileCtx tctx{tr, tc, wr, wc, lane, tid, NT, (int)blockIdx.x, r0, c0};
-    epi.begin(split, tctx);
-#pragma unroll
-    for (int i = 0; i < TR; ++i)
-#pragma unroll
-        for (int j = 0; j < TC; ++j) {
-            const int64_t c = c0 + wc * WTC + j * MT + (lane % MT);
-            const int64_t rbase = r0 + wr * WTR + i * MT;
-            // two phases per MFMA tile: issue every global load of the epilogue first, then compute and store.
-            // (Inputs and outputs of an epilogue may alias as far as the compiler knows, so a fused
-            // load-compute-store per element serialises one memory round trip per element.)
-            typename Epi::Pre pre[M::NACC];
-#pragma unroll
-            for (int reg = 0; reg < M::NACC; ++reg) {
-                int64_t r;
-                if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                else r = rbase + (lane >> 4) + 4 * reg;
-                pre[reg] = epi.prefetch(r, c);
-            }
-#pragma unroll
-            for (int reg = 0; reg < M::NACC; ++reg) {
-                int64_t r;
-                if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                else r = rbase + (lane >> 4) + 4 * reg;
-                epi.apply(r, c, acc[i][j][reg], j, pre[reg]);
-            }
+    // Work decomposition.
+    //   plain split-K : block = (tile, split); split s handles k-tiles [s*kchunk/BK, (s+1)*kchunk/BK) and writes slab s.
+    //   stream-K      : the (tile, k-tile) space, tile-major, is cut into gridDim.x equal contiguous ranges -- a block
+    //                   may finish one tile and start the next.  Every block does the same number of k-tiles (+-1), so a
+    //                   grid of exactly 2 blocks per CU has no wave-quantisation tail whatever the tile count is
+    //                   (this is what lets the k x k Gram ride in the same launch as the big GEMM).  Segment number
+    //                   `bid - first_block(tile)` selects the slab; slabs a tile never writes stay zero (the host zeroes
+    //                   the buffer once per shape), so consumers simply add all `splits` slabs.
+    const int nkt = g.streamk ? g.nkt : g.kchunk / BK;
+    long long u = 0, ue = 0;
+    const long long U = (long long)tiles * nkt;
+    if (g.streamk) { u = ((long long)bid * U) / nblk; ue = ((long long)(bid + 1) * U) / nblk; }
+    TileCtx tctx{0, 0, wr, wc, lane, tid, NT, (int)blockIdx.x, 0, 0};
+    bool first_seg = true;
+    while (first_seg || (g.streamk && u < ue)) {
+        first_seg = false;
+        int trem, split, kt0, nk;
+        if (g.streamk) {
+            trem = (int)(u / nkt);
+            kt0 = (int)(u % nkt);
+            nk = (int)((ue - u < (long long)(nkt - kt0)) ? (ue - u) : (long long)(nkt - kt0));
+            // first block whose range reaches unit trem*nkt
+            const long long fb = (((long long)trem * nkt + 1) * nblk - 1) / U;
+            split = bid - (int)fb;
+            u += nk;
+            if (nk <= 0) break;
+        } else {
+            split = bid / tiles;
+            trem = bid % tiles;
+            kt0 = split * nkt;
+            nk = nkt;
         }
+        int tr, tc;
+        if (g.group > 1) {
+            // 2-D super-tiles of group x group block tiles (both tile counts are multiples of `group`): the blocks of
+            // one super-tile are consecutive logical ids, i.e. they run on ONE XCD at about the same time, so each
+            // operand tile is fetched into that XCD's 4 MiB L2 once and re-used `group` times (outputs that are large
+            // in both dimensions -- W*H for the objective / the ratio pass -- otherwise re-stream one operand per tile row).
+            const int G = g.group, per = G * G;
+            const int st = trem / per, in = trem % per;
+            const int sr = st / (g.tiles_c / G), sc = st % (g.tiles_c / G);
+            tr = sr * G + in / G;
+            tc = sc * G + in % G;
+        } else if (g.c_fastest) { tc = trem % g.tiles_c; tr = trem / g.tiles_c; }
+        else                    { tr = trem % g.tiles_r; tc = trem / g.tiles_r; }
+        const int64_t r0 = (int64_t)tr * BR, c0 = (int64_t)tc * BC;
+        const int64_t kbeg = (int64_t)kt0 * BK;
+        const T *Ab = g.A, *Bb = g.B;
+        int64_t lda = g.lda, ldb = g.ldb, ra0 = r0, cb0 = c0;
+        if (r0 >= g.r_split) { Ab = g.A2; lda = g.lda2; ra0 = r0 - g.r_split; }
+        if (c0 >= g.c_split) { Bb = g.B2; ldb = g.ldb2; cb0 = c0 - g.c_split; }
+        tctx.tr = tr; tctx.tc = tc; tctx.r0 = r0; tctx.c0 = c0;
+
+        typename M::acc_t acc[TR][TC];
+    #pragma unroll
+        for (int i = 0; i < TR; ++i)
+    #pragma unroll
+            for (int j = 0; j < TC; ++j)
+    #pragma unroll
+                for (int r = 0; r < M::NACC; ++r) acc[i][j][r] = (T)0;
+
+        // Software pipeline (one barrier per k-tile, no MFMA-free phase besides it):
+        //   registers hold k-tile t+1 while the MFMAs of tile t run out of LDS stage t&1;
+        //   first half of the k-groups : registers -> LDS stage (t+1)&1   (ds_write interleaved with MFMAs)
+        //   second half                : global   -> registers, tile t+2  (loads interleaved with MFMAs)
+        // Stage (t+1)&1 was last read during tile t-1, i.e. before the barrier that ended iteration t-1.
+        typename M::vec_t ra[LoadA::PER_THREAD], rb[LoadB::PER_THREAD];
+        LoadA::load(ra, Ab, lda, ra0, kbeg, tid, g.a_nslab, g.a_slab_stride);
+        LoadB::load(rb, Bb, ldb, cb0, kbeg, tid, g.b_nslab, g.b_slab_stride);
+        LoadA::store(ra, smem, tid);
+        LoadB::store(rb, smem + BR * BK, tid);
+        {
+            const int64_t k1 = kbeg + (int64_t)((nk > 1) ? 1 : 0) * BK;
+            LoadA::load(ra, Ab, lda, ra0, k1, tid, g.a_nslab, g.a_slab_stride);
+            LoadB::load(rb, Bb, ldb, cb0, k1, tid, g.b_nslab, g.b_slab_stride);
+        }
+        __syncthreads();
+
+        constexpr int NG = BK / 8;   // k-groups per tile
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            const T *a_s = smem + cur * STAGE, *b_s = a_s + BR * BK;
+            T *a_n = smem + (cur ^ 1) * STAGE, *b_n = a_n + BR * BK;
+            const int tn = (t + 2 < nk) ? t + 2 : nk - 1;   // clamped: the last iterations re-load the final tile (never used)
+            const int64_t kn = kbeg + (int64_t)tn * BK;
+            static_for<NG>([&](auto KGC) {
+                constexpr int kg = decltype(KGC)::value;
+                T af[TR][M::VEC], bf[TC][M::VEC];
+    #pragma unroll
+                for (int i = 0; i < TR; ++i) read_frag<T, LA, BR>(af[i], a_s, wr * WTR + i * MT, kg, lane);
+    #pragma unroll
+                for (int j = 0; j < TC; ++j) read_frag<T, LB, BC>(bf[j], b_s, wc * WTC + j * MT, kg, lane);
+                constexpr bool stA = (kg == 0), stB = (kg == (NG > 2 ? 1 : 0));
+                constexpr bool ldA = (kg == NG / 2), ldB = (kg == (NG > 2 ? NG / 2 + 1 : NG / 2));
+                if constexpr (stA) LoadA::store(ra, a_n, tid);
+                if constexpr (stB) LoadB::store(rb, b_n, tid);
+                if constexpr (ldA) LoadA::load(ra, Ab, lda, ra0, kn, tid, g.a_nslab, g.a_slab_stride);
+                if constexpr (ldB) LoadB::load(rb, Bb, ldb, cb0, kn, tid, g.b_nslab, g.b_slab_stride);
+    #pragma unroll
+                for (int q = 0; q < M::VEC; ++q)
+    #pragma unroll
+                    for (int i = 0; i < TR; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TC; ++j) acc[i][j] = M::mma(af[i][q], bf[j][q], acc[i][j]);
+                // Issue-order template for this k-group (LLVM sched_group_barrier; masks: MFMA 0x8, VMEM read 0x20,
+                // DS read 0x100, DS write 0x200): fragment reads first, then the staging traffic of this group spread
+                // one instruction per MFMA pair, so neither the LDS writes nor the global loads open an MFMA-free window.
+                constexpr int NMFMA = M::VEC * TR * TC;
+                constexpr int NFRAG = (LA == KCONTIG ? TR : TR * M::VEC) + (LB == KCONTIG ? TC : TC * M::VEC);
+                constexpr int NW0 = (stA ? LoadA::PER_THREAD : 0) + (stB ? LoadB::PER_THREAD : 0);
+                constexpr int NL0 = (ldA ? LoadA::PER_THREAD : 0) + (ldB ? LoadB::PER_THREAD : 0);
+                constexpr int NW = (2 * NW0 <= NMFMA) ? NW0 : NMFMA / 2;
+                constexpr int NL = (2 * (NW + NL0) <= NMFMA) ? NL0 : (NMFMA / 2 - NW);
+                __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
+                sched_pairs<0x200, NW>();
+                sched_pairs<0x20, NL>();
+                if constexpr (NMFMA - 2 * (NW + NL) > 0) __builtin_amdgcn_sched_group_barrier(0x8, NMFMA - 2 * (NW + NL), 0);
+            });
+            __syncthreads();
+        }
+
+        // Epilogue.  MFMA C/D layout: f32 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
+        // f64 16x16: col = lane&15, row = (lane>>4) + 4*reg.  col <-> c (contiguous), row <-> r.
+        epi.begin(split, tctx);
+    #pragma unroll
+        for (int i = 0; i < TR; ++i)
+    #pragma unroll
+            for (int j = 0; j < TC; ++j) {
+                const int64_t c = c0 + wc * WTC + j * MT + (lane % MT);
+                const int64_t rbase = r0 + wr * WTR + i * MT;
+                // two phases per MFMA tile: issue every global load of the epilogue first, then compute and store.
+                // (Inputs and outputs of an epilogue may alias as far as the compiler knows, so a fused
+                // load-compute-store per element serialises one memory round trip per element.)
+                typename Epi::Pre pre[M::NACC];
+    #pragma unroll
+                for (int reg = 0; reg < M::NACC; ++reg) {
+                    int64_t r;
+                    if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    else r = rbase + (lane >> 4) + 4 * reg;
+                    pre[reg] = epi.prefetch(r, c);
+                }
+    #pragma unroll
+                for (int reg = 0; reg < M::NACC; ++reg) {
+                    int64_t r;
+                    if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    else r = rbase + (lane >> 4) + 4 * reg;
+                    epi.apply(r, c, acc[i][j][reg], j, pre[reg]);
+                }
+            }
+    }
     epi.template finish<MT, TC, WGR, WGC>(reinterpret_cast<double *>(smem), tctx);
 }
 

@@ -124,7 +124,18 @@ template <typename T> class Solver : public SolverBase {
         s_gh = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), N);
         // slab buffer = [ big-GEMM slabs | Gram slabs ]: the two live side by side so the update GEMM can consume
         // the un-reduced numerator slabs directly in its epilogue
-        gram_slab_off = std::max((size_t)s_h * K * (N + K), (size_t)s_w * (P * K + K * K));
+        sk_grid = 2 * num_cu;
+        auto sk_slabs = [&](int64_t tiles, int64_t kdim) {
+            const int64_t nkt = kdim / BK, U = tiles * nkt;
+            const int64_t per = std::max<int64_t>(1, U / std::min<int64_t>(sk_grid, U));
+            return (int)((nkt + per - 1) / per) + 1;
+        };
+        sk_sh = sk_slabs(((N + K) / 128) * ((K + 127) / 128), P);
+        sk_sw = sk_slabs(((P + K) / 128) * ((K + 127) / 128), N);
+        const size_t h_region = std::max((size_t)s_h * K * N, (size_t)sk_sh * K * (N + K));
+        const size_t w_region = std::max((size_t)s_w * P * K, (size_t)sk_sw * ((size_t)P * K + (size_t)K * K));
+        slab_w_off = h_region;
+        gram_slab_off = h_region + w_region;
         slabs.alloc(gram_slab_off + std::max((size_t)s_gw * K * K, (size_t)s_gh * K * K));
         stat_chunks_w = (int)std::max<int64_t>(1, std::min<int64_t>(64, P / 1024));
         stat_chunks_h = (int)std::max<int64_t>(1, std::min<int64_t>(256, N / 64));
@@ -267,9 +278,13 @@ template <typename T> class Solver : public SolverBase {
     int last_blocks = 1;    // blocks of the most recent GEMM launch (= number of its objective partials)
     bool have_X = false, have_F = false;
     // Fusing the k x k Gram into the big GEMM launch adds (K/128)^2 tiles to a grid that otherwise fills the 512
-    // block slots exactly (256 tiles x 2 splits @C3): the 8 extra blocks form a second wave and cost +50 % (measured
-    // 1584 vs 1053+27 us).  Kept behind a flag until the grid is stream-K balanced.
-    bool fuse_gram = false;
+    // block slots exactly (256 tiles x 2 splits @C3); with plain split-K the 8 extra blocks form a second wave
+    // (+50 %: 1505 vs 1010 us).  The fused launches therefore use the stream-K decomposition (1030 us).
+    bool fuse_gram = true;    // K % 128 == 0: Gram rides in the big GEMM launch (stream-K balanced grid)
+    int sk_grid = 512;        // stream-K grid: 2 resident blocks per CU
+    int sk_sh = 2, sk_sw = 2; // stream-K slabs per tile (H side / W side)
+    size_t slab_w_off = 0;    // W-side slab region (regions are disjoint so never-written slabs stay zero)
+    long long sig_h = -1, sig_w = -1;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
 
@@ -298,7 +313,7 @@ template <typename T> class Solver : public SolverBase {
 
     template <typename F> void timed(const char *name, double flops, double bytes, F &&launch) {
         if (!profiling) { launch(); return; }
-        if (profiling == 2 && (flops < 1e10 || (prof_tick++ & 3) != 0)) { launch(); return; }
+        if (profiling == 2 && (flops < 1e10 || (((prof_tick++) >> 1) & 3) != 0)) { launch(); return; }   // two big GEMMs per iteration: sample both, every 4th iteration
         if (ev_used == (int)ev_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));
@@ -314,7 +329,10 @@ template <typename T> class Solver : public SolverBase {
 
     template <int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi>
     void launch_gemm_cfg(const GemmArgs<T> &g, const Epi &epi) {
-        const int blocks = g.tiles_r * g.tiles_c * g.splits;
+        // stream-K: never more blocks than (tile, k-tile) units -- every block must own >= 1 unit for the
+        // slab numbering `bid - first_block(tile)` to stay below the slab count
+        const int blocks = g.streamk ? (int)std::min<int64_t>(sk_grid, (int64_t)g.tiles_r * g.tiles_c * g.nkt)
+                                     : g.tiles_r * g.tiles_c * g.splits;
         hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi>), dim3(blocks), dim3(WGR * WGC * 64), 0,
                            stream, g, epi);
         HIP_TRY(hipGetLastError());
@@ -325,6 +343,7 @@ template <typename T> class Solver : public SolverBase {
         const T *A2 = nullptr; int64_t lda2 = 0, r_split = INT64_MAX;
         const T *B2 = nullptr; int64_t ldb2 = 0, c_split = INT64_MAX;
         int a_nslab = 1, b_nslab = 1; int64_t a_slab_stride = 0, b_slab_stride = 0;
+        int streamk = 0;
     };
     template <int LA, int LB, typename Epi>
     void gemm(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim,
@@ -334,12 +353,13 @@ template <typename T> class Solver : public SolverBase {
         g.A2 = seg.A2; g.lda2 = seg.lda2; g.r_split = seg.r_split;
         g.B2 = seg.B2; g.ldb2 = seg.ldb2; g.c_split = seg.c_split;
         g.a_nslab = seg.a_nslab; g.b_nslab = seg.b_nslab; g.a_slab_stride = seg.a_slab_stride; g.b_slab_stride = seg.b_slab_stride;
+        g.streamk = seg.streamk; g.nkt = (int)(Kdim / BK);
         g.splits = splits;
         g.kchunk = (int)(Kdim / splits);
         g.c_fastest = c_fastest ? 1 : 0;
         g.done = done;
         const double flops = 2.0 * (double)R * (double)C * (double)Kdim;
-        auto note = [&] { last_tiles_r = g.tiles_r; last_blocks = g.tiles_r * g.tiles_c * g.splits; };
+        auto note = [&] { last_tiles_r = g.tiles_r; last_blocks = g.streamk ? (int)std::min<int64_t>(sk_grid, (int64_t)g.tiles_r * g.tiles_c * g.nkt) : g.tiles_r * g.tiles_c * g.splits; };
         // Short contractions (the k x k Gram products: 8 k-tiles) are dominated by prologue/epilogue latency; give
         // them half-size tiles so >= 2 blocks per CU are resident and one block's epilogue overlaps another's MFMAs.
         const bool small_k = (Kdim <= 1024) && splits == 1 && ((R / 128) * (C / 128) < 2 * (int64_t)num_cu);
@@ -370,11 +390,13 @@ template <typename T> class Solver : public SolverBase {
         note();
     }
 
-    void reduce_slabs_from(const char *name, T *dst, const T *src, int64_t count, int nslab, const int *done) {
+    void reduce_slabs_from(const char *name, T *dst, const T *src, int64_t count, int nslab, const int *done,
+                           int64_t stride = -1) {
+        if (stride < 0) stride = count;
         timed(name, 0.0, (double)count * (nslab + 1) * sizeof(T), [&] {
             const int bs = 256;
             hipLaunchKernelGGL(reduce_slabs_kernel<T>, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, stream, dst,
-                               src, count, nslab, count, done);
+                               src, count, nslab, stride, done);
             HIP_TRY(hipGetLastError());
         });
     }
@@ -385,52 +407,106 @@ template <typename T> class Solver : public SolverBase {
     // ---- shared building blocks ------------------------------------------------
     void reduce_to(const char *name, T *dst, int64_t count, int nslab, const int *done) { reduce_slabs(name, dst, count, nslab, done); }
 
+    // Make sure a slab region only ever holds the slabs of ONE launch shape: stream-K leaves the slabs a tile does
+    // not use untouched, and consumers add all of them, so they must be zero.
+    void claim_region(long long &sig, long long want, T *base, size_t elems) {
+        if (sig == want) return;
+        HIP_TRY(hipMemsetAsync(base, 0, elems * sizeof(T), stream));
+        sig = want;
+    }
+
     // numH = W' * Bmat  (K x N, ld K), Bmat = X or Q (P x N)      src/multupd.jl:98,175; projals.jl:93; alspgrad.jl:66
     // with_gram: also gramW = W'W (src/projals.jl:92, alspgrad.jl:65) in the SAME launch: the A operand is the
-    // row-concatenation [Bmat ; W], the output the K x (N+K) matrix [numH | gramW].
+    // row-concatenation [Bmat ; W], the output the K x (N+K) matrix [numH | gramW] (hside).
+    // keep_slabs: leave the result as split-K slabs in the H region (caller consumes h_nslab slabs of stride h_stride).
+    int h_nslab = 1;
+    int64_t h_stride = 0;
     void wt_times(const T *Wp, const T *Bmat, bool with_gram, const int *done, bool keep_slabs = false) {
+        T *reg = slabs.p;
         if (with_gram && fuse_gram && K % 128 == 0) {
-            EpiStore<T> e{slabs.p, K, (int64_t)K * (N + K), nullptr};
+            h_nslab = sk_sh; h_stride = (int64_t)K * (N + K);
+            claim_region(sig_h, 1, reg, (size_t)h_nslab * h_stride);
+            EpiStore<T> e{reg, K, h_stride, nullptr};
             Seg sg;
-            sg.A2 = Wp; sg.lda2 = P; sg.r_split = N;
-            gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N + K, Wp, P, K, P, s_h, true, e, done,
+            sg.A2 = Wp; sg.lda2 = P; sg.r_split = N; sg.streamk = 1;
+            gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N + K, Wp, P, K, P, h_nslab, true, e, done,
                                    (double)(P * N + 2 * P * K) * sizeof(T), sg);
-            reduce_slabs("reduce_WtX", hside.p, (int64_t)K * (N + K), s_h, done);
+            if (!keep_slabs || h_nslab > 4) {
+                reduce_slabs_from("reduce_WtX", hside.p, reg, h_stride, h_nslab, done);
+                h_in_slabs = false;
+            } else {
+                // the k x k Gram is an OPERAND of the next GEMM (re-read by every block): reduce it (tiny) now;
+                // the numerator is touched once per element and is summed in that GEMM's epilogue.
+                reduce_slabs_from("reduce_WtW", gramW_p, reg + (size_t)K * N, (int64_t)K * K, h_nslab, done, h_stride);
+                h_in_slabs = true;
+            }
             return;
         }
-        EpiStore<T> e{slabs.p, K, (int64_t)K * N, nullptr};
+        h_nslab = s_h; h_stride = (int64_t)K * N;
+        claim_region(sig_h, 2, reg, (size_t)h_nslab * h_stride);
+        EpiStore<T> e{reg, K, h_stride, nullptr};
         gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                (double)(P * N + P * K) * sizeof(T));
-        if (!keep_slabs) reduce_slabs("reduce_WtX", numH_p, (int64_t)K * N, s_h, done);
+        if (!keep_slabs || h_nslab > 4) {
+            reduce_slabs_from("reduce_WtX", numH_p, reg, h_stride, h_nslab, done);
+            h_in_slabs = false;
+        } else {
+            h_in_slabs = true;
+        }
         if (with_gram) {
             EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
             gemm<KCONTIG, KCONTIG>("gemm_WtW", Wp, P, K, Wp, P, K, P, s_gw, true, eg, done, (double)(P * K) * sizeof(T));
             reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gw, done);
         }
     }
+    // after wt_times(..., with_gram=true): where the numerator / the Gram operand live
+    bool h_in_slabs = false, w_in_slabs = false;
+    const T *h_num() const { return h_in_slabs ? slabs.p : numH_p; }
+    int h_num_nslab() const { return h_in_slabs ? h_nslab : 1; }
+
     // numW = Amat * H'  (P x K, ld P), Amat = X or Q              src/multupd.jl:109,187; projals.jl:101; alspgrad.jl:221
     // with_gram: also gramH = HH' (src/projals.jl:100, alspgrad.jl:220) in the same launch: B operand = [Amat ; H],
     // slab = [ numW (ld P) | gramH (ld K) ] = the layout of the packed all-reduce buffer.
+    int w_nslab = 1;
+    int64_t w_stride = 0;
     void times_ht(const T *Amat, const T *Hp, bool with_gram, const int *done, bool keep_slabs = false) {
+        T *reg = slabs.p + slab_w_off;
         if (with_gram && fuse_gram && K % 128 == 0) {
-            EpiStore2<T> e{slabs.p, P, P, K, (int64_t)P * K, (int64_t)P * K + (int64_t)K * K, nullptr};
+            w_nslab = sk_sw; w_stride = (int64_t)P * K + (int64_t)K * K;
+            claim_region(sig_w, 1, reg, (size_t)w_nslab * w_stride);
+            EpiStore2<T> e{reg, P, P, K, (int64_t)P * K, w_stride, nullptr};
             Seg sg;
-            sg.B2 = Hp; sg.ldb2 = K; sg.c_split = P;
-            gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P + K, N, s_w, false, e, done,
+            sg.B2 = Hp; sg.ldb2 = K; sg.c_split = P; sg.streamk = 1;
+            gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P + K, N, w_nslab, false, e, done,
                                      (double)(P * N + 2 * K * N) * sizeof(T), sg);
-            reduce_slabs("reduce_XHt", pack.p, (int64_t)P * K + (int64_t)K * K, s_w, done);
+            if (!keep_slabs || w_nslab > 4) {
+                reduce_slabs_from("reduce_XHt", pack.p, reg, w_stride, w_nslab, done);
+                w_in_slabs = false;
+            } else {
+                reduce_slabs_from("reduce_HHt", gramH_p, reg + (size_t)P * K, (int64_t)K * K, w_nslab, done, w_stride);
+                w_in_slabs = true;
+            }
             return;
         }
-        EpiStore<T> e{slabs.p, P, (int64_t)P * K, nullptr};
+        w_nslab = s_w; w_stride = (int64_t)P * K;
+        claim_region(sig_w, 2, reg, (size_t)w_nslab * w_stride);
+        EpiStore<T> e{reg, P, w_stride, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                  (double)(P * N + K * N) * sizeof(T));
-        if (!keep_slabs) reduce_slabs("reduce_XHt", numW_p, (int64_t)P * K, s_w, done);
+        if (!keep_slabs || w_nslab > 4) {
+            reduce_slabs_from("reduce_XHt", numW_p, reg, w_stride, w_nslab, done);
+            w_in_slabs = false;
+        } else {
+            w_in_slabs = true;
+        }
         if (with_gram) {
             EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
             gemm<KSTRIDED, KSTRIDED>("gemm_HHt", Hp, K, K, Hp, K, K, N, s_gh, true, eg, done, (double)(K * N) * sizeof(T));
             reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gh, done);
         }
     }
+    const T *w_num() const { return w_in_slabs ? slabs.p + slab_w_off : numW_p; }
+    int w_num_nslab() const { return w_in_slabs ? w_nslab : 1; }
 
     void stats_w(const T *Wn, const T *Wo, const int *done) {
         timed("stats_W", 0.0, 2.0 * P * K * sizeof(T), [&] {

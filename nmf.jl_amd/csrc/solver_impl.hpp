@@ -81,11 +81,12 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
         const T *Wp = W[wcur].p;
         const T *Ho = H[hcur].p;
         T *Hn = H[hcur ^ 1].p;
-        // :98 W'X stays as split-K slabs: the update GEMM's epilogue sums them (ascending slab order, identical to
-        // reduce_slabs_kernel) and also produces the stop_condition statistics of H -- two launches less per iteration
+        // :98 W'X (and W'W, same launch) stay as split-K slabs: the Gram slabs get a tiny reduction, the update GEMM sums
+        // the numerator slabs in its epilogue (ascending slab order, like reduce_slabs_kernel), and it also
+        // produces the stop_condition statistics of H -- three launches for the whole H phase.
         wt_times(Wp, X.p, true, done, /*keep_slabs=*/true);
-        EpiMultUpdate<T, 1> e{slabs.p, s_h, (int64_t)K * N, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};  // :99-103
-        gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (3.0 + s_h) * K * N * sizeof(T));
+        EpiMultUpdate<T, 1> e{h_num(), h_num_nslab(), h_stride, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};  // :99-103
+        gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (3.0 + h_num_nslab()) * K * N * sizeof(T));
         stats_h_finalize(last_tiles_r, done);
         hcur ^= 1;
     }
@@ -97,8 +98,7 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
     const bool w_slabs = (nranks == 1);
     times_ht(X.p, Hp, true, done, /*keep_slabs=*/w_slabs);
     allreduce_w_side(o.update_H != 0, done);
-    EpiMultUpdate<T, 0> e{w_slabs ? slabs.p : numW_p, w_slabs ? s_w : 1, (int64_t)P * K, Wo, Wn, P, (T)o.lambda_w, (T)o.delta,
-                          nullptr, 0};                                     // :110-114
+    EpiMultUpdate<T, 0> e{w_num(), w_num_nslab(), w_stride, Wo, Wn, P, (T)o.lambda_w, (T)o.delta, nullptr, 0};   // :110-114
     gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo, P, P, K, 1, false, e, done, 3.0 * P * K * sizeof(T));
     stats_w(Wn, Wo, done);
     wcur ^= 1;

@@ -1,0 +1,120 @@
+"""Parity at the BASELINE.json sizes.
+
+C2 (4096 x 4096, k=64, f32): the NumPy oracle still finishes in seconds, so the objective trajectory is compared
+iteration for iteration like in the small tests.
+C3 (16384 x 16384, k=256, f32): the oracle needs ~10 s per iteration, so one iteration is checked through
+size-independent pieces of the update rule instead (SURVEY.md section 8c "size-independent properties"):
+  * H-update columns: H_new[:, J] depends only on X[:, J], H[:, J] and W  -> fp64 NumPy on a column sample
+  * W-update rows:    W_new[I, :] depends only on X[I, :], W[I, :] and H_new -> fp64 NumPy on a row sample
+  * the objective of the final factors against a full fp64-accumulated NumPy evaluation
+  * monotone non-increasing objective, non-negativity, zero-preservation (multiplicative updates keep exact zeros)
+"""
+import numpy as np
+import pytest
+import torch
+
+import nmf_oracle as orc
+import nmfx
+from problems import planted, rel_trace_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("obj", ["mse", "div"])
+def test_c2_trajectory(built, obj):
+    T = np.float32
+    p = n = 4096
+    k = 64
+    X, W0, H0 = planted(p, n, k, T, seed=4096)
+    alg = nmfx.MultUpdate(T, obj=obj, maxiter=6, tol=1e-30)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg, track_objective=True)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("mult" + obj, X, Wc, Hc, orc.Opts(maxiter=6, tol=1e-30, track_objective=True))
+    assert r.niters == ro.niters == 6
+    assert rel_trace_err(r.trace, ro.trace) < 1e-5          # north_star: objective within 1e-5 relative
+    assert np.max(np.abs(Wg - Wc)) <= 1e-3 * np.max(np.abs(Wc))
+    assert np.max(np.abs(Hg - Hc)) <= 1e-3 * np.max(np.abs(Hc))
+
+
+def _c3_inputs():
+    p = n = 16384
+    k = 256
+    g = torch.Generator(device="cuda")
+    g.manual_seed(16384)
+    Wg = torch.rand((p, k), generator=g, device="cuda")
+    Hg = torch.rand((k, n), generator=g, device="cuda")
+    Xt = Hg.t().contiguous() @ Wg.t().contiguous()                      # (n, p) row-major == X column-major
+    Xt.add_(torch.rand(Xt.shape, generator=g, device="cuda"), alpha=0.01)
+    X = np.asfortranarray(Xt.cpu().numpy().T)
+    rng = np.random.default_rng(3)
+    W0 = rng.random((p, k), dtype=np.float32)
+    W0 /= W0.sum(axis=0, keepdims=True)
+    H0 = rng.random((k, n), dtype=np.float32)
+    W0[::97, 3] = 0.0                                                    # exact zeros must survive multiplicative updates
+    H0[5, ::101] = 0.0
+    return X, np.asfortranarray(W0), np.asfortranarray(H0)
+
+
+def test_c3_multmse_one_iteration_pieces(built):
+    T = np.float32
+    X, W0, H0 = _c3_inputs()
+    p, n = X.shape
+    k = W0.shape[1]
+    delta = float(T(np.sqrt(np.finfo(T).eps)))
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+        o = nmfx.make_opts(T, maxiter=1, tol=1e-30, track_objective=True)
+        res, trace = ctx.solve(0, o, W1, H1)
+        assert res.niters == 1
+        # --- H update on a column sample (fp64 reference of src/multupd.jl:98-103 in Gram form)
+        J = np.random.default_rng(0).choice(n, 96, replace=False)
+        W64 = W0.astype(np.float64)
+        num = W64.T @ X[:, J].astype(np.float64)
+        den = (W64.T @ W64) @ H0[:, J].astype(np.float64) + delta
+        Href = H0[:, J] * (np.maximum(num, 0) / den)
+        assert np.max(np.abs(H1[:, J] - Href)) <= 2e-5 * np.max(np.abs(Href))
+        # --- W update on a row sample (uses the NEW H, src/multupd.jl:109-114)
+        I = np.random.default_rng(1).choice(p, 64, replace=False)
+        H64 = H1.astype(np.float64)
+        numw = X[I, :].astype(np.float64) @ H64.T
+        denw = W0[I, :].astype(np.float64) @ (H64 @ H64.T) + delta
+        Wref = W0[I, :] * (np.maximum(numw, 0) / denw)
+        assert np.max(np.abs(W1[I, :] - Wref)) <= 2e-5 * np.max(np.abs(Wref))
+        # --- objective of the result: fp32 product like the reference, Float64 accumulation (sqL2dist)
+        WH = W1 @ H1
+        d = X - WH
+        ref_obj = 0.5 * float(np.sum((d * d).astype(np.float64)))
+        assert abs(trace[1] - ref_obj) <= 1e-5 * ref_obj
+        # --- properties
+        assert np.all(W1 >= 0) and np.all(H1 >= 0) and np.isfinite(W1).all() and np.isfinite(H1).all()
+        assert not W1[::97, 3].any() and not H1[5, ::101].any()
+        # a few more iterations: Lee-Seung updates never increase the objective (lambda = 0)
+        o = nmfx.make_opts(T, maxiter=4, tol=1e-30, track_objective=True)
+        res, tr2 = ctx.solve(0, o, W1, H1)
+        assert np.all(np.diff(tr2[: res.niters + 1]) <= 1e-6 * tr2[0])
+
+
+def test_c3_multdiv_properties(built):
+    T = np.float32
+    X, W0, H0 = _c3_inputs()
+    p, n = X.shape
+    k = W0.shape[1]
+    eps = np.finfo(T).eps
+    lam = float(T(np.sqrt(eps)))
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+        o = nmfx.make_opts(T, maxiter=3, tol=1e-30, track_objective=True, lambda_w=lam, lambda_h=lam)
+        res, trace = ctx.solve(1, o, W1, H1)
+        assert res.niters == 3
+        assert np.all(np.diff(trace[:4]) <= 1e-6 * trace[0])           # KL multiplicative updates are monotone too
+        assert np.all(W1 >= 0) and np.all(H1 >= 0) and np.isfinite(W1).all() and np.isfinite(H1).all()
+        assert not W1[::97, 3].any() and not H1[5, ::101].any()
+        # generalized KL divergence of the final factors (gkldiv, term in T, Float64 accumulation)
+        WH = W1 @ H1
+        pos = X > 0
+        t = np.where(pos, X * np.log(np.where(pos, X, 1) / WH) - X + WH, WH)
+        ref = float(np.sum(t.astype(np.float64)))
+        assert abs(trace[3] - ref) <= 2e-5 * abs(ref)

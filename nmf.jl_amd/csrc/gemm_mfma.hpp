@@ -76,8 +76,9 @@ template <typename T> struct GemmArgs {
     int a_nslab = 1, b_nslab = 1;
     int64_t a_slab_stride = 0, b_slab_stride = 0;
     int group = 1;          // >1: super-tile rasterisation (see the block -> tile mapping)
-    int streamk = 0;        // 1: stream-K decomposition over gridDim.x blocks (see the kernel)
-    int nkt = 0;            // stream-K: k-tiles per output tile (= Kdim / BK)
+    int tail_tiles = 0;     // extra output tiles along the slow tile direction, done as a balanced second segment
+    int tail_nkt = 0;       // k-tiles of a tail tile (= Kdim / BK)
+    int tail_per = 0;       // k-tiles of one tail piece (one piece per block)
 };
 
 // what an epilogue may need to know about the block / wave it runs in
@@ -190,36 +191,38 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int tiles = g.tiles_r * g.tiles_c;
     // Work decomposition.
-    //   plain split-K : block = (tile, split); split s handles k-tiles [s*kchunk/BK, (s+1)*kchunk/BK) and writes slab s.
-    //   stream-K      : the (tile, k-tile) space, tile-major, is cut into gridDim.x equal contiguous ranges -- a block
-    //                   may finish one tile and start the next.  Every block does the same number of k-tiles (+-1), so a
-    //                   grid of exactly 2 blocks per CU has no wave-quantisation tail whatever the tile count is
-    //                   (this is what lets the k x k Gram ride in the same launch as the big GEMM).  Segment number
-    //                   `bid - first_block(tile)` selects the slab; slabs a tile never writes stay zero (the host zeroes
-    //                   the buffer once per shape), so consumers simply add all `splits` slabs.
-    const int nkt = g.streamk ? g.nkt : g.kchunk / BK;
-    long long u = 0, ue = 0;
-    const long long U = (long long)tiles * nkt;
-    if (g.streamk) { u = ((long long)bid * U) / nblk; ue = ((long long)(bid + 1) * U) / nblk; }
+    //   main part : block = (tile, split) over the tiles_r x tiles_c MAIN tiles; split s handles k-tiles
+    //               [s*kchunk/BK, (s+1)*kchunk/BK) and writes slab s.  All blocks of a split walk k in lockstep, so the
+    //               operand slices they share (W for every X tile, the X tile for both c-tiles) are L2 hits.
+    //   tail part : `tail_tiles` extra output tiles appended along the slow tile direction (the k x k Gram riding in the
+    //               big GEMM launch).  Their (tile, k-tile) units are dealt out evenly, `tail_per` k-tiles per block, as
+    //               a second short segment of every block: each block does kchunk/BK + tail_per k-tiles, so a grid of
+    //               exactly 2 blocks per CU stays balanced (a plain extra-tiles grid would put the 8 Gram blocks into a
+    //               second wave: +50 %), and the main part keeps its k-alignment (a full stream-K split de-phases the
+    //               blocks in k and re-fetches W from the fabric for every tile row: 2.9 GB instead of 1.3 GB per launch).
+    //               Tail piece p of a tail tile writes tail slab p (epilogue: begin(-1 - p)).
+    const int nkt = g.kchunk / BK;
     TileCtx tctx{0, 0, wr, wc, lane, tid, NT, (int)blockIdx.x, 0, 0};
-    bool first_seg = true;
-    while (first_seg || (g.streamk && u < ue)) {
-        first_seg = false;
+    for (int phase = 0; phase < 2; ++phase) {
         int trem, split, kt0, nk;
-        if (g.streamk) {
-            trem = (int)(u / nkt);
-            kt0 = (int)(u % nkt);
-            nk = (int)((ue - u < (long long)(nkt - kt0)) ? (ue - u) : (long long)(nkt - kt0));
-            // first block whose range reaches unit trem*nkt
-            const long long fb = (((long long)trem * nkt + 1) * nblk - 1) / U;
-            split = bid - (int)fb;
-            u += nk;
-            if (nk <= 0) break;
-        } else {
+        bool tail = false;
+        if (phase == 0) {
             split = bid / tiles;
             trem = bid % tiles;
             kt0 = split * nkt;
             nk = nkt;
+        } else {
+            if (g.tail_tiles == 0) break;
+            const int inner = g.c_fastest ? g.tiles_c : g.tiles_r;     // tail tiles extend the slow (outer) direction
+            const int pieces_per_tile = (g.tail_nkt + g.tail_per - 1) / g.tail_per;
+            const int piece = bid % pieces_per_tile, ttile = bid / pieces_per_tile;
+            if (ttile >= g.tail_tiles * inner) break;
+            kt0 = piece * g.tail_per;
+            nk = (g.tail_nkt - kt0 < g.tail_per) ? (g.tail_nkt - kt0) : g.tail_per;
+            if (nk <= 0) break;
+            split = -1 - piece;
+            trem = tiles + ttile;          // tile ids continue past the main tiles along the outer direction
+            tail = true;
         }
         int tr, tc;
         if (g.group > 1) {
@@ -347,32 +350,22 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
 // apply(r, c, v, jt, pre) receives D(r, c) and stores.  The element lives at  base[c + r*ld].
 // ---------------------------------------------------------------------------
 
-// C (or split-K slab `split`) = acc
+// C (or split-K slab `split`) = acc.  Tail segments (split < 0, see the kernel's work decomposition) go to a second
+// matrix: tail slab p = C2 + p*stride2, element (r, c) at (c - c_off) + (r - r_off)*ld2.
 template <typename T> struct EpiStore {
     T *C;
     int64_t ld, slab_stride;
     T *dst;
+    T *C2 = nullptr;
+    int64_t ld2 = 0, stride2 = 0, r_off = 0, c_off = 0;
+    int64_t ldc;
     struct Pre {};
-    __device__ __forceinline__ void begin(int split, const TileCtx &) { dst = C + (int64_t)split * slab_stride; }
-    __device__ __forceinline__ Pre prefetch(int64_t, int64_t) const { return Pre{}; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &) { dst[c + r * ld] = v; }
-    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
-};
-
-// Split-K slab store with two destinations: columns c < c_split go to the main output (ld), columns
-// c >= c_split to a second matrix (ld2) placed right behind it inside the same slab.  Used by the fused
-// [X ; H] * H' launch: slab = [ XH' (c_split x R, ld = c_split) | HH' (ld2 x R, ld2) ].
-template <typename T> struct EpiStore2 {
-    T *C;
-    int64_t ld, c_split, ld2, off2, slab_stride;
-    T *dst;
-    __device__ __forceinline__ void begin(int split, const TileCtx &) { dst = C + (int64_t)split * slab_stride; }
-    struct Pre {};
-    __device__ __forceinline__ Pre prefetch(int64_t, int64_t) const { return Pre{}; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &) {
-        if (c < c_split) dst[c + r * ld] = v;
-        else dst[off2 + (c - c_split) + r * ld2] = v;
+    __device__ __forceinline__ void begin(int split, const TileCtx &) {
+        if (split >= 0) { dst = C + (int64_t)split * slab_stride; ldc = ld; }
+        else { dst = C2 + (int64_t)(-1 - split) * stride2 - (c_off + r_off * ld2); ldc = ld2; }
     }
+    __device__ __forceinline__ Pre prefetch(int64_t, int64_t) const { return Pre{}; }
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &) { dst[c + r * ldc] = v; }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 

@@ -36,6 +36,33 @@ __global__ void reduce_slabs_kernel(T *dst, const T *src, int64_t count, int nsl
     dst[i] = s;
 }
 
+// Same sum for MANY slabs of a small matrix (the tail pieces of the fused Gram: ~128 slabs of k x k).  A thread per
+// element would chain `nslab` dependent loads; here 4 slab-lanes per element each add every 4th slab with 8 loads in
+// flight, then the 4 partial sums are combined in a fixed order (((l0 + l1) + l2) + l3): deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_many_slabs_kernel(T *dst, const T *src, int64_t count, int nslab, int64_t stride,
+                                                                const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ T sm[4][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + e;
+    T acc = (T)0;
+    if (i < count) {
+        int k = sl;
+        for (; k + 28 < nslab; k += 32) {
+            T v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(k + 4 * q) * stride + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; k < nslab; k += 4) acc += src[(int64_t)k * stride + i];
+    }
+    sm[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && i < count) dst[i] = ((sm[0][e] + sm[1][e]) + sm[2][e]) + sm[3][e];
+}
+
 // A[i + i*ld] += a for i < m  (adddiag!, src/utils.jl:15-24)
 template <typename T>
 __global__ void adddiag_kernel(T *A, int64_t ld, int m, T a, const int *done) {

@@ -124,19 +124,16 @@ template <typename T> class Solver : public SolverBase {
         s_gh = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), N);
         // slab buffer = [ big-GEMM slabs | Gram slabs ]: the two live side by side so the update GEMM can consume
         // the un-reduced numerator slabs directly in its epilogue
-        sk_grid = 2 * num_cu;
-        auto sk_slabs = [&](int64_t tiles, int64_t kdim) {
-            const int64_t nkt = kdim / BK, U = tiles * nkt;
-            const int64_t per = std::max<int64_t>(1, U / std::min<int64_t>(sk_grid, U));
-            return (int)((nkt + per - 1) / per) + 1;
-        };
-        sk_sh = sk_slabs(((N + K) / 128) * ((K + 127) / 128), P);
-        sk_sw = sk_slabs(((P + K) / 128) * ((K + 127) / 128), N);
-        const size_t h_region = std::max((size_t)s_h * K * N, (size_t)sk_sh * K * (N + K));
-        const size_t w_region = std::max((size_t)s_w * P * K, (size_t)sk_sw * ((size_t)P * K + (size_t)K * K));
+        const size_t h_region = (size_t)s_h * K * N;
+        const size_t w_region = (size_t)s_w * P * K;
         slab_w_off = h_region;
         gram_slab_off = h_region + w_region;
-        slabs.alloc(gram_slab_off + std::max((size_t)s_gw * K * K, (size_t)s_gh * K * K));
+        // Gram slabs: split-K slabs of the stand-alone Gram launch, or tail pieces of the fused launch
+        // (pieces <= blocks / tail tiles, see tail_piece)
+        const size_t tail_tiles_total = std::max<size_t>(1, ((K + 127) / 128) * ((K + 127) / 128));
+        const size_t max_pieces = (size_t)(2 * num_cu * 4) / tail_tiles_total + 2;
+        max_gram_slabs = (int)std::max<size_t>((size_t)std::max(s_gw, s_gh), max_pieces);
+        slabs.alloc(gram_slab_off + (size_t)max_gram_slabs * K * K);
         stat_chunks_w = (int)std::max<int64_t>(1, std::min<int64_t>(64, P / 1024));
         stat_chunks_h = (int)std::max<int64_t>(1, std::min<int64_t>(256, N / 64));
         stat_part.alloc((size_t)std::max<int64_t>(std::max(stat_chunks_w, stat_chunks_h), N / 64) * 2 * K);
@@ -274,17 +271,15 @@ template <typename T> class Solver : public SolverBase {
     int s_h = 1, s_w = 1, s_gw = 1, s_gh = 1;
     int stat_chunks_w = 1, stat_chunks_h = 1;
     size_t gram_slab_off = 0;
+    int max_gram_slabs = 1;
     int last_tiles_r = 1;   // r-tiles of the most recent GEMM launch (= chunks of its statistics partials)
     int last_blocks = 1;    // blocks of the most recent GEMM launch (= number of its objective partials)
     bool have_X = false, have_F = false;
     // Fusing the k x k Gram into the big GEMM launch adds (K/128)^2 tiles to a grid that otherwise fills the 512
-    // block slots exactly (256 tiles x 2 splits @C3); with plain split-K the 8 extra blocks form a second wave
-    // (+50 %: 1505 vs 1010 us).  The fused launches therefore use the stream-K decomposition (1030 us).
-    bool fuse_gram = true;    // K % 128 == 0: Gram rides in the big GEMM launch (stream-K balanced grid)
-    int sk_grid = 512;        // stream-K grid: 2 resident blocks per CU
-    int sk_sh = 2, sk_sw = 2; // stream-K slabs per tile (H side / W side)
-    size_t slab_w_off = 0;    // W-side slab region (regions are disjoint so never-written slabs stay zero)
-    long long sig_h = -1, sig_w = -1;
+    // block slots exactly (256 tiles x 2 splits @C3); as plain extra tiles the 8 Gram blocks form a second wave
+    // (+50 %: 1505 vs 1010 us), so they are dealt out as a short second segment of EVERY block (see the kernel).
+    bool fuse_gram = true;    // K % 128 == 0: Gram rides in the big GEMM launch as a balanced tail segment
+    size_t slab_w_off = 0;    // W-side slab region
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
 
@@ -329,10 +324,7 @@ template <typename T> class Solver : public SolverBase {
 
     template <int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi>
     void launch_gemm_cfg(const GemmArgs<T> &g, const Epi &epi) {
-        // stream-K: never more blocks than (tile, k-tile) units -- every block must own >= 1 unit for the
-        // slab numbering `bid - first_block(tile)` to stay below the slab count
-        const int blocks = g.streamk ? (int)std::min<int64_t>(sk_grid, (int64_t)g.tiles_r * g.tiles_c * g.nkt)
-                                     : g.tiles_r * g.tiles_c * g.splits;
+        const int blocks = g.tiles_r * g.tiles_c * g.splits;
         hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi>), dim3(blocks), dim3(WGR * WGC * 64), 0,
                            stream, g, epi);
         HIP_TRY(hipGetLastError());
@@ -343,23 +335,24 @@ template <typename T> class Solver : public SolverBase {
         const T *A2 = nullptr; int64_t lda2 = 0, r_split = INT64_MAX;
         const T *B2 = nullptr; int64_t ldb2 = 0, c_split = INT64_MAX;
         int a_nslab = 1, b_nslab = 1; int64_t a_slab_stride = 0, b_slab_stride = 0;
-        int streamk = 0;
+        int tail_tiles = 0;    // extra tiles along the slow direction, processed as a balanced tail segment
     };
     template <int LA, int LB, typename Epi>
     void gemm(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim,
-              int splits, bool c_fastest, const Epi &epi, const int *done, double bytes = 0.0, const Seg &seg = Seg()) {
+              int splits, bool c_fastest, const Epi &epi, const int *done, double bytes = 0.0, const Seg &seg = Seg(),
+              double extra_flops = 0.0) {
         GemmArgs<T> g;
         g.A = A; g.B = B; g.lda = lda; g.ldb = ldb;
         g.A2 = seg.A2; g.lda2 = seg.lda2; g.r_split = seg.r_split;
         g.B2 = seg.B2; g.ldb2 = seg.ldb2; g.c_split = seg.c_split;
         g.a_nslab = seg.a_nslab; g.b_nslab = seg.b_nslab; g.a_slab_stride = seg.a_slab_stride; g.b_slab_stride = seg.b_slab_stride;
-        g.streamk = seg.streamk; g.nkt = (int)(Kdim / BK);
+        g.tail_tiles = seg.tail_tiles; g.tail_nkt = (int)(Kdim / BK);
         g.splits = splits;
         g.kchunk = (int)(Kdim / splits);
         g.c_fastest = c_fastest ? 1 : 0;
         g.done = done;
-        const double flops = 2.0 * (double)R * (double)C * (double)Kdim;
-        auto note = [&] { last_tiles_r = g.tiles_r; last_blocks = g.streamk ? (int)std::min<int64_t>(sk_grid, (int64_t)g.tiles_r * g.tiles_c * g.nkt) : g.tiles_r * g.tiles_c * g.splits; };
+        const double flops = 2.0 * (double)R * (double)C * (double)Kdim + extra_flops;
+        auto note = [&] { last_tiles_r = g.tiles_r; last_blocks = g.tiles_r * g.tiles_c * g.splits; };
         // Short contractions (the k x k Gram products: 8 k-tiles) are dominated by prologue/epilogue latency; give
         // them half-size tiles so >= 2 blocks per CU are resident and one block's epilogue overlaps another's MFMAs.
         const bool small_k = (Kdim <= 1024) && splits == 1 && ((R / 128) * (C / 128) < 2 * (int64_t)num_cu);
@@ -373,6 +366,7 @@ template <typename T> class Solver : public SolverBase {
             } else if (R % 128 == 0 && C % 128 == 0) {
                 g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 128);
                 if (splits == 1 && g.tiles_r >= 16 && g.tiles_c >= 16 && g.tiles_r % 8 == 0 && g.tiles_c % 8 == 0) g.group = 8;
+                if (g.tail_tiles > 0) g.tail_per = tail_piece(g.tiles_r * g.tiles_c * splits, g.tail_tiles * (c_fastest ? g.tiles_c : g.tiles_r), g.tail_nkt);
                 launch_gemm_cfg<LA, LB, 128, 128, 2, 2>(g, epi);
             } else if (C == 64 && R % 256 == 0) {
                 g.tiles_r = (int)(R / 256); g.tiles_c = 1;
@@ -395,8 +389,12 @@ template <typename T> class Solver : public SolverBase {
         if (stride < 0) stride = count;
         timed(name, 0.0, (double)count * (nslab + 1) * sizeof(T), [&] {
             const int bs = 256;
-            hipLaunchKernelGGL(reduce_slabs_kernel<T>, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, stream, dst,
-                               src, count, nslab, stride, done);
+            if (nslab >= 16)
+                hipLaunchKernelGGL(reduce_many_slabs_kernel<T>, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, stream, dst,
+                                   src, count, nslab, stride, done);
+            else
+                hipLaunchKernelGGL(reduce_slabs_kernel<T>, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, stream, dst,
+                                   src, count, nslab, stride, done);
             HIP_TRY(hipGetLastError());
         });
     }
@@ -407,12 +405,12 @@ template <typename T> class Solver : public SolverBase {
     // ---- shared building blocks ------------------------------------------------
     void reduce_to(const char *name, T *dst, int64_t count, int nslab, const int *done) { reduce_slabs(name, dst, count, nslab, done); }
 
-    // Make sure a slab region only ever holds the slabs of ONE launch shape: stream-K leaves the slabs a tile does
-    // not use untouched, and consumers add all of them, so they must be zero.
-    void claim_region(long long &sig, long long want, T *base, size_t elems) {
-        if (sig == want) return;
-        HIP_TRY(hipMemsetAsync(base, 0, elems * sizeof(T), stream));
-        sig = want;
+    // k-tiles per tail piece: smallest piece such that (tail tiles) x (pieces per tile) <= blocks, and the pieces fit
+    // the Gram slab buffer.  One piece per block => every block does kchunk/BK + tail_per k-tiles.
+    int tail_piece(int blocks, int tail_tiles_total, int nkt) const {
+        int per = std::max(1, (int)(((int64_t)tail_tiles_total * nkt + blocks - 1) / blocks));
+        while ((int64_t)tail_tiles_total * ((nkt + per - 1) / per) > blocks || (nkt + per - 1) / per > max_gram_slabs) ++per;
+        return per;
     }
 
     // numH = W' * Bmat  (K x N, ld K), Bmat = X or Q (P x N)      src/multupd.jl:98,175; projals.jl:93; alspgrad.jl:66
@@ -424,26 +422,27 @@ template <typename T> class Solver : public SolverBase {
     void wt_times(const T *Wp, const T *Bmat, bool with_gram, const int *done, bool keep_slabs = false) {
         T *reg = slabs.p;
         if (with_gram && fuse_gram && K % 128 == 0) {
-            h_nslab = sk_sh; h_stride = (int64_t)K * (N + K);
-            claim_region(sig_h, 1, reg, (size_t)h_nslab * h_stride);
+            h_nslab = s_h; h_stride = (int64_t)K * N;
+            const int tiles = (int)((N / 128) * (K / 128));
+            const int tt = (int)((K / 128) * (K / 128));
+            const int per = tail_piece(tiles * s_h, tt, (int)(P / BK));
+            const int pieces = (int)((P / BK + per - 1) / per);
             EpiStore<T> e{reg, K, h_stride, nullptr};
+            e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = (int64_t)K * K; e.r_off = N; e.c_off = 0;
             Seg sg;
-            sg.A2 = Wp; sg.lda2 = P; sg.r_split = N; sg.streamk = 1;
-            gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N + K, Wp, P, K, P, h_nslab, true, e, done,
-                                   (double)(P * N + 2 * P * K) * sizeof(T), sg);
+            sg.A2 = Wp; sg.lda2 = P; sg.r_split = N; sg.tail_tiles = (int)(K / 128);
+            gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
+                                   (double)(P * N + 2 * P * K) * sizeof(T), sg, 2.0 * K * K * P);
+            reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
             if (!keep_slabs || h_nslab > 4) {
-                reduce_slabs_from("reduce_WtX", hside.p, reg, h_stride, h_nslab, done);
+                reduce_slabs_from("reduce_WtX", numH_p, reg, h_stride, h_nslab, done);
                 h_in_slabs = false;
             } else {
-                // the k x k Gram is an OPERAND of the next GEMM (re-read by every block): reduce it (tiny) now;
-                // the numerator is touched once per element and is summed in that GEMM's epilogue.
-                reduce_slabs_from("reduce_WtW", gramW_p, reg + (size_t)K * N, (int64_t)K * K, h_nslab, done, h_stride);
                 h_in_slabs = true;
             }
             return;
         }
         h_nslab = s_h; h_stride = (int64_t)K * N;
-        claim_region(sig_h, 2, reg, (size_t)h_nslab * h_stride);
         EpiStore<T> e{reg, K, h_stride, nullptr};
         gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                (double)(P * N + P * K) * sizeof(T));
@@ -472,24 +471,27 @@ template <typename T> class Solver : public SolverBase {
     void times_ht(const T *Amat, const T *Hp, bool with_gram, const int *done, bool keep_slabs = false) {
         T *reg = slabs.p + slab_w_off;
         if (with_gram && fuse_gram && K % 128 == 0) {
-            w_nslab = sk_sw; w_stride = (int64_t)P * K + (int64_t)K * K;
-            claim_region(sig_w, 1, reg, (size_t)w_nslab * w_stride);
-            EpiStore2<T> e{reg, P, P, K, (int64_t)P * K, w_stride, nullptr};
+            w_nslab = s_w; w_stride = (int64_t)P * K;
+            const int tiles = (int)((K / 128) * (P / 128));
+            const int tt = (int)((K / 128) * (K / 128));
+            const int per = tail_piece(tiles * s_w, tt, (int)(N / BK));
+            const int pieces = (int)((N / BK + per - 1) / per);
+            EpiStore<T> e{reg, P, w_stride, nullptr};
+            e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = (int64_t)K * K; e.r_off = 0; e.c_off = P;
             Seg sg;
-            sg.B2 = Hp; sg.ldb2 = K; sg.c_split = P; sg.streamk = 1;
-            gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P + K, N, w_nslab, false, e, done,
-                                     (double)(P * N + 2 * K * N) * sizeof(T), sg);
+            sg.B2 = Hp; sg.ldb2 = K; sg.c_split = P; sg.tail_tiles = (int)(K / 128);
+            gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
+                                     (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
+            reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
             if (!keep_slabs || w_nslab > 4) {
-                reduce_slabs_from("reduce_XHt", pack.p, reg, w_stride, w_nslab, done);
+                reduce_slabs_from("reduce_XHt", numW_p, reg, w_stride, w_nslab, done);
                 w_in_slabs = false;
             } else {
-                reduce_slabs_from("reduce_HHt", gramH_p, reg + (size_t)P * K, (int64_t)K * K, w_nslab, done, w_stride);
                 w_in_slabs = true;
             }
             return;
         }
         w_nslab = s_w; w_stride = (int64_t)P * K;
-        claim_region(sig_w, 2, reg, (size_t)w_nslab * w_stride);
         EpiStore<T> e{reg, P, w_stride, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                  (double)(P * N + K * N) * sizeof(T));

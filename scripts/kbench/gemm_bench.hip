@@ -14,11 +14,7 @@ template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC>
 double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool c_fastest, int reps) {
     // A: R rows, B: C rows; KCONTIG -> ld = Kd, KSTRIDED -> ld = rows
     const int64_t lda = (LA == KCONTIG) ? Kd : R, ldb = (LB == KCONTIG) ? Kd : C;
-    if (g_stagger) {   // stream-K over 512 blocks: max slabs per tile
-        const long long U = (long long)(R / BR) * (C / BC) * (Kd / Mfma<T>::BK);
-        const long long per = std::max<long long>(1, U / 512);
-        splits = (int)((Kd / Mfma<T>::BK + per - 1) / per) + 1;
-    }
+
     T *A, *B, *D;
     CK(hipMalloc(&A, (size_t)R * Kd * sizeof(T))); CK(hipMalloc(&B, (size_t)C * Kd * sizeof(T)));
     CK(hipMalloc(&D, (size_t)R * C * splits * sizeof(T))); CK(hipMemset(D, 0, (size_t)R * C * splits * sizeof(T)));
@@ -31,9 +27,9 @@ double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool 
     CK(hipMemcpy(B, h.data(), (size_t)C * Kd * sizeof(T), hipMemcpyHostToDevice));
     GemmArgs<T> g;
     g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.tiles_r = (int)(R / BR); g.tiles_c = (int)(C / BC);
-    g.splits = splits; g.kchunk = (int)(Kd / splits); g.c_fastest = c_fastest; g.done = nullptr; g.streamk = g_stagger; g.nkt = (int)(Kd / Mfma<T>::BK);
+    g.splits = splits; g.kchunk = (int)(Kd / splits); g.c_fastest = c_fastest; g.done = nullptr; 
     EpiStore<T> e{D, C, R * C, nullptr};
-    const int blocks = g_stagger ? 512 : g.tiles_r * g.tiles_c * splits;
+    const int blocks = g.tiles_r * g.tiles_c * splits;
 
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9;
@@ -73,9 +69,9 @@ double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool 
 int main(int argc, char **argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 6;
     g_mode = 1;
-    for (int st : {0, 1}) {
+    for (int st : {0}) {
     g_stagger = st;
-    printf("--- streamk %d\n", st);
+    
     run<float, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN big (WtX) 128x128", 16384, 256, 16384, 2, true, reps);
     run<float, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN big+gram rows (260 tiles)", 16384 + 256, 256, 16384, 2, true, reps);
     run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT big (XHt) 128x128", 256, 16384, 16384, 2, false, reps);

@@ -185,54 +185,151 @@ __global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int
     }
 }
 
-// Uinv (zero-initialised, ld) <- inverse of the upper-triangular k x k factor U.  grid = k workgroups of one
-// wave; workgroup j solves U x = e_j from the bottom up.  Rows are processed in blocks of RB: the part of the
-// dot products that only needs already-known x (columns beyond the block) is done lane-parallel straight from
-// global memory, the block's own RB x RB triangle is staged in LDS for the short serial recurrence.
-// Dynamic LDS: k + RB*RB elements of T (+ RB for the partial sums).
-template <typename T, int RB>
-__global__ __launch_bounds__(64) void trtri_upper_kernel(const T *U, T *Uinv, int64_t ld, int k, const int *done) {
+// ---------------------------------------------------------------------------------------------
+// Triangular inverse Uinv = inv(U) (what potri!'s first half, trtri, computes), blocked by 32:
+//   Uinv[b,b] = inv(U[b,b])                                              -- trtri_diag_kernel
+//   Uinv[a,b] = -Uinv[a,a] * sum_{c=a+1..b} U[a,c] * Uinv[c,b],  a < b    -- trtri_offdiag_kernel
+// Block columns b are independent (one workgroup each); inside one, the block rows are a serial chain
+// a = b-1 .. 0 of 32 x 32 x 32 products on the matrix cores, with the finished tiles of the column kept in LDS.
+// ---------------------------------------------------------------------------------------------
+
+// grid = ceil(k/32) workgroups of one wave.  Lane c computes column c of inv(U_bb) by back-substitution on e_c; the
+// needed U(i,l) live in lane l's registers and are broadcast with v_readlane (branch-free, identity-padded).
+template <typename T>
+__global__ __launch_bounds__(64) void trtri_diag_kernel(const T *U, T *Uinv, int64_t ld, int k, const int *done) {
     NMFX_DONE_GUARD(done);
+    constexpr int NB = 32;
+    const int jb = blockIdx.x * NB, lane = threadIdx.x;
+    const int nb = (k - jb < NB) ? (k - jb) : NB;
+    T col[NB], v[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        const bool in = (lane < nb) && (r <= lane);
+        col[r] = in ? U[(jb + r) + (int64_t)(jb + (in ? lane : 0)) * ld] : ((r == lane) ? (T)1 : (T)0);
+    }
+#pragma unroll
+    for (int i = NB - 1; i >= 0; --i) {
+        // v[i] = (delta_{i,lane} - sum_{l=i+1..31} U(i,l) v[l]) / U(i,i);   U(i,l) = lane l's col[i] (zero for l < i)
+        T s = (lane == i) ? (T)1 : (T)0;
+#pragma unroll
+        for (int l = i + 1; l < NB; ++l) s -= lane_bcast(col[i], l) * v[l];
+        v[i] = s / lane_bcast(col[i], i);
+    }
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+        if (lane < nb && r <= lane) Uinv[(jb + r) + (int64_t)(jb + lane) * ld] = v[r];
+}
+
+// grid = ceil(k/32) workgroups (block column b) of 4 waves.  LDS: finished tiles Y[c] (c = 0..b, row-major 32x32 each),
+// 4 partial-sum tiles.  Dynamic LDS = (nblk + 4) * 1024 elements of T.
+template <typename T>
+__global__ __launch_bounds__(256) void trtri_offdiag_kernel(const T *U, T *Uinv, int64_t ld, int k, const int *done) {
+    NMFX_DONE_GUARD(done);
+    using M = Mfma<T>;
+    constexpr int NB = 32, MT = M::MT, KS = M::KS, SUB = NB / MT;   // SUB x SUB MFMA tiles per 32 x 32 block
     extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
-    T *x = reinterpret_cast<T *>(chol_smem);   // k entries
-    T *tri = x + ((k + 3) / 4) * 4;            // RB x RB: tri[i*RB + l] = U(ib+i, ib+l)
-    T *part = tri + RB * RB;                   // RB partial sums
-    const int j = blockIdx.x, lane = threadIdx.x;
-    for (int i = lane; i < k; i += 64) x[i] = (T)0;
+    T *Y = reinterpret_cast<T *>(chol_smem);          // Y[c*1024 + l*32 + j] = Uinv(32c + l, 32b + j)
+    const int nblk = (k + NB - 1) / NB;
+    T *Ps = Y + (size_t)nblk * NB * NB;               // 4 partial tiles, same row-major layout
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane % MT, ks = lane / MT;
+    // Y[b] = diagonal block (already in Uinv), zero-padded
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int l = e / NB, j = e % NB;
+        const int gr = b * NB + l, gc = b * NB + j;
+        Y[(size_t)b * NB * NB + e] = (gr < k && gc < k && l <= j) ? Uinv[gr + (int64_t)gc * ld] : (T)0;
+    }
     __syncthreads();
-    // last (partial) block ends at row j
-    for (int ie = j; ie >= 0; ie -= RB) {
-        const int ib = (ie - RB + 1 > 0) ? ie - RB + 1 : 0;   // rows ib..ie
-        const int nr = ie - ib + 1;
-        // stage the triangle U(ib..ie, ib..ie)
-        for (int e = lane; e < nr * nr; e += 64) {
-            const int i = e % nr, l = e / nr;
-            tri[i * RB + l] = (l >= i) ? U[(ib + i) + (int64_t)(ib + l) * ld] : (T)0;
+    for (int a = b - 1; a >= 0; --a) {
+        // partial sums: wave w adds the products U[a,c] * Y[c] for c = a+1+w, a+1+w+4, ...
+        typename M::acc_t acc[SUB][SUB];
+#pragma unroll
+        for (int si = 0; si < SUB; ++si)
+#pragma unroll
+            for (int sj = 0; sj < SUB; ++sj)
+#pragma unroll
+                for (int r = 0; r < M::NACC; ++r) acc[si][sj][r] = (T)0;
+        for (int c = a + 1 + wave; c <= b; c += 4) {
+            const T *Yc = Y + (size_t)c * NB * NB;
+#pragma unroll
+            for (int kk = 0; kk < NB / KS; ++kk) {
+                const int l = kk * KS + ks;
+                T af[SUB], bf[SUB];
+#pragma unroll
+                for (int si = 0; si < SUB; ++si) {     // A(i, l) = U(32a + i, 32c + l)
+                    const int gr = a * NB + si * MT + li, gc = c * NB + l;
+                    af[si] = (gr < k && gc < k) ? U[gr + (int64_t)gc * ld] : (T)0;
+                }
+#pragma unroll
+                for (int sj = 0; sj < SUB; ++sj) bf[sj] = Yc[l * NB + sj * MT + li];
+#pragma unroll
+                for (int si = 0; si < SUB; ++si)
+#pragma unroll
+                    for (int sj = 0; sj < SUB; ++sj) acc[si][sj] = M::mma(af[si], bf[sj], acc[si][sj]);
+            }
         }
-        // partial sums over the known part: part[i] = sum_{l = ie+1..j} U(ib+i, l) x[l]
-        {
-            const int i = lane % RB, h = lane / RB;   // RB = 32: two half-waves split the l range
-            T s = (T)0;
-            if (i < nr)
-                for (int l = ie + 1 + h; l <= j; l += 64 / RB) s += U[(ib + i) + (int64_t)l * ld] * x[l];
-            s += __shfl_down(s, RB, 64);
-            if (lane < RB) part[lane] = s;
+        // write this wave's partial tile (row-major) and combine the four in a fixed order
+        T *Pw = Ps + (size_t)wave * NB * NB;
+#pragma unroll
+        for (int si = 0; si < SUB; ++si)
+#pragma unroll
+            for (int sj = 0; sj < SUB; ++sj)
+#pragma unroll
+                for (int reg = 0; reg < M::NACC; ++reg) {
+                    int rr;
+                    if constexpr (sizeof(T) == 4) rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    else rr = (lane >> 4) + 4 * reg;
+                    Pw[(si * MT + rr) * NB + sj * MT + li] = acc[si][sj][reg];
+                }
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += 256)
+            Ps[e] = ((Ps[e] + Ps[NB * NB + e]) + Ps[2 * NB * NB + e]) + Ps[3 * NB * NB + e];
+        __syncthreads();
+        // Y[a] = -Vinv_a * S   (wave 0; Vinv_a = Uinv[a,a] from global, S = Ps[0])
+        if (wave == 0) {
+            typename M::acc_t acc2[SUB][SUB];
+#pragma unroll
+            for (int si = 0; si < SUB; ++si)
+#pragma unroll
+                for (int sj = 0; sj < SUB; ++sj)
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r) acc2[si][sj][r] = (T)0;
+#pragma unroll
+            for (int kk = 0; kk < NB / KS; ++kk) {
+                const int l = kk * KS + ks;
+                T af[SUB], bf[SUB];
+#pragma unroll
+                for (int si = 0; si < SUB; ++si) {     // A(i, l) = Vinv_a(i, l), upper triangular
+                    const int i = si * MT + li;
+                    const int gr = a * NB + i, gc = a * NB + l;
+                    af[si] = (i <= l && gr < k && gc < k) ? Uinv[gr + (int64_t)gc * ld] : (T)0;
+                }
+#pragma unroll
+                for (int sj = 0; sj < SUB; ++sj) bf[sj] = Ps[l * NB + sj * MT + li];
+#pragma unroll
+                for (int si = 0; si < SUB; ++si)
+#pragma unroll
+                    for (int sj = 0; sj < SUB; ++sj) acc2[si][sj] = M::mma(af[si], bf[sj], acc2[si][sj]);
+            }
+            T *Ya = Y + (size_t)a * NB * NB;
+#pragma unroll
+            for (int si = 0; si < SUB; ++si)
+#pragma unroll
+                for (int sj = 0; sj < SUB; ++sj)
+#pragma unroll
+                    for (int reg = 0; reg < M::NACC; ++reg) {
+                        int rr;
+                        if constexpr (sizeof(T) == 4) rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                        else rr = (lane >> 4) + 4 * reg;
+                        const int i = si * MT + rr, j = sj * MT + li;
+                        const T val = -acc2[si][sj][reg];
+                        Ya[i * NB + j] = val;
+                        const int gr = a * NB + i, gc = b * NB + j;
+                        if (gr < k && gc < k) Uinv[gr + (int64_t)gc * ld] = val;
+                    }
         }
         __syncthreads();
-        // serial recurrence inside the block (bottom row first), lane-parallel dot over the block's columns
-        for (int i = nr - 1; i >= 0; --i) {
-            T s = (T)0;
-            const int l = lane;
-            if (l > i && l < nr) s = tri[i * RB + l] * x[ib + l];
-            for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 64);   // RB = 32 columns live in lanes 0..31
-            if (lane == 0) {
-                const T rhs = ((ib + i) == j) ? (T)1 : (T)0;
-                x[ib + i] = (rhs - part[i] - s) / tri[i * RB + i];
-            }
-            __syncthreads();
-        }
     }
-    for (int i = lane; i <= j; i += 64) Uinv[i + (int64_t)j * ld] = x[i];
 }
 
 }  // namespace nmfx

@@ -1,7 +1,7 @@
 // projals_impl.hpp -- ProjectedALS kernel sequence.  update_wh!(::ProjectedALSUpd), src/projals.jl:76-107:
 //   H <- max(0, (W'W + lh I)^-1 W'X)      pdsolve!  (potrf! + potrs!, src/utils.jl:63-70)
 //   W <- max(0, XH' (HH' + lw I)^-1)      pdrsolve! (potrf! + potri! + copytri! + mul!, src/utils.jl:72-84)
-// Device form: U = potrf(A); Uinv = trtri(U);  the H solve is Uinv*(Uinv'*B) (two k x k x n MFMA GEMMs
+// Device form: U = potrf(A) (LDS-blocked, MFMA trailing update); Uinv = trtri(U) (blocked by 32, MFMA);  the H solve is Uinv*(Uinv'*B) (two k x k x n MFMA GEMMs
 // in place of the two triangular substitutions of potrs!), the W side forms inv(A) = Uinv*Uinv' exactly
 // like potri! and multiplies (MFMA GEMM) like the reference's mul!.
 #pragma once
@@ -21,7 +21,8 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // potrf: 32 x 32 diagonal block + 32 x kp row panel in LDS (kp = k rounded up to 32)
     const size_t kp32 = (size_t)(k + 31) / 32 * 32;
     const size_t lds32 = ((size_t)(32 * 32 + 32 * kp32) * sizeof(T) + 15) / 16 * 16 + 16;
-    const size_t lds_tri = ((size_t)((k + 3) / 4 * 4 + 32 * 32 + 32) * sizeof(T) + 15) / 16 * 16;
+    const size_t lds_tri = (size_t)((k + 31) / 32 + 4) * 1024 * sizeof(T);   // finished tiles of a block column + 4 partial tiles
+    if (lds_tri > 160 * 1024) throw StatusError{NMFX_ERR_UNSUPPORTED, "projals: k too large for the blocked triangular inverse"};
     if (lds32 > 160 * 1024) throw StatusError{NMFX_ERR_UNSUPPORTED, "projals: k too large for the single-workgroup Cholesky panel (k <= 1248 f32 / 608 f64)"};
     auto factor = [&](T *A, T lambda, const char *tag_potrf, const char *tag_trtri) {
         timed(tag_potrf, (double)k * k * k / 3.0, 0.0, [&] {
@@ -34,7 +35,11 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
         });
         timed(tag_trtri, (double)k * k * k / 3.0, 0.0, [&] {
             HIP_TRY(hipMemsetAsync(Uinv, 0, kk * sizeof(T), stream));
-            hipLaunchKernelGGL((trtri_upper_kernel<T, 32>), dim3((unsigned)k), dim3(64), lds_tri, stream, A, Uinv, K, (int)k, done);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&trtri_offdiag_kernel<T>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tri));
+            const unsigned nblk = (unsigned)((k + 31) / 32);
+            hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3(nblk), dim3(64), 0, stream, A, Uinv, K, (int)k, done);
+            hipLaunchKernelGGL((trtri_offdiag_kernel<T>), dim3(nblk), dim3(256), lds_tri, stream, A, Uinv, K, (int)k, done);
             HIP_TRY(hipGetLastError());
         });
     };

@@ -24,7 +24,8 @@ template <typename T> int run(int k) {
     CK(hipMalloc(&ctrl, sizeof(Ctrl))); CK(hipMemset(ctrl, 0, sizeof(Ctrl)));
     const size_t kp = (size_t)(k + 31) / 32 * 32;
     const size_t lds = ((size_t)(32 * 32 + 32 * kp) * sizeof(T) + 15) / 16 * 16 + 16;
-    const size_t lds_tri = ((size_t)((k + 3) / 4 * 4 + 32 * 32 + 32) * sizeof(T) + 15) / 16 * 16;
+    const size_t lds_tri = (size_t)((k + 31) / 32 + 4) * 1024 * sizeof(T);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&trtri_offdiag_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tri));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_upper_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best_p = 1e9, best_t = 1e9;
@@ -36,7 +37,8 @@ template <typename T> int run(int k) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best_p = std::min(best_p, ms);
         CK(hipMemset(dInv, 0, A.size() * sizeof(T)));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((trtri_upper_kernel<T, 32>), dim3(k), dim3(64), lds_tri, 0, dU, dInv, (int64_t)K, k, (const int *)nullptr);
+        hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3((k + 31) / 32), dim3(64), 0, 0, dU, dInv, (int64_t)K, k, (const int *)nullptr);
+        hipLaunchKernelGGL((trtri_offdiag_kernel<T>), dim3((k + 31) / 32), dim3(256), lds_tri, 0, dU, dInv, (int64_t)K, k, (const int *)nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); best_t = std::min(best_t, ms);
     }

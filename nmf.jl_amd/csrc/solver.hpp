@@ -355,7 +355,7 @@ template <typename T> class Solver : public SolverBase {
         auto note = [&] { last_tiles_r = g.tiles_r; last_blocks = g.tiles_r * g.tiles_c * g.splits; };
         // Short contractions (the k x k Gram products: 8 k-tiles) are dominated by prologue/epilogue latency; give
         // them half-size tiles so >= 2 blocks per CU are resident and one block's epilogue overlaps another's MFMAs.
-        const bool small_k = (Kdim <= 1024) && splits == 1 && ((R / 128) * (C / 128) < 2 * (int64_t)num_cu);
+        const bool small_k = (Kdim <= 1024) && splits == 1 && seg.tail_tiles == 0 && ((R / 128) * (C / 128) < 2 * (int64_t)num_cu);
         timed(name, flops, bytes, [&] {
             if (small_k && R % 64 == 0 && C % 128 == 0 && R >= C) {
                 g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 128);

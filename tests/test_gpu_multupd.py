@@ -14,7 +14,10 @@ from problems import planted, rel_trace_err, uniform
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(6, 6, 3), (5, 8, 3), (200, 500, 5), (300, 260, 70), (512, 768, 64), (257, 1030, 129)]
+# includes degenerate and tile-boundary shapes: k = 1, p <= 256 with k = 128 (one k-tile column: the fused-Gram tail path
+# with a single main split), k just above a tile multiple
+SHAPES = [(2, 3, 1), (6, 6, 3), (5, 8, 3), (200, 500, 5), (300, 260, 70), (512, 768, 64), (257, 1030, 129),
+          (129, 257, 128)]
 TOL = {np.float32: (1e-5, 1e-3), np.float64: (1e-10, 1e-8)}
 
 
@@ -33,7 +36,11 @@ def test_trajectory_matches_oracle(built, T, obj, shape):
                                                      track_objective=True))
     assert r.niters == ro.niters == maxiter and not r.converged
     tol_obj, tol_fac = TOL[T]
-    assert rel_trace_err(r.trace, ro.trace) < tol_obj
+    # relative to each point, plus the cancellation floor of the objective itself: degenerate fits (1x1, 2x3, k=1)
+    # drive the objective from O(1) to ~1e-6 of its start, where the sum of O(1) terms only carries ~eps(T) of
+    # absolute accuracy -- the two CPU restatements differ there by the same amount.
+    tr, tro = np.asarray(r.trace), np.asarray(ro.trace)
+    assert np.all(np.abs(tr - tro) <= tol_obj * np.abs(tro) + 8 * np.finfo(T).eps * abs(tro[0]))
     assert np.max(np.abs(Wg - Wc)) <= tol_fac * np.max(np.abs(Wc))
     assert np.max(np.abs(Hg - Hc)) <= tol_fac * np.max(np.abs(Hc))
     assert np.all(Wg >= 0) and np.all(Hg >= 0) and not np.isnan(Wg).any() and not np.isnan(Hg).any()

@@ -19,7 +19,7 @@ TOL = {np.float64: 1e-7, np.float32: 2e-3}
 
 
 @pytest.mark.parametrize("T", [np.float64, np.float32])
-@pytest.mark.parametrize("shape", [(64, 96, 5), (300, 260, 70), (130, 515, 8)])
+@pytest.mark.parametrize("shape", [(64, 96, 5), (300, 260, 70), (130, 515, 8), (129, 257, 100)])
 def test_projals_trajectory(built, T, shape):
     p, n, k = shape
     X, W0, H0 = planted(p, n, k, T, seed=9 + p, normalize=False, zeroh=True)
@@ -83,7 +83,7 @@ def test_alspgrad_subsolver_kat(built, T):
 
 
 @pytest.mark.parametrize("T", [np.float64, np.float32])
-@pytest.mark.parametrize("shape", [(40, 56, 4), (140, 300, 9)])
+@pytest.mark.parametrize("shape", [(40, 56, 4), (140, 300, 9), (129, 200, 100)])
 def test_alspgrad_trajectory(built, T, shape):
     p, n, k = shape
     X, W0, H0 = planted(p, n, k, T, seed=31 + n)

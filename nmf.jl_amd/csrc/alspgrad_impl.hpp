@@ -7,21 +7,15 @@
 
 namespace nmfx {
 
-template <typename T> struct PgBuffers {
-    T *G, *Zn, *Zp, *D, *GD;
-};
-
 // returns executed inner iterations; Z updated in place
 template <typename T>
 long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int maxiter, int traceiter, T tolg, T beta,
                                  T sigma, long long *inner_total) {
     const int64_t rows = left ? K : P, cols = left ? N : K;
     const int64_t count = rows * cols;
-    const size_t need = (size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K);
-    for (int i = 3; i < 8; ++i) work[i].ensure(need);
-    T *G = work[3].p, *Zn = work[4].p, *Zp = work[5].p, *D = work[6].p, *GD = work[7].p;
-    const int NB = 512;
-    pg_part.ensure((size_t)2 * NB);
+    work[3].ensure((size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K));
+    T *G = work[3].p;
+    pg_part.ensure((size_t)3 * 65536);
     if (!pg_state) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pg_state), sizeof(PgState)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pg_host), sizeof(PgState)));
@@ -33,30 +27,35 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     HIP_TRY(hipMemcpyAsync(pg_state, &init, sizeof init, hipMemcpyHostToDevice, stream));
     const bool sharded = left && nranks > 1;                               // H is column-sharded, W is replicated
     const T epsT = std::numeric_limits<T>::epsilon();
-    int step_id = 0;
-    auto grad = [&](const T *src, T *dst, const T *sub, const int *idle) {
-        if (left) {
-            if (sub) { EpiSubStore<T> e{sub, dst, K}; gemm<KCONTIG, KCONTIG>("gemm_pg_GramZ", src, K, N, Gram, K, K, K, 1, true, e, idle); }
-            else { EpiStore<T> e{dst, K, 0, nullptr}; gemm<KCONTIG, KCONTIG>("gemm_pg_GramD", src, K, N, Gram, K, K, K, 1, true, e, idle); }
-        } else {
-            if (sub) { EpiSubStore<T> e{sub, dst, P}; gemm<KSTRIDED, KSTRIDED>("gemm_pg_ZGram", Gram, K, K, src, P, P, K, 1, false, e, idle); }
-            else { EpiStore<T> e{dst, P, 0, nullptr}; gemm<KSTRIDED, KSTRIDED>("gemm_pg_DGram", Gram, K, K, src, P, P, K, 1, false, e, idle); }
-        }
+    const int *idle = &pg_state->idle;
+    // G = Gram*Z - B  (+ projgradnorm^2 partials)            :124-130 / :280-286
+    auto grad = [&]() {
+        EpiGradNorm<T> e{B, Z, G, left ? K : P, pg_part.p, 0.0};
+        if (left) gemm<KCONTIG, KCONTIG>("gemm_pg_grad", Z, K, N, Gram, K, K, K, 1, true, e, nullptr, 4.0 * K * N * sizeof(T));
+        else gemm<KSTRIDED, KSTRIDED>("gemm_pg_grad", Gram, K, K, Z, P, P, K, 1, false, e, nullptr, 4.0 * P * K * sizeof(T));
+        return last_blocks;
     };
-    auto enqueue_steps = [&](int nsteps) {
-        const int *idle = &pg_state->idle;
-        for (int s = 0; s < nsteps; ++s) {
-            ++step_id;
-            hipLaunchKernelGGL(pg_project_kernel<T>, dim3(NB), dim3(256), 0, stream, Z, G, Zn, D, count, pg_state, pg_part.p);
-            hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, stream, pg_part.p, NB, 1, pg_state->red, 0, idle);
-            grad(D, GD, nullptr, idle);                                    // :151 WtWD = WtW * D
-            hipLaunchKernelGGL(pg_dots_kernel<T>, dim3(NB), dim3(256), 0, stream, GD, D, Z, Zp, Zn, count, pg_state, pg_part.p);
-            hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, stream, pg_part.p, NB, 2, pg_state->red, 1, idle);
-            if (sharded) RCCL_TRY(ncclAllReduce(pg_state->red, pg_state->red, 3, ncclDouble, ncclSum, comm, stream));
-            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(1), 0, stream, pg_state, beta, sigma, epsT, traceiter, step_id);
-            hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(NB), dim3(256), 0, stream, Z, Zp, Zn, count, pg_state, step_id);
+    // one back-tracking step: Gram * D(alpha) with D formed in the operand loader, scalars reduced in the epilogue
+    auto step = [&]() {
+        EpiPgStep<T> e{Z, G, left ? K : P, pg_state, pg_part.p, (T)0, (T)0, 0, 0.0, 0.0, 0.0};
+        Seg sg;
+        sg.alpha_ptr = &pg_state->alpha;
+        int nblk;
+        if (left) {
+            sg.a_aux = G;
+            gemm<KCONTIG, KCONTIG>("gemm_pg_step", Z, K, N, Gram, K, K, K, 1, true, e, idle, 4.0 * K * N * sizeof(T), sg);
+        } else {
+            sg.b_aux = G;
+            gemm<KSTRIDED, KSTRIDED>("gemm_pg_step", Gram, K, K, Z, P, P, K, 1, false, e, idle, 4.0 * P * K * sizeof(T), sg);
         }
-        HIP_TRY(hipGetLastError());
+        nblk = last_blocks;
+        if (sharded) {
+            hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 3, 0, 1);
+            RCCL_TRY(ncclAllReduce(pg_state->red, pg_state->red, 3, ncclDouble, ncclSum, comm, stream));
+            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, beta, sigma, epsT, traceiter);
+        } else {
+            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, beta, sigma, epsT, traceiter);
+        }
     };
     auto fetch = [&]() {
         HIP_TRY(hipMemcpyAsync(pg_host, pg_state, sizeof(PgState), hipMemcpyDeviceToHost, stream));
@@ -66,20 +65,26 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     bool converged = false;
     while (!converged && t < maxiter) {
         ++t;
-        grad(Z, G, B, nullptr);                                            // :124-127 G = WtW*H - WtX
-        hipLaunchKernelGGL(pg_norm_kernel<T>, dim3(NB), dim3(256), 0, stream, G, Z, count, pg_part.p);
-        hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, stream, pg_part.p, NB, 1, pg_state->red, 3, (const int *)nullptr);
-        if (sharded) RCCL_TRY(ncclAllReduce(pg_state->red + 3, pg_state->red + 3, 1, ncclDouble, ncclSum, comm, stream));
-        hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(1), 0, stream, pg_state, tolg);
-        enqueue_steps(std::min(3, traceiter));
-        fetch();
-        int enq = std::min(3, traceiter);
-        while (!pg_host->idle && enq < traceiter) {
-            const int more = std::min(4, traceiter - enq);
-            enqueue_steps(more);
-            enq += more;
-            fetch();
+        const int nblk = grad();
+        if (sharded) {
+            hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 1, 3, 0);
+            RCCL_TRY(ncclAllReduce(pg_state->red + 3, pg_state->red + 3, 1, ncclDouble, ncclSum, comm, stream));
+            hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, tolg);
+        } else {
+            hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, tolg);
         }
+        int enq = 0;
+        auto batch = [&](int nsteps) {
+            for (int s = 0; s < nsteps; ++s) step();
+            enq += nsteps;
+            // H <- Hn / H <- Hp of the step that broke the loop (no-op while the loop is still running or unchanged)
+            hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(512), dim3(256), 0, stream, Z, G, count, pg_state, (int *)nullptr);
+            hipLaunchKernelGGL(pg_clear_apply_kernel, dim3(1), dim3(1), 0, stream, pg_state);
+            HIP_TRY(hipGetLastError());
+            fetch();
+        };
+        batch(std::min(3, traceiter));
+        while (!pg_host->idle && enq < traceiter) batch(std::min(4, traceiter - enq));
         if (pg_host->nonfinite) throw StatusError{NMFX_ERR_ALPHA_NONFINITE, "alpha is not finite"};
         converged = pg_host->converged != 0;
     }

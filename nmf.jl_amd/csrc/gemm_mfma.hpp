@@ -76,6 +76,8 @@ template <typename T> struct GemmArgs {
     int a_nslab = 1, b_nslab = 1;
     int64_t a_slab_stride = 0, b_slab_stride = 0;
     int group = 1;          // >1: super-tile rasterisation (see the block -> tile mapping)
+    const T *a_aux = nullptr, *b_aux = nullptr;   // operand computed on the fly as max(z - alpha*g, 0) - z (see TileLoader::load)
+    const double *alpha_ptr = nullptr;            // device-resident step size (PgState::alpha)
     int tail_tiles = 0;     // extra output tiles along the slow tile direction, done as a balanced second segment
     int tail_nkt = 0;       // k-tiles of a tail tile (= Kdim / BK)
     int tail_per = 0;       // k-tiles of one tail piece (one piece per block)
@@ -100,8 +102,12 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
     using vec_t = typename M::vec_t;
 
     // global -> registers
+    // aux != nullptr: the operand is not read but COMPUTED on the fly from two arrays with identical addressing,
+    //   d = max(z - alpha*g, 0) - z   (z from `base`, g from `aux`)
+    // i.e. the projected-gradient trial step D = Zn - Z of src/alspgrad.jl:142-147, which therefore never exists in memory.
     static __device__ __forceinline__ void load(vec_t (&r)[PER_THREAD], const T *base, int64_t ld,
-                                                int64_t row0, int64_t k0, int tid, int nslab = 1, int64_t slab_stride = 0) {
+                                                int64_t row0, int64_t k0, int tid, int nslab = 1, int64_t slab_stride = 0,
+                                                const T *aux = nullptr, T alpha = (T)0) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int s = tid + NTHREADS * i;
@@ -118,6 +124,16 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
             }
             r[i] = *reinterpret_cast<const vec_t *>(p);
             for (int sl = 1; sl < nslab; ++sl) r[i] += *reinterpret_cast<const vec_t *>(p + (int64_t)sl * slab_stride);
+            if (aux != nullptr) {
+                const vec_t gv = *reinterpret_cast<const vec_t *>(aux + (p - base));
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const T z = r[i][q];
+                    T v = z - alpha * gv[q];
+                    v = (v > (T)0) ? v : ((v != v) ? v : (T)0);
+                    r[i][q] = v - z;
+                }
+            }
         }
     }
     // registers -> LDS (linear image: chunk s at byte 16*s)
@@ -177,6 +193,7 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     using LoadB = TileLoader<T, LB, BC, NT>;
 
     if (g.done != nullptr && *reinterpret_cast<const volatile int *>(g.done) != 0) return;
+    const T xalpha = (g.alpha_ptr != nullptr) ? (T)*g.alpha_ptr : (T)0;
     __shared__ __attribute__((aligned(16))) T smem[2 * (BR + BC) * BK];
     constexpr int STAGE = (BR + BC) * BK;   // stage s: A tile at smem + s*STAGE, B tile right behind it
 
@@ -259,14 +276,14 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
         //   second half                : global   -> registers, tile t+2  (loads interleaved with MFMAs)
         // Stage (t+1)&1 was last read during tile t-1, i.e. before the barrier that ended iteration t-1.
         typename M::vec_t ra[LoadA::PER_THREAD], rb[LoadB::PER_THREAD];
-        LoadA::load(ra, Ab, lda, ra0, kbeg, tid, g.a_nslab, g.a_slab_stride);
-        LoadB::load(rb, Bb, ldb, cb0, kbeg, tid, g.b_nslab, g.b_slab_stride);
+        LoadA::load(ra, Ab, lda, ra0, kbeg, tid, g.a_nslab, g.a_slab_stride, g.a_aux, xalpha);
+        LoadB::load(rb, Bb, ldb, cb0, kbeg, tid, g.b_nslab, g.b_slab_stride, g.b_aux, xalpha);
         LoadA::store(ra, smem, tid);
         LoadB::store(rb, smem + BR * BK, tid);
         {
             const int64_t k1 = kbeg + (int64_t)((nk > 1) ? 1 : 0) * BK;
-            LoadA::load(ra, Ab, lda, ra0, k1, tid, g.a_nslab, g.a_slab_stride);
-            LoadB::load(rb, Bb, ldb, cb0, k1, tid, g.b_nslab, g.b_slab_stride);
+            LoadA::load(ra, Ab, lda, ra0, k1, tid, g.a_nslab, g.a_slab_stride, g.a_aux, xalpha);
+            LoadB::load(rb, Bb, ldb, cb0, k1, tid, g.b_nslab, g.b_slab_stride, g.b_aux, xalpha);
         }
         __syncthreads();
 
@@ -288,8 +305,8 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
                 constexpr bool ldA = (kg == NG / 2), ldB = (kg == (NG > 2 ? NG / 2 + 1 : NG / 2));
                 if constexpr (stA) LoadA::store(ra, a_n, tid);
                 if constexpr (stB) LoadB::store(rb, b_n, tid);
-                if constexpr (ldA) LoadA::load(ra, Ab, lda, ra0, kn, tid, g.a_nslab, g.a_slab_stride);
-                if constexpr (ldB) LoadB::load(rb, Bb, ldb, cb0, kn, tid, g.b_nslab, g.b_slab_stride);
+                if constexpr (ldA) LoadA::load(ra, Ab, lda, ra0, kn, tid, g.a_nslab, g.a_slab_stride, g.a_aux, xalpha);
+                if constexpr (ldB) LoadB::load(rb, Bb, ldb, cb0, kn, tid, g.b_nslab, g.b_slab_stride, g.b_aux, xalpha);
     #pragma unroll
                 for (int q = 0; q < M::VEC; ++q)
     #pragma unroll
@@ -316,31 +333,39 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
         // Epilogue.  MFMA C/D layout: f32 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
         // f64 16x16: col = lane&15, row = (lane>>4) + 4*reg.  col <-> c (contiguous), row <-> r.
         epi.begin(split, tctx);
-    #pragma unroll
-        for (int i = 0; i < TR; ++i)
-    #pragma unroll
+        // Two phases per ROW of MFMA tiles: issue every global load the epilogue needs for the row (prefetch), then
+        // compute and store (apply).  (Inputs and outputs of an epilogue may alias as far as the compiler knows, so a
+        // fused load-compute-store per element serialises one memory round trip per element.)  The scheduling barrier
+        // after each row keeps the compiler from hoisting ALL rows' prefetches to the top: with f64 (16 tiles per
+        // wave) that cost 250+ VGPRs and one wave per SIMD.
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+            const int64_t rbase = r0 + wr * WTR + i * MT;
+            typename Epi::Pre pre[TC][M::NACC];
+#pragma unroll
             for (int j = 0; j < TC; ++j) {
                 const int64_t c = c0 + wc * WTC + j * MT + (lane % MT);
-                const int64_t rbase = r0 + wr * WTR + i * MT;
-                // two phases per MFMA tile: issue every global load of the epilogue first, then compute and store.
-                // (Inputs and outputs of an epilogue may alias as far as the compiler knows, so a fused
-                // load-compute-store per element serialises one memory round trip per element.)
-                typename Epi::Pre pre[M::NACC];
-    #pragma unroll
+#pragma unroll
                 for (int reg = 0; reg < M::NACC; ++reg) {
                     int64_t r;
                     if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                     else r = rbase + (lane >> 4) + 4 * reg;
-                    pre[reg] = epi.prefetch(r, c);
-                }
-    #pragma unroll
-                for (int reg = 0; reg < M::NACC; ++reg) {
-                    int64_t r;
-                    if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                    else r = rbase + (lane >> 4) + 4 * reg;
-                    epi.apply(r, c, acc[i][j][reg], j, pre[reg]);
+                    pre[j][reg] = epi.prefetch(r, c);
                 }
             }
+#pragma unroll
+            for (int j = 0; j < TC; ++j) {
+                const int64_t c = c0 + wc * WTC + j * MT + (lane % MT);
+#pragma unroll
+                for (int reg = 0; reg < M::NACC; ++reg) {
+                    int64_t r;
+                    if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    else r = rbase + (lane >> 4) + 4 * reg;
+                    epi.apply(r, c, acc[i][j][reg], j, pre[j][reg]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     epi.template finish<MT, TC, WGR, WGC>(reinterpret_cast<double *>(smem), tctx);
 }

@@ -1,165 +1,197 @@
-// pgrad.hpp -- device kernels of the projected-gradient sub-solvers of ALSPGrad
+// pgrad.hpp -- device side of the projected-gradient sub-solvers of ALSPGrad
 // (_alspgrad_updateh!, src/alspgrad.jl:86-191; _alspgrad_updatew!, :242-347).
-// The back-tracking state machine (alpha, decr_alpha, it, break/continue) lives on the device
-// so a batch of back-tracking steps can be enqueued without a host round trip per step.
+//
+// None of the reference's work arrays Hn, Hp, D, WtWD (src/alspgrad.jl:41-60) exists on the device: each is a pure
+// function of (Z, G, alpha),
+//     Zn(alpha) = max(Z - alpha*G, 0),   D(alpha) = Zn(alpha) - Z,   Zp = Zn(alpha_prev),
+// so a back-tracking step is ONE MFMA GEMM launch -- Gram*D(alpha) with D computed inside the operand loader, and the
+// three scalars <G,D>, <Gram D,D>, ||Zp-Zn||^2 reduced in its epilogue -- plus a one-block decision kernel that carries
+// the state machine (alpha, decr_alpha, it, accept / restore / grow, "20 steps exhausted => unchanged", non-finite alpha).
+// A batch of steps is enqueued without a host round trip; steps after the loop breaks are no-ops (PgState::idle).
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "gemm_mfma.hpp"
 #include "kernels.hpp"
 
 namespace nmfx {
 
 struct PgState {
-    double alpha;        // step size, always a value of T
-    double red[4];       // reduced scalars of the current step: <G,D>, <Gram D,D>, ||Zp-Zn||^2, projgradnorm^2
+    double alpha;        // current step size, always a value of T                         (alspgrad.jl:119)
+    double alpha_prev;   // step size of the previous trial point Zp (valid if zp_valid)
+    double alpha_apply;  // step size whose Zn must become Z (set with apply = 1)
+    double red[4];       // <G,D>, <Gram D,D>, ||Zp-Zn||^2, projgradnorm^2
     int decr_alpha;
     int it;              // back-tracking steps done in the current inner iteration
     int idle;            // 1: no back-tracking in progress (kernels of further steps are no-ops)
     int converged;       // projgradnorm < tolg at the current inner iteration
-    int action;          // what pg_apply must do for step `action_step`: 1 Z<-Zn, 2 Z<-Zp, 3 Zp<-Zn
-    int action_step;
-    int nonfinite;       // alpha became non-finite ("alpha is not finite", src/alspgrad.jl:140,296)
-    int zp_valid;        // Zp holds a previous trial point (false at it == 1 where Hp == H)
+    int apply;           // 1: Z <- max(Z - alpha_apply*G, 0) pending (pg_apply_kernel clears it)
+    int nonfinite;       // alpha became non-finite ("alpha is not finite", alspgrad.jl:140,296)
+    int zp_valid;        // a previous trial point exists (false at it == 1 where Hp == H)
+    int pad;
     long long backtracks;
 };
 
-// partial[blk] = sum over this block of g^2 where (g < 0 or z > 0)   (projgradnorm, src/alspgrad.jl:9-19)
-template <typename T>
-__global__ void pg_norm_kernel(const T *G, const T *Z, int64_t count, double *partial) {
-    __shared__ double sm[4];
-    double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-        const T g = G[i];
-        if (g < (T)0 || Z[i] > (T)0) s += (double)(T)(g * g);
+template <typename T> __device__ __forceinline__ T pg_trial(T z, T g, T alpha) {
+    const T v = z - alpha * g;
+    return (v > (T)0) ? v : ((v != v) ? v : (T)0);          // max(v, 0), NaN propagates
+}
+
+// G = acc - B (src/alspgrad.jl:124-127, 280-283) + per-block partial of projgradnorm^2 (alspgrad.jl:9-19:
+// sum of g^2 where g < 0 or z > 0; term in T, sum in Float64).
+template <typename T> struct EpiGradNorm {
+    const T *B;
+    const T *Z;
+    T *G;
+    int64_t ld;
+    double *partial;   // one per block
+    double sum;
+    struct Pre { T b, z; };
+    __device__ __forceinline__ void begin(int, const TileCtx &) { sum = 0.0; }
+    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const {
+        const int64_t o = c + r * ld;
+        return Pre{B[o], Z[o]};
     }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int, const Pre &pre) {
+        const T g = v - pre.b;
+        G[c + r * ld] = g;
+        if (g < (T)0 || pre.z > (T)0) sum += (double)(T)(g * g);
+    }
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *smem, const TileCtx &t) {
+        block_sum_store(sum, smem, t.tid, t.nthreads, partial + t.bid);
+    }
+};
+
+// One back-tracking step: acc = (Gram * D(alpha))(r, c).  Per block: partial[3*bid + {0,1,2}] =
+//   <G, D>, <Gram D, D>, ||Zprev - Zn||^2   with Zprev = Zn(alpha_prev) if a previous trial exists, else Z
+// (src/alspgrad.jl:150-152 and the isapprox of :170).  Nothing is stored.
+template <typename T> struct EpiPgStep {
+    const T *Z;
+    const T *G;
+    int64_t ld;
+    const PgState *st;
+    double *partial;
+    T alpha, alpha_prev;
+    int zp_valid;
+    double s1, s2, s3;
+    struct Pre { T z, g; };
+    __device__ __forceinline__ void begin(int, const TileCtx &) {
+        alpha = (T)st->alpha;
+        alpha_prev = (T)st->alpha_prev;
+        zp_valid = st->zp_valid;
+        s1 = s2 = s3 = 0.0;
+    }
+    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const {
+        const int64_t o = c + r * ld;
+        return Pre{Z[o], G[o]};
+    }
+    __device__ __forceinline__ void apply(int64_t, int64_t, T v, int, const Pre &pre) {
+        const T zn = pg_trial(pre.z, pre.g, alpha);
+        const T d = zn - pre.z;
+        const T zprev = zp_valid ? pg_trial(pre.z, pre.g, alpha_prev) : pre.z;
+        const T e = zprev - zn;
+        s1 += (double)(T)(pre.g * d);
+        s2 += (double)(T)(v * d);
+        s3 += (double)(T)(e * e);
+    }
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *smem, const TileCtx &t) {
+        block_sum_store(s1, smem, t.tid, t.nthreads, partial + 3 * t.bid);
+        block_sum_store(s2, smem, t.tid, t.nthreads, partial + 3 * t.bid + 1);
+        block_sum_store(s3, smem, t.tid, t.nthreads, partial + 3 * t.bid + 2);
+    }
+};
+
+// fixed-order sum of `n` partials with stride `stride` starting at `off` (one block of 256 threads)
+__device__ __forceinline__ double pg_block_sum(const double *partial, int n, int stride, int off, double *sm) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[(int64_t)i * stride + off];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sm[q];
+    return t;
+}
+
+// start of an inner iteration (src/alspgrad.jl:129-137): red[3] = projgradnorm^2 from the gradient GEMM's partials
+// (n_local = 0 when the caller already reduced / all-reduced them into red[3]); converged if < tolg, else arm back-tracking.
+template <typename T> __global__ void pg_begin_kernel(PgState *st, const double *partial, int n_local, T tolg) {
+    __shared__ double sm[4];
+    if (n_local > 0) {
+        const double s = pg_block_sum(partial, n_local, 1, 0, sm);
+        if (threadIdx.x == 0) st->red[3] = s;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sm[q];
-        partial[blockIdx.x] = t;
+        const T pgnrm = sqrt((T)st->red[3]);
+        const bool conv = pgnrm < tolg;
+        st->converged = conv ? 1 : 0;
+        st->idle = conv ? 1 : 0;
+        st->it = 0;
+        st->zp_valid = 0;
+        st->apply = 0;
     }
 }
 
-// red[slot] = sum of n partials (fixed order).  One block.
-__global__ void pg_sum_kernel(const double *partial, int n, int nslots, double *red, int slot0, const int *idle) {
-    if (idle != nullptr && *reinterpret_cast<const volatile int *>(idle) != 0) return;
+// only the reduction part (sharded H: the partial sums are all-reduced before the decision)
+__global__ void pg_reduce_kernel(PgState *st, const double *partial, int n, int nslots, int slot0, int guard_idle) {
+    if (guard_idle && st->idle) return;
     __shared__ double sm[4];
     for (int sl = 0; sl < nslots; ++sl) {
-        double v = 0.0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[(int64_t)sl * n + i];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        const double s = pg_block_sum(partial, n, nslots, sl, sm);
+        if (threadIdx.x == 0) st->red[slot0 + sl] = s;
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-            for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sm[q];
-            red[slot0 + sl] = t;
+    }
+}
+
+// The branch logic of one back-tracking step (src/alspgrad.jl:155-177); n_local > 0: sum the step's partials first.
+template <typename T>
+__global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local, T beta, T sigma, T epsT, int traceiter) {
+    if (st->idle) return;
+    __shared__ double sm[4];
+    if (n_local > 0) {
+        for (int sl = 0; sl < 3; ++sl) {
+            const double s = pg_block_sum(partial, n_local, 3, sl, sm);
+            if (threadIdx.x == 0) st->red[sl] = s;
+            __syncthreads();
         }
     }
-}
-
-// start of an inner iteration (src/alspgrad.jl:129-137): converged if projgradnorm < tolg, else arm back-tracking
-template <typename T> __global__ void pg_begin_kernel(PgState *st, T tolg) {
-    const T pgnrm = sqrt((T)st->red[3]);
-    const bool conv = pgnrm < tolg;
-    st->converged = conv ? 1 : 0;
-    st->idle = conv ? 1 : 0;
-    st->it = 0;
-    st->zp_valid = 0;
-    st->action = 0;
-}
-
-// Zn = max(Z - alpha*G, 0); D = Zn - Z; partial[blk] = <G, D>   (src/alspgrad.jl:142-150)
-template <typename T>
-__global__ void pg_project_kernel(const T *Z, const T *G, T *Zn, T *D, int64_t count, PgState *st, double *partial) {
-    if (*reinterpret_cast<volatile int *>(&st->idle) != 0) return;
-    __shared__ double sm[4];
-    const T alpha = (T)st->alpha;
-    double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-        const T z = Z[i], g = G[i];
-        T v = z - alpha * g;
-        v = (v > (T)0) ? v : ((v != v) ? v : (T)0);
-        const T d = v - z;
-        Zn[i] = v;
-        D[i] = d;
-        s += (double)(T)(g * d);
-    }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sm[q];
-        partial[blockIdx.x] = t;
-    }
-}
-
-// partial[blk] = <GD, D>; partial[nblk + blk] = ||Zprev - Zn||^2 with Zprev = Zp if a previous trial exists else Z
-template <typename T>
-__global__ void pg_dots_kernel(const T *GD, const T *D, const T *Z, const T *Zp, const T *Zn, int64_t count, PgState *st,
-                               double *partial) {
-    if (*reinterpret_cast<volatile int *>(&st->idle) != 0) return;
-    __shared__ double sm[8];
-    const T *prev = st->zp_valid ? Zp : Z;
-    double s = 0.0, q2 = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-        const T d = D[i];
-        s += (double)(T)(GD[i] * d);
-        const T e = prev[i] - Zn[i];
-        q2 += (double)(T)(e * e);
-    }
-    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q2 += __shfl_down(q2, off, 64); }
-    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = s; sm[4 + (threadIdx.x >> 6)] = q2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) { a += sm[q]; b += sm[4 + q]; }
-        partial[blockIdx.x] = a;
-        partial[gridDim.x + blockIdx.x] = b;
-    }
-}
-
-// The branch logic of one back-tracking step (src/alspgrad.jl:155-177).
-template <typename T>
-__global__ void pg_decide_kernel(PgState *st, T beta, T sigma, T epsT, int traceiter, int step_id) {
-    if (st->idle) return;
+    if (threadIdx.x != 0) return;
     T alpha = (T)st->alpha;
-    if (!isfinite(alpha)) { st->nonfinite = 1; st->idle = 1; return; }   // :140 (checked at the top of each step)
+    if (!isfinite(alpha)) { st->nonfinite = 1; st->idle = 1; return; }   // :140 (the step's sums are garbage then)
     const T dv1 = (T)st->red[0], dv2 = (T)st->red[1];
     const bool suff_decr = (((T)1 - sigma) * dv1 + (T)0.5 * dv2) < (T)0;
     st->it += 1;
     st->backtracks += 1;
-    int action = 0;
     bool brk = false;
     if (st->it == 1) st->decr_alpha = suff_decr ? 0 : 1;                  // :157-160 (Hp <- H is implicit: zp_valid = 0)
     if (st->decr_alpha) {
-        if (suff_decr) { action = 1; brk = true; }                        // :163-165 H <- Hn
+        if (suff_decr) { st->apply = 1; st->alpha_apply = (double)alpha; brk = true; }   // :163-165 H <- Hn
         else alpha = alpha * beta;                                        // :167
     } else {
         const T nrm = sqrt((T)st->red[2]);                                // isapprox(Hp, Hn, atol=eps(T)) <=> ||Hp-Hn|| <= eps
-        if (!suff_decr || nrm <= epsT) { action = st->zp_valid ? 2 : 0; brk = true; }   // :170-172 H <- Hp
-        else { alpha = alpha / beta; action = 3; st->zp_valid = 1; }      // :174-175 Hp <- Hn
+        if (!suff_decr || nrm <= epsT) {                                  // :170-172 H <- Hp
+            if (st->zp_valid) { st->apply = 1; st->alpha_apply = st->alpha_prev; }
+            brk = true;
+        } else {                                                          // :174-175 alpha /= beta; Hp <- Hn
+            st->alpha_prev = (double)alpha;
+            st->zp_valid = 1;
+            alpha = alpha / beta;
+        }
     }
     st->alpha = (double)alpha;
-    st->action = action;
-    st->action_step = step_id;
     if (brk || st->it >= traceiter) st->idle = 1;                         // loop exhausted: Z unchanged (quirk i)
 }
 
-template <typename T>
-__global__ void pg_apply_kernel(T *Z, T *Zp, const T *Zn, int64_t count, const PgState *st, int step_id) {
-    if (st->action_step != step_id) return;
-    const int action = st->action;
-    if (action == 0) return;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-        if (action == 1) Z[i] = Zn[i];
-        else if (action == 2) Z[i] = Zp[i];
-        else Zp[i] = Zn[i];
-    }
+// Z <- max(Z - alpha_apply*G, 0) if the decision asked for it (H <- Hn / H <- Hp of the reference)
+template <typename T> __global__ void pg_apply_kernel(T *Z, const T *G, int64_t count, PgState *st, int *apply_seen) {
+    if (!st->apply) return;
+    const T a = (T)st->alpha_apply;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        Z[i] = pg_trial(Z[i], G[i], a);
+    (void)apply_seen;
 }
+__global__ void pg_clear_apply_kernel(PgState *st) { st->apply = 0; }
 
 }  // namespace nmfx

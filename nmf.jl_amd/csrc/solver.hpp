@@ -336,6 +336,8 @@ template <typename T> class Solver : public SolverBase {
         const T *B2 = nullptr; int64_t ldb2 = 0, c_split = INT64_MAX;
         int a_nslab = 1, b_nslab = 1; int64_t a_slab_stride = 0, b_slab_stride = 0;
         int tail_tiles = 0;    // extra tiles along the slow direction, processed as a balanced tail segment
+        const T *a_aux = nullptr, *b_aux = nullptr;   // operand computed on the fly (projected-gradient trial step)
+        const double *alpha_ptr = nullptr;
     };
     template <int LA, int LB, typename Epi>
     void gemm(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim,
@@ -347,6 +349,7 @@ template <typename T> class Solver : public SolverBase {
         g.B2 = seg.B2; g.ldb2 = seg.ldb2; g.c_split = seg.c_split;
         g.a_nslab = seg.a_nslab; g.b_nslab = seg.b_nslab; g.a_slab_stride = seg.a_slab_stride; g.b_slab_stride = seg.b_slab_stride;
         g.tail_tiles = seg.tail_tiles; g.tail_nkt = (int)(Kdim / BK);
+        g.a_aux = seg.a_aux; g.b_aux = seg.b_aux; g.alpha_ptr = seg.alpha_ptr;
         g.splits = splits;
         g.kchunk = (int)(Kdim / splits);
         g.c_fastest = c_fastest ? 1 : 0;

@@ -366,6 +366,10 @@ template <typename T> class Solver : public SolverBase {
             } else if (small_k && R % 128 == 0 && C % 64 == 0 && C > R) {
                 g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 64);
                 launch_gemm_cfg<LA, LB, 128, 64, 4, 1>(g, epi);
+            } else if (small_k && (C == 64 || R == 64) && R % 64 == 0 && C % 64 == 0) {
+                // k <= 64: 64 x 64 tiles give 4x the blocks of the 256 x 64 / 64 x 256 shapes (16 -> 64 at C2)
+                g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 64);
+                launch_gemm_cfg<LA, LB, 64, 64, 2, 2>(g, epi);
             } else if (R % 128 == 0 && C % 128 == 0) {
                 g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 128);
                 if (splits == 1 && g.tiles_r >= 16 && g.tiles_c >= 16 && g.tiles_r % 8 == 0 && g.tiles_c % 8 == 0) g.group = 8;

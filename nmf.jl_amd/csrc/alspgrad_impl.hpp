@@ -43,10 +43,10 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
         int nblk;
         if (left) {
             sg.a_aux = G;
-            gemm<KCONTIG, KCONTIG>("gemm_pg_step", Z, K, N, Gram, K, K, K, 1, true, e, idle, 4.0 * K * N * sizeof(T), sg);
+            gemm<KCONTIG, KCONTIG, 1>("gemm_pg_step", Z, K, N, Gram, K, K, K, 1, true, e, idle, 4.0 * K * N * sizeof(T), sg);
         } else {
             sg.b_aux = G;
-            gemm<KSTRIDED, KSTRIDED>("gemm_pg_step", Gram, K, K, Z, P, P, K, 1, false, e, idle, 4.0 * P * K * sizeof(T), sg);
+            gemm<KSTRIDED, KSTRIDED, 2>("gemm_pg_step", Gram, K, K, Z, P, P, K, 1, false, e, idle, 4.0 * P * K * sizeof(T), sg);
         }
         nblk = last_blocks;
         if (sharded) {

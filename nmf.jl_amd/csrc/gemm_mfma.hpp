@@ -70,11 +70,6 @@ template <typename T> struct GemmArgs {
     const T *B2 = nullptr;
     int64_t lda2 = 0, ldb2 = 0;
     int64_t r_split = INT64_MAX, c_split = INT64_MAX;
-    // An operand may itself be a split-K result that has not been reduced yet: element = sum over
-    // a_nslab (b_nslab) slabs, slab s at base + s*a_slab_stride.  (Used for the k x k Gram operand of the
-    // update GEMMs, whose 8 k-tiles are all L2 hits; saves a reduction launch.)
-    int a_nslab = 1, b_nslab = 1;
-    int64_t a_slab_stride = 0, b_slab_stride = 0;
     int group = 1;          // >1: super-tile rasterisation (see the block -> tile mapping)
     const T *a_aux = nullptr, *b_aux = nullptr;   // operand computed on the fly as max(z - alpha*g, 0) - z (see TileLoader::load)
     const double *alpha_ptr = nullptr;            // device-resident step size (PgState::alpha)
@@ -105,9 +100,11 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
     // aux != nullptr: the operand is not read but COMPUTED on the fly from two arrays with identical addressing,
     //   d = max(z - alpha*g, 0) - z   (z from `base`, g from `aux`)
     // i.e. the projected-gradient trial step D = Zn - Z of src/alspgrad.jl:142-147, which therefore never exists in memory.
+    // (AUX is a compile-time flag: a run-time test here would split the software-pipelined main loop into basic
+    // blocks and void its issue-order template -- measured 142 -> 133 TF/s on the big GEMM.)
+    template <bool AUX = false>
     static __device__ __forceinline__ void load(vec_t (&r)[PER_THREAD], const T *base, int64_t ld,
-                                                int64_t row0, int64_t k0, int tid, int nslab = 1, int64_t slab_stride = 0,
-                                                const T *aux = nullptr, T alpha = (T)0) {
+                                                int64_t row0, int64_t k0, int tid, const T *aux = nullptr, T alpha = (T)0) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int s = tid + NTHREADS * i;
@@ -123,8 +120,7 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
                 p = base + (k0 + kk) * ld + row0 + r4 * VEC;
             }
             r[i] = *reinterpret_cast<const vec_t *>(p);
-            for (int sl = 1; sl < nslab; ++sl) r[i] += *reinterpret_cast<const vec_t *>(p + (int64_t)sl * slab_stride);
-            if (aux != nullptr) {
+            if constexpr (AUX) {
                 const vec_t gv = *reinterpret_cast<const vec_t *>(aux + (p - base));
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) {
@@ -181,7 +177,8 @@ template <int MASK, int N> __device__ __forceinline__ void sched_pairs() {
     }
 }
 
-template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi>
+// AUX: 0 plain operands; 1 / 2: operand A / B is the projected-gradient trial step computed in the loader.
+template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi, int AUX = 0>
 __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g, Epi epi) {
     using M = Mfma<T>;
     constexpr int NT = WGR * WGC * 64;
@@ -193,7 +190,8 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     using LoadB = TileLoader<T, LB, BC, NT>;
 
     if (g.done != nullptr && *reinterpret_cast<const volatile int *>(g.done) != 0) return;
-    const T xalpha = (g.alpha_ptr != nullptr) ? (T)*g.alpha_ptr : (T)0;
+    T xalpha = (T)0;
+    if constexpr (AUX != 0) xalpha = (T)*g.alpha_ptr;
     __shared__ __attribute__((aligned(16))) T smem[2 * (BR + BC) * BK];
     constexpr int STAGE = (BR + BC) * BK;   // stage s: A tile at smem + s*STAGE, B tile right behind it
 
@@ -276,14 +274,14 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
         //   second half                : global   -> registers, tile t+2  (loads interleaved with MFMAs)
         // Stage (t+1)&1 was last read during tile t-1, i.e. before the barrier that ended iteration t-1.
         typename M::vec_t ra[LoadA::PER_THREAD], rb[LoadB::PER_THREAD];
-        LoadA::load(ra, Ab, lda, ra0, kbeg, tid, g.a_nslab, g.a_slab_stride, g.a_aux, xalpha);
-        LoadB::load(rb, Bb, ldb, cb0, kbeg, tid, g.b_nslab, g.b_slab_stride, g.b_aux, xalpha);
+        LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, kbeg, tid, g.a_aux, xalpha);
+        LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, kbeg, tid, g.b_aux, xalpha);
         LoadA::store(ra, smem, tid);
         LoadB::store(rb, smem + BR * BK, tid);
         {
             const int64_t k1 = kbeg + (int64_t)((nk > 1) ? 1 : 0) * BK;
-            LoadA::load(ra, Ab, lda, ra0, k1, tid, g.a_nslab, g.a_slab_stride, g.a_aux, xalpha);
-            LoadB::load(rb, Bb, ldb, cb0, k1, tid, g.b_nslab, g.b_slab_stride, g.b_aux, xalpha);
+            LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, k1, tid, g.a_aux, xalpha);
+            LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, k1, tid, g.b_aux, xalpha);
         }
         __syncthreads();
 
@@ -305,8 +303,8 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
                 constexpr bool ldA = (kg == NG / 2), ldB = (kg == (NG > 2 ? NG / 2 + 1 : NG / 2));
                 if constexpr (stA) LoadA::store(ra, a_n, tid);
                 if constexpr (stB) LoadB::store(rb, b_n, tid);
-                if constexpr (ldA) LoadA::load(ra, Ab, lda, ra0, kn, tid, g.a_nslab, g.a_slab_stride, g.a_aux, xalpha);
-                if constexpr (ldB) LoadB::load(rb, Bb, ldb, cb0, kn, tid, g.b_nslab, g.b_slab_stride, g.b_aux, xalpha);
+                if constexpr (ldA) LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, kn, tid, g.a_aux, xalpha);
+                if constexpr (ldB) LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, kn, tid, g.b_aux, xalpha);
     #pragma unroll
                 for (int q = 0; q < M::VEC; ++q)
     #pragma unroll

@@ -322,10 +322,10 @@ template <typename T> class Solver : public SolverBase {
         records.push_back(Rec{name, id, flops, bytes});
     }
 
-    template <int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi>
+    template <int LA, int LB, int BR, int BC, int WGR, int WGC, int AUX, typename Epi>
     void launch_gemm_cfg(const GemmArgs<T> &g, const Epi &epi) {
         const int blocks = g.tiles_r * g.tiles_c * g.splits;
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi>), dim3(blocks), dim3(WGR * WGC * 64), 0,
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi, AUX>), dim3(blocks), dim3(WGR * WGC * 64), 0,
                            stream, g, epi);
         HIP_TRY(hipGetLastError());
     }
@@ -334,12 +334,11 @@ template <typename T> class Solver : public SolverBase {
     struct Seg {   // optional second operand segment (see GemmArgs)
         const T *A2 = nullptr; int64_t lda2 = 0, r_split = INT64_MAX;
         const T *B2 = nullptr; int64_t ldb2 = 0, c_split = INT64_MAX;
-        int a_nslab = 1, b_nslab = 1; int64_t a_slab_stride = 0, b_slab_stride = 0;
         int tail_tiles = 0;    // extra tiles along the slow direction, processed as a balanced tail segment
         const T *a_aux = nullptr, *b_aux = nullptr;   // operand computed on the fly (projected-gradient trial step)
         const double *alpha_ptr = nullptr;
     };
-    template <int LA, int LB, typename Epi>
+    template <int LA, int LB, int AUX = 0, typename Epi>
     void gemm(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim,
               int splits, bool c_fastest, const Epi &epi, const int *done, double bytes = 0.0, const Seg &seg = Seg(),
               double extra_flops = 0.0) {
@@ -347,7 +346,6 @@ template <typename T> class Solver : public SolverBase {
         g.A = A; g.B = B; g.lda = lda; g.ldb = ldb;
         g.A2 = seg.A2; g.lda2 = seg.lda2; g.r_split = seg.r_split;
         g.B2 = seg.B2; g.ldb2 = seg.ldb2; g.c_split = seg.c_split;
-        g.a_nslab = seg.a_nslab; g.b_nslab = seg.b_nslab; g.a_slab_stride = seg.a_slab_stride; g.b_slab_stride = seg.b_slab_stride;
         g.tail_tiles = seg.tail_tiles; g.tail_nkt = (int)(Kdim / BK);
         g.a_aux = seg.a_aux; g.b_aux = seg.b_aux; g.alpha_ptr = seg.alpha_ptr;
         g.splits = splits;
@@ -362,28 +360,28 @@ template <typename T> class Solver : public SolverBase {
         timed(name, flops, bytes, [&] {
             if (small_k && R % 64 == 0 && C % 128 == 0 && R >= C) {
                 g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 128);
-                launch_gemm_cfg<LA, LB, 64, 128, 1, 4>(g, epi);
+                launch_gemm_cfg<LA, LB, 64, 128, 1, 4, AUX>(g, epi);
             } else if (small_k && R % 128 == 0 && C % 64 == 0 && C > R) {
                 g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 64);
-                launch_gemm_cfg<LA, LB, 128, 64, 4, 1>(g, epi);
+                launch_gemm_cfg<LA, LB, 128, 64, 4, 1, AUX>(g, epi);
             } else if (small_k && (C == 64 || R == 64) && R % 64 == 0 && C % 64 == 0) {
                 // k <= 64: 64 x 64 tiles give 4x the blocks of the 256 x 64 / 64 x 256 shapes (16 -> 64 at C2)
                 g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 64);
-                launch_gemm_cfg<LA, LB, 64, 64, 2, 2>(g, epi);
+                launch_gemm_cfg<LA, LB, 64, 64, 2, 2, AUX>(g, epi);
             } else if (R % 128 == 0 && C % 128 == 0) {
                 g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 128);
                 if (splits == 1 && g.tiles_r >= 16 && g.tiles_c >= 16 && g.tiles_r % 8 == 0 && g.tiles_c % 8 == 0) g.group = 8;
                 if (g.tail_tiles > 0) g.tail_per = tail_piece(g.tiles_r * g.tiles_c * splits, g.tail_tiles * (c_fastest ? g.tiles_c : g.tiles_r), g.tail_nkt);
-                launch_gemm_cfg<LA, LB, 128, 128, 2, 2>(g, epi);
+                launch_gemm_cfg<LA, LB, 128, 128, 2, 2, AUX>(g, epi);
             } else if (C == 64 && R % 256 == 0) {
                 g.tiles_r = (int)(R / 256); g.tiles_c = 1;
-                launch_gemm_cfg<LA, LB, 256, 64, 4, 1>(g, epi);
+                launch_gemm_cfg<LA, LB, 256, 64, 4, 1, AUX>(g, epi);
             } else if (R == 64 && C % 256 == 0) {
                 g.tiles_r = 1; g.tiles_c = (int)(C / 256);
-                launch_gemm_cfg<LA, LB, 64, 256, 1, 4>(g, epi);
+                launch_gemm_cfg<LA, LB, 64, 256, 1, 4, AUX>(g, epi);
             } else if (R == 64 && C == 64) {
                 g.tiles_r = 1; g.tiles_c = 1;
-                launch_gemm_cfg<LA, LB, 64, 64, 2, 2>(g, epi);
+                launch_gemm_cfg<LA, LB, 64, 64, 2, 2, AUX>(g, epi);
             } else {
                 throw StatusError{NMFX_ERR_UNSUPPORTED, "internal: no tile configuration for this GEMM shape"};
             }

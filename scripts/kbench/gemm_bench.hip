@@ -29,6 +29,18 @@ double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool 
     g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.tiles_r = (int)(R / BR); g.tiles_c = (int)(C / BC);
     g.splits = splits; g.kchunk = (int)(Kd / splits); g.c_fastest = c_fastest; g.done = nullptr; 
     EpiStore<T> e{D, C, R * C, nullptr};
+    T *D2 = nullptr;
+    if (g_stagger) {   // Gram tail: extra tiles A2 = B (the small operand), (C/BC)^2 tail tiles
+        g.A2 = B; g.lda2 = ldb; g.r_split = R; g.tail_tiles = (int)(C / BR); g.tail_nkt = (int)(Kd / Mfma<T>::BK);
+        const int blocks0 = g.tiles_r * g.tiles_c * splits;
+        const int tt = g.tail_tiles * g.tiles_c;
+        int per = std::max(1, (int)(((int64_t)tt * g.tail_nkt + blocks0 - 1) / blocks0));
+        while ((int64_t)tt * ((g.tail_nkt + per - 1) / per) > blocks0) ++per;
+        g.tail_per = per;
+        const int pieces = (g.tail_nkt + per - 1) / per;
+        CK(hipMalloc(&D2, (size_t)pieces * C * C * sizeof(T)));
+        e.C2 = D2; e.ld2 = C; e.stride2 = C * C; e.r_off = R; e.c_off = 0;
+    }
     const int blocks = g.tiles_r * g.tiles_c * splits;
 
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -69,7 +81,8 @@ double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool 
 int main(int argc, char **argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 6;
     g_mode = 1;
-    for (int st : {0}) {
+    for (int st : {0, 1}) {
+    printf("--- gram tail %d\n", st);
     g_stagger = st;
     
     run<float, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN big (WtX) 128x128", 16384, 256, 16384, 2, true, reps);

@@ -87,6 +87,18 @@ struct TileCtx {
 // XOR swizzle of the 16-byte chunk position inside a KCONTIG LDS row (8 chunks/row):
 // conflict-free ds_read_b128 for 16 rows distinct mod 16 (MI355X LDS: 64 banks x 4 B).
 __device__ __forceinline__ int swz8(int row) { return (row >> 1) & 7; }
+// Row permutation of the KSTRIDED micro-tile image (16-byte slot index inside one k-quad): makes BOTH the
+// ds_write_b128 of a micro-tile row (lanes 4 rows apart: 64-byte stride) and the ds_read_b128 of a fragment
+// (lanes on consecutive rows) conflict-free.
+__device__ __forceinline__ int swzrow(int r) { return r ^ ((r >> 3) & 3); }
+
+// KSTRIDED tiles use the transposing micro-tile image when every thread owns whole VEC x VEC micro-tiles; small
+// tiles (fewer chunks per thread than VEC) keep the plain [k][row] image.
+template <typename T, int ROWS, int NTHREADS> constexpr bool kstrided_micro() {
+    // f32 only: with f64 (2 x 2 micro-tiles, 8-byte fragment reads already pair up) the plain image measured faster
+    return sizeof(T) == 4 && ((ROWS * Mfma<T>::BK / Mfma<T>::VEC / NTHREADS) % Mfma<T>::VEC) == 0 &&
+           (ROWS * Mfma<T>::BK / Mfma<T>::VEC / NTHREADS) > 0;
+}
 
 template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
     using M = Mfma<T>;
@@ -105,45 +117,88 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
     template <bool AUX = false>
     static __device__ __forceinline__ void load(vec_t (&r)[PER_THREAD], const T *base, int64_t ld,
                                                 int64_t row0, int64_t k0, int tid, const T *aux = nullptr, T alpha = (T)0) {
+        if constexpr (LAYOUT == KCONTIG) {
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int s = tid + NTHREADS * i;
-            const T *p;
-            if constexpr (LAYOUT == KCONTIG) {
+            for (int i = 0; i < PER_THREAD; ++i) {
+                const int s = tid + NTHREADS * i;
                 constexpr int CPR = BK / VEC;   // 8 chunks per row
                 const int row = s / CPR, cpos = s % CPR;
                 const int c = cpos ^ swz8(row);
-                p = base + (row0 + row) * ld + k0 + c * VEC;
-            } else {
-                constexpr int CPK = ROWS / VEC;
-                const int kk = s / CPK, r4 = s % CPK;
-                p = base + (k0 + kk) * ld + row0 + r4 * VEC;
+                const T *p = base + (row0 + row) * ld + k0 + c * VEC;
+                r[i] = *reinterpret_cast<const vec_t *>(p);
+                if constexpr (AUX) xform(r[i], *reinterpret_cast<const vec_t *>(aux + (p - base)), alpha);
             }
-            r[i] = *reinterpret_cast<const vec_t *>(p);
-            if constexpr (AUX) {
-                const vec_t gv = *reinterpret_cast<const vec_t *>(aux + (p - base));
+        } else {
+            // KSTRIDED: a thread owns VEC x VEC micro-tiles (VEC rows x VEC consecutive k): VEC global loads of 16 bytes
+            // (rows contiguous), transposed in registers (free: only the register naming changes), so that the LDS
+            // image is [k/VEC][row][VEC] and one ds_read_b128 yields a lane's VEC consecutive k -- the same fragment
+            // read as the KCONTIG image (the [k][row] image needed 4x as many LDS reads: 134.6 vs 142 TF/s).
+          if constexpr (kstrided_micro<T, ROWS, NTHREADS>()) {
+            constexpr int RPV = ROWS / VEC;   // micro-tile columns (groups of VEC rows)
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) {
-                    const T z = r[i][q];
-                    T v = z - alpha * gv[q];
-                    v = (v > (T)0) ? v : ((v != v) ? v : (T)0);
-                    r[i][q] = v - z;
+            for (int m = 0; m < PER_THREAD / VEC; ++m) {
+                const int mt = tid + NTHREADS * m;
+                const int kq = mt / RPV, r4 = mt % RPV;
+                // r[m*VEC + ek] = raw chunk of k-row ek; the transpose happens in store(), one k-tile later, when the
+                // data has long arrived (transposing here would put an s_waitcnt vmcnt right behind the loads)
+#pragma unroll
+                for (int ek = 0; ek < VEC; ++ek) {
+                    const T *p = base + (k0 + kq * VEC + ek) * ld + row0 + r4 * VEC;
+                    r[m * VEC + ek] = *reinterpret_cast<const vec_t *>(p);
+                    if constexpr (AUX) xform(r[m * VEC + ek], *reinterpret_cast<const vec_t *>(aux + (p - base)), alpha);
                 }
             }
+          } else {
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) {
+                const int s = tid + NTHREADS * i;
+                constexpr int CPK = ROWS / VEC;
+                const int kk = s / CPK, r4 = s % CPK;
+                const T *p = base + (k0 + kk) * ld + row0 + r4 * VEC;
+                r[i] = *reinterpret_cast<const vec_t *>(p);
+                if constexpr (AUX) xform(r[i], *reinterpret_cast<const vec_t *>(aux + (p - base)), alpha);
+            }
+          }
         }
     }
-    // registers -> LDS (linear image: chunk s at byte 16*s)
-    static __device__ __forceinline__ void store(const vec_t (&r)[PER_THREAD], T *lds, int tid) {
+    static __device__ __forceinline__ void xform(vec_t &z, const vec_t &gv, T alpha) {
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int s = tid + NTHREADS * i;
-            *reinterpret_cast<vec_t *>(lds + s * VEC) = r[i];
+        for (int q = 0; q < VEC; ++q) {
+            const T zz = z[q];
+            T v = zz - alpha * gv[q];
+            v = (v > (T)0) ? v : ((v != v) ? v : (T)0);
+            z[q] = v - zz;
+        }
+    }
+    // registers -> LDS.  KCONTIG: linear image, chunk s at byte 16*s.  KSTRIDED: micro-tile (kq, r4), row er at
+    // 16-byte slot kq*ROWS + r4*VEC + er.
+    static __device__ __forceinline__ void store(const vec_t (&r)[PER_THREAD], T *lds, int tid) {
+        if constexpr (LAYOUT == KCONTIG || !kstrided_micro<T, ROWS, NTHREADS>()) {
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) {
+                const int s = tid + NTHREADS * i;
+                *reinterpret_cast<vec_t *>(lds + s * VEC) = r[i];
+            }
+        } else {
+            constexpr int RPV = ROWS / VEC;
+#pragma unroll
+            for (int m = 0; m < PER_THREAD / VEC; ++m) {
+                const int mt = tid + NTHREADS * m;
+                const int kq = mt / RPV, r4 = mt % RPV;
+#pragma unroll
+                for (int er = 0; er < VEC; ++er) {
+                    vec_t t;
+#pragma unroll
+                    for (int ek = 0; ek < VEC; ++ek) t[ek] = r[m * VEC + ek][er];
+                    *reinterpret_cast<vec_t *>(lds + (kq * ROWS + swzrow(r4 * VEC + er)) * VEC) = t;
+                }
+            }
         }
     }
 };
 
 // Read the VEC operand values of k-group g for the MFMA row-tile starting at tile row rt.
-template <typename T, int LAYOUT, int ROWS>
+template <typename T, int LAYOUT, int ROWS, int NTHREADS>
 __device__ __forceinline__ void read_frag(T (&out)[Mfma<T>::VEC], const T *lds, int rt, int g, int lane) {
     using M = Mfma<T>;
     const int r = rt + (lane % M::MT);
@@ -152,6 +207,11 @@ __device__ __forceinline__ void read_frag(T (&out)[Mfma<T>::VEC], const T *lds, 
         const int c = (g * M::KS + ks) ^ swz8(r);
         const typename M::vec_t v =
             *reinterpret_cast<const typename M::vec_t *>(lds + (r * (M::BK / M::VEC) + c) * M::VEC);
+#pragma unroll
+        for (int q = 0; q < M::VEC; ++q) out[q] = v[q];
+    } else if constexpr (kstrided_micro<T, ROWS, NTHREADS>()) {
+        const typename M::vec_t v =
+            *reinterpret_cast<const typename M::vec_t *>(lds + ((g * M::KS + ks) * ROWS + swzrow(r)) * M::VEC);
 #pragma unroll
         for (int q = 0; q < M::VEC; ++q) out[q] = v[q];
     } else {
@@ -286,6 +346,14 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
         __syncthreads();
 
         constexpr int NG = BK / 8;   // k-groups per tile
+        // fragments of the FIRST k-group of a tile are fetched one k-group early (right after the barrier that
+        // publishes the tile, in front of the previous tile's last MFMAs), so the barrier is never followed by an
+        // exposed LDS round trip
+        T af0[TR][M::VEC], bf0[TC][M::VEC];
+#pragma unroll
+        for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af0[i], smem, wr * WTR + i * MT, 0, lane);
+#pragma unroll
+        for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf0[j], smem + BR * BK, wc * WTC + j * MT, 0, lane);
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
             const T *a_s = smem + cur * STAGE, *b_s = a_s + BR * BK;
@@ -294,39 +362,61 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
             const int64_t kn = kbeg + (int64_t)tn * BK;
             static_for<NG>([&](auto KGC) {
                 constexpr int kg = decltype(KGC)::value;
+                constexpr bool last = (kg == NG - 1);
                 T af[TR][M::VEC], bf[TC][M::VEC];
-    #pragma unroll
-                for (int i = 0; i < TR; ++i) read_frag<T, LA, BR>(af[i], a_s, wr * WTR + i * MT, kg, lane);
-    #pragma unroll
-                for (int j = 0; j < TC; ++j) read_frag<T, LB, BC>(bf[j], b_s, wc * WTC + j * MT, kg, lane);
+                if constexpr (kg == 0) {
+#pragma unroll
+                    for (int i = 0; i < TR; ++i)
+#pragma unroll
+                        for (int q = 0; q < M::VEC; ++q) af[i][q] = af0[i][q];
+#pragma unroll
+                    for (int j = 0; j < TC; ++j)
+#pragma unroll
+                        for (int q = 0; q < M::VEC; ++q) bf[j][q] = bf0[j][q];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[i], a_s, wr * WTR + i * MT, kg, lane);
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[j], b_s, wc * WTC + j * MT, kg, lane);
+                }
                 constexpr bool stA = (kg == 0), stB = (kg == (NG > 2 ? 1 : 0));
                 constexpr bool ldA = (kg == NG / 2), ldB = (kg == (NG > 2 ? NG / 2 + 1 : NG / 2));
                 if constexpr (stA) LoadA::store(ra, a_n, tid);
                 if constexpr (stB) LoadB::store(rb, b_n, tid);
+                if constexpr (last) {
+                    // every LDS read of tile t and every LDS write of tile t+1 by this wave is issued: publish tile t+1,
+                    // then fetch its first fragments while the MFMAs below still run on tile t's registers
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af0[i], a_n, wr * WTR + i * MT, 0, lane);
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf0[j], b_n, wc * WTC + j * MT, 0, lane);
+                }
                 if constexpr (ldA) LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, kn, tid, g.a_aux, xalpha);
                 if constexpr (ldB) LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, kn, tid, g.b_aux, xalpha);
-    #pragma unroll
+#pragma unroll
                 for (int q = 0; q < M::VEC; ++q)
-    #pragma unroll
+#pragma unroll
                     for (int i = 0; i < TR; ++i)
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < TC; ++j) acc[i][j] = M::mma(af[i][q], bf[j][q], acc[i][j]);
                 // Issue-order template for this k-group (LLVM sched_group_barrier; masks: MFMA 0x8, VMEM read 0x20,
                 // DS read 0x100, DS write 0x200): fragment reads first, then the staging traffic of this group spread
                 // one instruction per MFMA pair, so neither the LDS writes nor the global loads open an MFMA-free window.
                 constexpr int NMFMA = M::VEC * TR * TC;
-                constexpr int NFRAG = (LA == KCONTIG ? TR : TR * M::VEC) + (LB == KCONTIG ? TC : TC * M::VEC);
+                constexpr int NFRAG = ((LA == KCONTIG || kstrided_micro<T, BR, NT>()) ? TR : TR * M::VEC) +
+                                      ((LB == KCONTIG || kstrided_micro<T, BC, NT>()) ? TC : TC * M::VEC);
                 constexpr int NW0 = (stA ? LoadA::PER_THREAD : 0) + (stB ? LoadB::PER_THREAD : 0);
                 constexpr int NL0 = (ldA ? LoadA::PER_THREAD : 0) + (ldB ? LoadB::PER_THREAD : 0);
                 constexpr int NW = (2 * NW0 <= NMFMA) ? NW0 : NMFMA / 2;
                 constexpr int NL = (2 * (NW + NL0) <= NMFMA) ? NL0 : (NMFMA / 2 - NW);
-                __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
+                if constexpr (kg != 0) __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
                 sched_pairs<0x200, NW>();
                 sched_pairs<0x20, NL>();
                 if constexpr (NMFMA - 2 * (NW + NL) > 0) __builtin_amdgcn_sched_group_barrier(0x8, NMFMA - 2 * (NW + NL), 0);
             });
-            __syncthreads();
         }
+        __syncthreads();   // the staging buffers are re-used by the next segment / the epilogue reductions
 
         // Epilogue.  MFMA C/D layout: f32 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
         // f64 16x16: col = lane&15, row = (lane>>4) + 4*reg.  col <-> c (contiguous), row <-> r.

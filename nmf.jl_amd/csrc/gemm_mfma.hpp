@@ -81,7 +81,43 @@ template <typename T> struct GemmArgs {
 // what an epilogue may need to know about the block / wave it runs in
 struct TileCtx {
     int tr, tc, wr, wc, lane, tid, nthreads, bid;
-    int64_t r0, c0;
+    int64_t r0, c0;     // block tile origin
+    int rl, cl;         // the lane's row / column inside an MFMA output tile
+    int64_t rw0, cw0;   // wave tile origin (wave-uniform)
+};
+
+// Epilogue addressing.  Element (r, c) of the wave's output tile splits into a WAVE-UNIFORM part (wave tile origin
+// (rw0, cw0), MFMA tile and accumulator register: compile-time (ro, co) relative to the origin) and a LANE part (rl, cl)
+// that is the same for every element a lane owns.  Every array an epilogue touches gets a buffer descriptor based at
+// the wave tile origin; element (ro, co) is then  buffer_load/store v, v_lane_off, s[desc], s_off offen  with ONE
+// shared 32-bit lane-offset VGPR and the row/column offset in an SGPR: no per-element address lives in VGPRs.  (The
+// plain  base[c + r*ld]  form kept a 64-bit VGPR pointer per accumulator row and prefetch set -- 30-60 VGPRs that put
+// the ratio / update / gradient kernels at one wave per SIMD -- plus 64-bit VALU address arithmetic per element.)
+// Offsets are 32-bit and relative to the wave tile: 256 * ld * sizeof(T) must stay below 2^32 (checked by the host).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+template <typename T> __device__ __forceinline__ rsrc_t tile_rsrc(const T *base, int64_t ld, const TileCtx &t) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(base + (t.cw0 + t.rw0 * ld)), 0, -1, 0x00020000);
+}
+template <typename T> __device__ __forceinline__ T buf_ld(rsrc_t rs, uint32_t voff, uint32_t soff) {
+    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
+    else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0));
+}
+template <typename T> __device__ __forceinline__ void buf_st(rsrc_t rs, uint32_t voff, uint32_t soff, T v) {
+    if constexpr (sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)voff, (int)soff, 0);
+    } else {
+        typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, v), rs, (int)voff, (int)soff, 0);
+    }
+}
+// lane part and row pitch of an array with leading dimension ld, in bytes
+template <typename T> struct LaneAddr {
+    uint32_t lb, pitch;
+    __device__ __forceinline__ void init(const TileCtx &t, int64_t ld) {
+        lb = (uint32_t)(((int64_t)t.cl + (int64_t)t.rl * ld) * (int64_t)sizeof(T));
+        pitch = (uint32_t)(ld * (int64_t)sizeof(T));
+    }
+    __device__ __forceinline__ uint32_t soff(int ro, int co) const { return (uint32_t)ro * pitch + (uint32_t)co * (uint32_t)sizeof(T); }
 };
 
 // XOR swizzle of the 16-byte chunk position inside a KCONTIG LDS row (8 chunks/row):
@@ -255,7 +291,7 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     __shared__ __attribute__((aligned(16))) T smem[2 * (BR + BC) * BK];
     constexpr int STAGE = (BR + BC) * BK;   // stage s: A tile at smem + s*STAGE, B tile right behind it
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
     const int wr = wave / WGC, wc = wave % WGC;
 
     // block -> (tile_r, tile_c, split).  Blocks are dealt round-robin to the 8 XCDs (block b runs
@@ -277,7 +313,8 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
     //               blocks in k and re-fetches W from the fabric for every tile row: 2.9 GB instead of 1.3 GB per launch).
     //               Tail piece p of a tail tile writes tail slab p (epilogue: begin(-1 - p)).
     const int nkt = g.kchunk / BK;
-    TileCtx tctx{0, 0, wr, wc, lane, tid, NT, (int)blockIdx.x, 0, 0};
+    TileCtx tctx{0, 0, wr, wc, lane, tid, NT, (int)blockIdx.x, 0, 0,
+                 (sizeof(T) == 4) ? 4 * (lane >> 5) : (lane >> 4), lane % MT, 0, 0};
     for (int phase = 0; phase < 2; ++phase) {
         int trem, split, kt0, nk;
         bool tail = false;
@@ -312,6 +349,13 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
             tc = sc * G + in % G;
         } else if (g.c_fastest) { tc = trem % g.tiles_c; tr = trem / g.tiles_c; }
         else                    { tr = trem % g.tiles_r; tc = trem / g.tiles_r; }
+        // integer divisions by run-time values are expanded on the vector unit: move the (wave-uniform) results back to
+        // SGPRs so that tile origins, operand base pointers, the k-loop trip count and all epilogue addresses stay scalar
+        tr = __builtin_amdgcn_readfirstlane(tr);
+        tc = __builtin_amdgcn_readfirstlane(tc);
+        split = __builtin_amdgcn_readfirstlane(split);
+        kt0 = __builtin_amdgcn_readfirstlane(kt0);
+        nk = __builtin_amdgcn_readfirstlane(nk);
         const int64_t r0 = (int64_t)tr * BR, c0 = (int64_t)tc * BC;
         const int64_t kbeg = (int64_t)kt0 * BK;
         const T *Ab = g.A, *Bb = g.B;
@@ -319,6 +363,7 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
         if (r0 >= g.r_split) { Ab = g.A2; lda = g.lda2; ra0 = r0 - g.r_split; }
         if (c0 >= g.c_split) { Bb = g.B2; ldb = g.ldb2; cb0 = c0 - g.c_split; }
         tctx.tr = tr; tctx.tc = tc; tctx.r0 = r0; tctx.c0 = c0;
+        tctx.rw0 = r0 + wr * WTR; tctx.cw0 = c0 + wc * WTC;
 
         typename M::acc_t acc[TR][TC];
     #pragma unroll
@@ -333,6 +378,24 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
         //   first half of the k-groups : registers -> LDS stage (t+1)&1   (ds_write interleaved with MFMAs)
         //   second half                : global   -> registers, tile t+2  (loads interleaved with MFMAs)
         // Stage (t+1)&1 was last read during tile t-1, i.e. before the barrier that ended iteration t-1.
+        // Epilogue inputs of the first row of MFMA tiles are requested BEFORE the main loop (epilogues that read
+        // memory: the X tile of the ratio / objective passes, numerator and old factor of the multiplicative update), so
+        // their HBM round trip runs under the MFMAs; the following rows are requested one row ahead of their use.
+        constexpr bool EARLY = Epi::EARLY && sizeof(T) == 4;
+        typename Epi::Pre pre[2][TC][M::NACC];
+        // MFMA C/D layout: f32 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
+        // f64 16x16: col = lane&15, row = (lane>>4) + 4*reg.  col <-> c (contiguous), row <-> r.
+        auto reg_row = [](int reg) { return (sizeof(T) == 4) ? ((reg & 3) + 8 * (reg >> 2)) : 4 * reg; };
+        epi.setup(split, tctx);
+        auto prefetch_row = [&](auto IC, auto SC) {
+            constexpr int i = decltype(IC)::value, set = decltype(SC)::value;
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+#pragma unroll
+                for (int reg = 0; reg < M::NACC; ++reg) pre[set][j][reg] = epi.prefetch(i * MT + reg_row(reg), j * MT);
+        };
+        if constexpr (EARLY) prefetch_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+
         typename M::vec_t ra[LoadA::PER_THREAD], rb[LoadB::PER_THREAD];
         LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, kbeg, tid, g.a_aux, xalpha);
         LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, kbeg, tid, g.b_aux, xalpha);
@@ -346,14 +409,16 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
         __syncthreads();
 
         constexpr int NG = BK / 8;   // k-groups per tile
-        // fragments of the FIRST k-group of a tile are fetched one k-group early (right after the barrier that
-        // publishes the tile, in front of the previous tile's last MFMAs), so the barrier is never followed by an
-        // exposed LDS round trip
-        T af0[TR][M::VEC], bf0[TC][M::VEC];
+        static_assert(NG % 2 == 0, "fragment double buffer assumes an even number of k-groups");
+        // Operand fragments are double-buffered in registers and fetched ONE k-group ahead: group kg's MFMAs run on set
+        // kg&1 while the ds_reads of group kg+1 (issued behind the first MFMA pair) fill the other set, so an LDS round
+        // trip (~130-200 cycles for four b128 reads) is covered by ~14 MFMAs instead of 2.  The first group of the next
+        // tile is fetched right behind the barrier that publishes it, in front of the last group's MFMAs.
+        T af[2][TR][M::VEC], bf[2][TC][M::VEC];
 #pragma unroll
-        for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af0[i], smem, wr * WTR + i * MT, 0, lane);
+        for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[0][i], smem, wr * WTR + i * MT, 0, lane);
 #pragma unroll
-        for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf0[j], smem + BR * BK, wc * WTC + j * MT, 0, lane);
+        for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[0][j], smem + BR * BK, wc * WTC + j * MT, 0, lane);
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
             const T *a_s = smem + cur * STAGE, *b_s = a_s + BR * BK;
@@ -363,24 +428,17 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
             static_for<NG>([&](auto KGC) {
                 constexpr int kg = decltype(KGC)::value;
                 constexpr bool last = (kg == NG - 1);
-                T af[TR][M::VEC], bf[TC][M::VEC];
-                if constexpr (kg == 0) {
-#pragma unroll
-                    for (int i = 0; i < TR; ++i)
-#pragma unroll
-                        for (int q = 0; q < M::VEC; ++q) af[i][q] = af0[i][q];
-#pragma unroll
-                    for (int j = 0; j < TC; ++j)
-#pragma unroll
-                        for (int q = 0; q < M::VEC; ++q) bf[j][q] = bf0[j][q];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[i], a_s, wr * WTR + i * MT, kg, lane);
-#pragma unroll
-                    for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[j], b_s, wc * WTC + j * MT, kg, lane);
-                }
+                constexpr int fc = kg & 1, fn = fc ^ 1;
                 constexpr bool stA = (kg == 0), stB = (kg == (NG > 2 ? 1 : 0));
+                // (issuing the global loads one k-group earlier, right behind their ds_write, measured no faster: the loads
+                // are not what the loop waits for)
                 constexpr bool ldA = (kg == NG / 2), ldB = (kg == (NG > 2 ? NG / 2 + 1 : NG / 2));
+                if constexpr (!last) {
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[fn][i], a_s, wr * WTR + i * MT, kg + 1, lane);
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[fn][j], b_s, wc * WTC + j * MT, kg + 1, lane);
+                }
                 if constexpr (stA) LoadA::store(ra, a_n, tid);
                 if constexpr (stB) LoadB::store(rb, b_n, tid);
                 if constexpr (last) {
@@ -388,9 +446,9 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
                     // then fetch its first fragments while the MFMAs below still run on tile t's registers
                     __syncthreads();
 #pragma unroll
-                    for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af0[i], a_n, wr * WTR + i * MT, 0, lane);
+                    for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[fn][i], a_n, wr * WTR + i * MT, 0, lane);
 #pragma unroll
-                    for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf0[j], b_n, wc * WTC + j * MT, 0, lane);
+                    for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[fn][j], b_n, wc * WTC + j * MT, 0, lane);
                 }
                 if constexpr (ldA) LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, kn, tid, g.a_aux, xalpha);
                 if constexpr (ldB) LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, kn, tid, g.b_aux, xalpha);
@@ -399,68 +457,59 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
 #pragma unroll
                     for (int i = 0; i < TR; ++i)
 #pragma unroll
-                        for (int j = 0; j < TC; ++j) acc[i][j] = M::mma(af[i][q], bf[j][q], acc[i][j]);
+                        for (int j = 0; j < TC; ++j) acc[i][j] = M::mma(af[fc][i][q], bf[fc][j][q], acc[i][j]);
                 // Issue-order template for this k-group (LLVM sched_group_barrier; masks: MFMA 0x8, VMEM read 0x20,
-                // DS read 0x100, DS write 0x200): fragment reads first, then the staging traffic of this group spread
-                // one instruction per MFMA pair, so neither the LDS writes nor the global loads open an MFMA-free window.
+                // DS read 0x100, DS write 0x200): one MFMA pair, the next group's fragment reads, then the staging traffic
+                // of this group spread one instruction per MFMA pair, so neither the LDS writes nor the global loads open
+                // an MFMA-free window.
                 constexpr int NMFMA = M::VEC * TR * TC;
                 constexpr int NFRAG = ((LA == KCONTIG || kstrided_micro<T, BR, NT>()) ? TR : TR * M::VEC) +
                                       ((LB == KCONTIG || kstrided_micro<T, BC, NT>()) ? TC : TC * M::VEC);
                 constexpr int NW0 = (stA ? LoadA::PER_THREAD : 0) + (stB ? LoadB::PER_THREAD : 0);
                 constexpr int NL0 = (ldA ? LoadA::PER_THREAD : 0) + (ldB ? LoadB::PER_THREAD : 0);
-                constexpr int NW = (2 * NW0 <= NMFMA) ? NW0 : NMFMA / 2;
-                constexpr int NL = (2 * (NW + NL0) <= NMFMA) ? NL0 : (NMFMA / 2 - NW);
-                if constexpr (kg != 0) __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
+                constexpr int LEAD = (last || 2 * (NW0 + NL0) + 2 > NMFMA) ? 0 : 2;
+                constexpr int ROOM = (NMFMA - LEAD) / 2;
+                constexpr int NW = (NW0 <= ROOM) ? NW0 : ROOM;
+                constexpr int NL = (NW + NL0 <= ROOM) ? NL0 : (ROOM - NW);
+                if constexpr (LEAD > 0) __builtin_amdgcn_sched_group_barrier(0x8, LEAD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
                 sched_pairs<0x200, NW>();
                 sched_pairs<0x20, NL>();
-                if constexpr (NMFMA - 2 * (NW + NL) > 0) __builtin_amdgcn_sched_group_barrier(0x8, NMFMA - 2 * (NW + NL), 0);
+                if constexpr (NMFMA - LEAD - 2 * (NW + NL) > 0)
+                    __builtin_amdgcn_sched_group_barrier(0x8, NMFMA - LEAD - 2 * (NW + NL), 0);
             });
         }
         __syncthreads();   // the staging buffers are re-used by the next segment / the epilogue reductions
 
-        // Epilogue.  MFMA C/D layout: f32 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
-        // f64 16x16: col = lane&15, row = (lane>>4) + 4*reg.  col <-> c (contiguous), row <-> r.
-        epi.begin(split, tctx);
+        // Epilogue.
+        epi.begin();
         // Two phases per ROW of MFMA tiles: issue every global load the epilogue needs for the row (prefetch), then
         // compute and store (apply).  (Inputs and outputs of an epilogue may alias as far as the compiler knows, so a
         // fused load-compute-store per element serialises one memory round trip per element.)  The scheduling barrier
         // after each row keeps the compiler from hoisting ALL rows' prefetches to the top: with f64 (16 tiles per
         // wave) that cost 250+ VGPRs and one wave per SIMD.
+        if constexpr (!EARLY) prefetch_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<TR>([&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            if constexpr (EARLY && i + 1 < TR)
+                prefetch_row(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
 #pragma unroll
-        for (int i = 0; i < TR; ++i) {
-            const int64_t rbase = r0 + wr * WTR + i * MT;
-            typename Epi::Pre pre[TC][M::NACC];
+            for (int j = 0; j < TC; ++j)
 #pragma unroll
-            for (int j = 0; j < TC; ++j) {
-                const int64_t c = c0 + wc * WTC + j * MT + (lane % MT);
-#pragma unroll
-                for (int reg = 0; reg < M::NACC; ++reg) {
-                    int64_t r;
-                    if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                    else r = rbase + (lane >> 4) + 4 * reg;
-                    pre[j][reg] = epi.prefetch(r, c);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TC; ++j) {
-                const int64_t c = c0 + wc * WTC + j * MT + (lane % MT);
-#pragma unroll
-                for (int reg = 0; reg < M::NACC; ++reg) {
-                    int64_t r;
-                    if constexpr (sizeof(T) == 4) r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                    else r = rbase + (lane >> 4) + 4 * reg;
-                    epi.apply(r, c, acc[i][j][reg], j, pre[j][reg]);
-                }
-            }
+                for (int reg = 0; reg < M::NACC; ++reg)
+                    epi.apply(i * MT + reg_row(reg), j * MT, acc[i][j][reg], j, pre[i & 1][j][reg]);
             __builtin_amdgcn_sched_barrier(0);
-        }
+            if constexpr (!EARLY && i + 1 < TR)
+                prefetch_row(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
+        });
     }
     epi.template finish<MT, TC, WGR, WGC>(reinterpret_cast<double *>(smem), tctx);
 }
 
 // ---------------------------------------------------------------------------
-// Epilogues: pre = prefetch(r, c) loads whatever the epilogue needs from memory for element (r, c);
-// apply(r, c, v, jt, pre) receives D(r, c) and stores.  The element lives at  base[c + r*ld].
+// Epilogues: setup(split, tile) once per output tile (descriptors, lane offsets); pre = prefetch(ro, co) loads whatever
+// the epilogue needs from memory for the element at (ro, co) relative to the wave tile origin (plus the lane part);
+// begin() after the main loop; apply(ro, co, v, jt, pre) receives D and stores.  Element (r, c) lives at base[c + r*ld].
 // ---------------------------------------------------------------------------
 
 // C (or split-K slab `split`) = acc.  Tail segments (split < 0, see the kernel's work decomposition) go to a second
@@ -471,14 +520,20 @@ template <typename T> struct EpiStore {
     T *dst;
     T *C2 = nullptr;
     int64_t ld2 = 0, stride2 = 0, r_off = 0, c_off = 0;
-    int64_t ldc;
+    rsrc_t rd;
+    LaneAddr<T> la;
     struct Pre {};
-    __device__ __forceinline__ void begin(int split, const TileCtx &) {
+    static constexpr bool EARLY = false;
+    __device__ __forceinline__ void setup(int split, const TileCtx &t) {
+        int64_t ldc;
         if (split >= 0) { dst = C + (int64_t)split * slab_stride; ldc = ld; }
         else { dst = C2 + (int64_t)(-1 - split) * stride2 - (c_off + r_off * ld2); ldc = ld2; }
+        rd = tile_rsrc(dst, ldc, t);
+        la.init(t, ldc);
     }
-    __device__ __forceinline__ Pre prefetch(int64_t, int64_t) const { return Pre{}; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &) { dst[c + r * ldc] = v; }
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ Pre prefetch(int, int) const { return Pre{}; }
+    __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &) { buf_st(rd, la.lb, la.soff(ro, co), v); }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
@@ -499,26 +554,39 @@ template <typename T, int STATS> struct EpiMultUpdate {
     double *stat_partial;
     int ncomp;
     double dev[STATS ? 8 : 1], sm[STATS ? 8 : 1];
-    __device__ __forceinline__ void begin(int, const TileCtx &) {
+    rsrc_t rnum, rold, rout;
+    LaneAddr<T> la;
+    int64_t tile_off;
+    __device__ __forceinline__ void setup(int, const TileCtx &t) {
+        rnum = tile_rsrc(num, ld, t);
+        rold = tile_rsrc(old, ld, t);
+        rout = tile_rsrc(out, ld, t);
+        tile_off = t.cw0 + t.rw0 * ld;
+        la.init(t, ld);
+    }
+    __device__ __forceinline__ void begin() {
         if constexpr (STATS != 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { dev[j] = 0.0; sm[j] = 0.0; }
         }
     }
     struct Pre { T nu, ov; };
-    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const {
-        const int64_t o = c + r * ld;
-        T nu = num[o];
-        for (int s = 1; s < nslab; ++s) nu += num[(int64_t)s * slab_stride + o];
-        return Pre{nu, old[o]};
+    static constexpr bool EARLY = true;   // prefetch() does not depend on begin()
+    __device__ __forceinline__ Pre prefetch(int ro, int co) const {
+        const uint32_t so = la.soff(ro, co);
+        T nu = buf_ld<T>(rnum, la.lb, so);
+        for (int s = 1; s < nslab; ++s) {
+            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(num + ((int64_t)s * slab_stride + tile_off)), 0, -1, 0x00020000);
+            nu += buf_ld<T>(rs, la.lb, so);
+        }
+        return Pre{nu, buf_ld<T>(rold, la.lb, so)};
     }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int jt, const Pre &pre) {
-        const int64_t o = c + r * ld;
+    __device__ __forceinline__ void apply(int ro, int co, T v, int jt, const Pre &pre) {
         T t = pre.nu - lambda;
         t = (t > (T)0) ? t : ((t != t) ? t : (T)0);   // max(zero(T), t); NaN propagates like Julia's max
         const T ov = pre.ov;
         const T nv = ov * (t / (v + delta));
-        out[o] = nv;
+        buf_st(rout, la.lb, la.soff(ro, co), nv);
         if constexpr (STATS != 0) {
             const T d = nv - ov, sp = nv + ov;
             dev[jt] += (double)(T)(d * d);
@@ -555,10 +623,16 @@ template <typename T, int STATS> struct EpiMultUpdate {
 template <typename T> struct EpiClampStore {
     T *out;
     int64_t ld;
-    __device__ __forceinline__ void begin(int, const TileCtx &) {}
+    rsrc_t rout;
+    LaneAddr<T> la;
+    __device__ __forceinline__ void setup(int, const TileCtx &t) { rout = tile_rsrc(out, ld, t); la.init(t, ld); }
+    __device__ __forceinline__ void begin() {}
     struct Pre {};
-    __device__ __forceinline__ Pre prefetch(int64_t, int64_t) const { return Pre{}; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &) { out[c + r * ld] = (v < (T)0) ? (T)0 : v; }
+    static constexpr bool EARLY = false;
+    __device__ __forceinline__ Pre prefetch(int, int) const { return Pre{}; }
+    __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &) {
+        buf_st(rout, la.lb, la.soff(ro, co), (v < (T)0) ? (T)0 : v);
+    }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
@@ -567,10 +641,14 @@ template <typename T> struct EpiSubStore {
     const T *sub;
     T *out;
     int64_t ld;
-    __device__ __forceinline__ void begin(int, const TileCtx &) {}
+    rsrc_t rsub, rout;
+    LaneAddr<T> la;
+    __device__ __forceinline__ void setup(int, const TileCtx &t) { rsub = tile_rsrc(sub, ld, t); rout = tile_rsrc(out, ld, t); la.init(t, ld); }
+    __device__ __forceinline__ void begin() {}
     struct Pre { T s; };
-    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const { return Pre{sub[c + r * ld]}; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &pre) { out[c + r * ld] = v - pre.s; }
+    static constexpr bool EARLY = true;
+    __device__ __forceinline__ Pre prefetch(int ro, int co) const { return Pre{buf_ld<T>(rsub, la.lb, la.soff(ro, co))}; }
+    __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &pre) { buf_st(rout, la.lb, la.soff(ro, co), v - pre.s); }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
@@ -580,10 +658,14 @@ template <typename T> struct EpiRatio {
     T *Q;
     int64_t ld;
     T delta;
-    __device__ __forceinline__ void begin(int, const TileCtx &) {}
+    rsrc_t rx, rq;
+    LaneAddr<T> la;
+    __device__ __forceinline__ void setup(int, const TileCtx &t) { rx = tile_rsrc(X, ld, t); rq = tile_rsrc(Q, ld, t); la.init(t, ld); }
+    __device__ __forceinline__ void begin() {}
     struct Pre { T x; };
-    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const { return Pre{X[c + r * ld]}; }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int /*jt*/, const Pre &pre) { Q[c + r * ld] = pre.x / (v + delta); }
+    static constexpr bool EARLY = true;
+    __device__ __forceinline__ Pre prefetch(int ro, int co) const { return Pre{buf_ld<T>(rx, la.lb, la.soff(ro, co))}; }
+    __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &pre) { buf_st(rq, la.lb, la.soff(ro, co), pre.x / (v + delta)); }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
@@ -612,10 +694,14 @@ template <typename T, int KL> struct EpiObjective {
     int64_t ld;
     double *partial;   // one per block
     double sum;
-    __device__ __forceinline__ void begin(int, const TileCtx &) { sum = 0.0; }
+    rsrc_t rx;
+    LaneAddr<T> la;
+    __device__ __forceinline__ void setup(int, const TileCtx &t) { rx = tile_rsrc(X, ld, t); la.init(t, ld); }
+    __device__ __forceinline__ void begin() { sum = 0.0; }
     struct Pre { T x; };
-    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const { return Pre{X[c + r * ld]}; }
-    __device__ __forceinline__ void apply(int64_t, int64_t, T v, int /*jt*/, const Pre &pre) {
+    static constexpr bool EARLY = true;
+    __device__ __forceinline__ Pre prefetch(int ro, int co) const { return Pre{buf_ld<T>(rx, la.lb, la.soff(ro, co))}; }
+    __device__ __forceinline__ void apply(int, int, T v, int /*jt*/, const Pre &pre) {
         const T x = pre.x;
         T t;
         if constexpr (KL == 0) {

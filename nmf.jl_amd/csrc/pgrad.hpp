@@ -47,14 +47,21 @@ template <typename T> struct EpiGradNorm {
     double *partial;   // one per block
     double sum;
     struct Pre { T b, z; };
-    __device__ __forceinline__ void begin(int, const TileCtx &) { sum = 0.0; }
-    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const {
-        const int64_t o = c + r * ld;
-        return Pre{B[o], Z[o]};
+    static constexpr bool EARLY = true;
+    rsrc_t rb, rz, rg;
+    LaneAddr<T> la;
+    __device__ __forceinline__ void setup(int, const TileCtx &t) {
+        rb = tile_rsrc(B, ld, t); rz = tile_rsrc(Z, ld, t); rg = tile_rsrc(G, ld, t);
+        la.init(t, ld);
     }
-    __device__ __forceinline__ void apply(int64_t r, int64_t c, T v, int, const Pre &pre) {
+    __device__ __forceinline__ void begin() { sum = 0.0; }
+    __device__ __forceinline__ Pre prefetch(int ro, int co) const {
+        const uint32_t so = la.soff(ro, co);
+        return Pre{buf_ld<T>(rb, la.lb, so), buf_ld<T>(rz, la.lb, so)};
+    }
+    __device__ __forceinline__ void apply(int ro, int co, T v, int, const Pre &pre) {
         const T g = v - pre.b;
-        G[c + r * ld] = g;
+        buf_st(rg, la.lb, la.soff(ro, co), g);
         if (g < (T)0 || pre.z > (T)0) sum += (double)(T)(g * g);
     }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *smem, const TileCtx &t) {
@@ -75,17 +82,21 @@ template <typename T> struct EpiPgStep {
     int zp_valid;
     double s1, s2, s3;
     struct Pre { T z, g; };
-    __device__ __forceinline__ void begin(int, const TileCtx &) {
+    static constexpr bool EARLY = true;
+    rsrc_t rz, rg;
+    LaneAddr<T> la;
+    __device__ __forceinline__ void setup(int, const TileCtx &t) { rz = tile_rsrc(Z, ld, t); rg = tile_rsrc(G, ld, t); la.init(t, ld); }
+    __device__ __forceinline__ void begin() {
         alpha = (T)st->alpha;
         alpha_prev = (T)st->alpha_prev;
         zp_valid = st->zp_valid;
         s1 = s2 = s3 = 0.0;
     }
-    __device__ __forceinline__ Pre prefetch(int64_t r, int64_t c) const {
-        const int64_t o = c + r * ld;
-        return Pre{Z[o], G[o]};
+    __device__ __forceinline__ Pre prefetch(int ro, int co) const {
+        const uint32_t so = la.soff(ro, co);
+        return Pre{buf_ld<T>(rz, la.lb, so), buf_ld<T>(rg, la.lb, so)};
     }
-    __device__ __forceinline__ void apply(int64_t, int64_t, T v, int, const Pre &pre) {
+    __device__ __forceinline__ void apply(int, int, T v, int, const Pre &pre) {
         const T zn = pg_trial(pre.z, pre.g, alpha);
         const T d = zn - pre.z;
         const T zprev = zp_valid ? pg_trial(pre.z, pre.g, alpha_prev) : pre.z;

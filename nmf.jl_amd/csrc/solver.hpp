@@ -103,6 +103,10 @@ template <typename T> class Solver : public SolverBase {
         P = round_up(p, 256);
         N = round_up(n, 256);
         K = (k <= 64) ? 64 : round_up(k, 128);
+        // the fused epilogues address a wave tile with 32-bit byte offsets (gemm_mfma.hpp, "Epilogue addressing"):
+        // 256 rows x leading dimension must stay below 4 GiB.  Leading dimensions are P (W, X, Q) and K (H, Gram).
+        if ((uint64_t)std::max(P, K) * sizeof(T) * 256 >= (1ull << 32))
+            throw StatusError{NMFX_ERR_UNSUPPORTED, "p (or k) too large: 256 * leading dimension * sizeof(T) must be < 2^32"};
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
@@ -359,7 +363,12 @@ template <typename T> class Solver : public SolverBase {
         // them half-size tiles so >= 2 blocks per CU are resident and one block's epilogue overlaps another's MFMAs.
         const bool small_k = (Kdim <= 1024) && splits == 1 && seg.tail_tiles == 0 && ((R / 128) * (C / 128) < 2 * (int64_t)num_cu);
         timed(name, flops, bytes, [&] {
-            if (small_k && R % 64 == 0 && C % 128 == 0 && R >= C) {
+            if (small_k && R % 64 == 0 && C % 64 == 0 && std::max(R / 64 * (C / 128), R / 128 * (C / 64)) < 2 * (int64_t)num_cu) {
+                // even the half-size tiles leave CUs idle (e.g. the 4096 x 512 projected-gradient products of a C5 shard:
+                // 256 blocks): quarter-size tiles, 4 waves of 32 x 32
+                g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 64);
+                launch_gemm_cfg<LA, LB, 64, 64, 2, 2, AUX>(g, epi);
+            } else if (small_k && R % 64 == 0 && C % 128 == 0 && R >= C) {
                 g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 128);
                 launch_gemm_cfg<LA, LB, 64, 128, 1, 4, AUX>(g, epi);
             } else if (small_k && R % 128 == 0 && C % 64 == 0 && C > R) {
@@ -440,7 +449,7 @@ template <typename T> class Solver : public SolverBase {
             gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                    (double)(P * N + 2 * P * K) * sizeof(T), sg, 2.0 * K * K * P);
             reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
-            if (!keep_slabs || h_nslab > 4) {
+            if (!keep_slabs || h_nslab > 2) {
                 reduce_slabs_from("reduce_WtX", numH_p, reg, h_stride, h_nslab, done);
                 h_in_slabs = false;
             } else {
@@ -452,7 +461,7 @@ template <typename T> class Solver : public SolverBase {
         EpiStore<T> e{reg, K, h_stride, nullptr};
         gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                (double)(P * N + P * K) * sizeof(T));
-        if (!keep_slabs || h_nslab > 4) {
+        if (!keep_slabs || h_nslab > 2) {
             reduce_slabs_from("reduce_WtX", numH_p, reg, h_stride, h_nslab, done);
             h_in_slabs = false;
         } else {
@@ -489,7 +498,7 @@ template <typename T> class Solver : public SolverBase {
             gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                      (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
             reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
-            if (!keep_slabs || w_nslab > 4) {
+            if (!keep_slabs || w_nslab > 2) {
                 reduce_slabs_from("reduce_XHt", numW_p, reg, w_stride, w_nslab, done);
                 w_in_slabs = false;
             } else {
@@ -501,7 +510,7 @@ template <typename T> class Solver : public SolverBase {
         EpiStore<T> e{reg, P, w_stride, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                  (double)(P * N + K * N) * sizeof(T));
-        if (!keep_slabs || w_nslab > 4) {
+        if (!keep_slabs || w_nslab > 2) {
             reduce_slabs_from("reduce_XHt", numW_p, reg, w_stride, w_nslab, done);
             w_in_slabs = false;
         } else {

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "nmf.jl_amd"))
 import numpy as np
 import nmfx
 
-def run(p, n, k, T, alg_name, iters=10, maxsub=200):
+def run(p, n, k, T, alg_name, iters=10, maxsub=200, comm=False):
     rng = np.random.default_rng(0)
     t0 = time.time()
     Wg = rng.random((p, k), dtype=np.float32); Hg = rng.random((k, n), dtype=np.float32)
@@ -18,6 +18,8 @@ def run(p, n, k, T, alg_name, iters=10, maxsub=200):
     algs = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3}
     with nmfx.Context(T, p, n, k) as ctx:
         t0 = time.time(); ctx.set_X(X); print(f"upload X {time.time()-t0:.2f}s", flush=True)
+        if comm:
+            ctx.comm_init(nmfx.api.comm_unique_id(), 0, 1)   # 1-rank RCCL communicator: exercises the sharded code path
         ctx.set_factors(W0, H0)
         lam = {"multdiv": 3.5e-4, "projals": 0.5}.get(alg_name, 0.0)
         o = nmfx.make_opts(T, maxiter=3, tol=1e-30, check_every=1000, lambda_w=lam, lambda_h=lam, maxsubiter=maxsub)
@@ -46,4 +48,6 @@ if __name__ == "__main__":
     if "c3f64" in which: run(8192, 8192, 256, np.float64, "multmse", 5)
     if "c4shard" in which: run(16384, 16384, 256, np.float32, "projals", 5)
     if "c5shard" in which: run(8192, 4096, 512, np.float64, "alspgrad", 2, maxsub=10)
+    if "shards" in which:      # per-rank shapes of the C3 problem at 2/4/8 GPUs (local compute + 1-rank all-reduce)
+        for nl in (8192, 4096, 2048): run(16384, nl, 256, np.float32, "multmse", 30, comm=True)
     if "alsf32" in which: run(4096, 4096, 64, np.float32, "alspgrad", 2, maxsub=20)

@@ -216,7 +216,7 @@ template <typename T> class Solver : public SolverBase {
         profiling = mode;
         records.clear();
         ev_used = 0;
-        prof_tick = 0;
+        prof_seen.clear();
     }
 
     int profile_get(nmfx_kernel_stat *out, int max_entries) override {
@@ -291,7 +291,7 @@ template <typename T> class Solver : public SolverBase {
     // profiling (hipEvent pair per launch, resolved lazily)
     struct Rec { const char *name; int ev; double flops, bytes; };
     int profiling = 0;
-    long long prof_tick = 0;
+    std::map<std::string, long long> prof_seen;   // mode 2: launches seen per GEMM name
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<Rec> records;
     int ev_used = 0;
@@ -313,7 +313,8 @@ template <typename T> class Solver : public SolverBase {
 
     template <typename F> void timed(const char *name, double flops, double bytes, F &&launch) {
         if (!profiling) { launch(); return; }
-        if (profiling == 2 && (flops < 1e10 || (((prof_tick++) >> 1) & 3) != 0)) { launch(); return; }   // two big GEMMs per iteration: sample both, every 4th iteration
+        // mode 2: only the GEMMs that carry the iteration's flops (>= 1 GFLOP per launch), every 4th launch of each
+        if (profiling == 2 && (flops < 1e9 || ((prof_seen[name]++) & 3) != 0)) { launch(); return; }
         if (ev_used == (int)ev_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));

@@ -1,0 +1,11 @@
+#!/bin/bash
+# One bench.py line per BASELINE.json config (single-GPU form: C4 / C5 as the per-GPU shard of the 8-GPU problem).
+# usage (on the GPU box): bash scripts/bench_configs.sh > gpurun_out/bench_configs.jsonl
+set +e
+cd "$(dirname "$0")/.."
+python bench.py --no-cpu-baseline --p 4096 --n 4096 --k 64 --steps 200 --warmup 50                       # C2
+python bench.py                                                                                           # C3 multmse (headline)
+python bench.py --no-cpu-baseline --alg multdiv --steps 30 --warmup 10                                    # C3 multdiv
+python bench.py --no-cpu-baseline --alg projals --steps 30 --warmup 10                                    # C4 per-GPU shard (16384 x 16384)
+python bench.py --no-cpu-baseline --alg alspgrad --dtype f64 --p 32768 --n 4096 --k 512 --steps 4 --warmup 1 --maxsubiter 10   # C5 per-GPU shard
+python bench.py --no-cpu-baseline --dtype f64 --p 8192 --n 8192 --k 256 --steps 30 --warmup 10            # f64 multmse

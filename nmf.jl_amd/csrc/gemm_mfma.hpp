@@ -275,7 +275,9 @@ template <int MASK, int N> __device__ __forceinline__ void sched_pairs() {
 
 // AUX: 0 plain operands; 1 / 2: operand A / B is the projected-gradient trial step computed in the loader.
 template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi, int AUX = 0>
-__global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g, Epi epi) {
+// half-size and smaller tiles ask for >= 2 waves per SIMD (they exist to overlap one block's prologue / epilogue with another
+// block's MFMAs); without the hint the fused f64 epilogues land a few registers above the 256-register budget of two waves
+__global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void gemm_mfma_kernel(GemmArgs<T> g, Epi epi) {
     using M = Mfma<T>;
     constexpr int NT = WGR * WGC * 64;
     constexpr int BK = M::BK, MT = M::MT;
@@ -414,11 +416,15 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
         // kg&1 while the ds_reads of group kg+1 (issued behind the first MFMA pair) fill the other set, so an LDS round
         // trip (~130-200 cycles for four b128 reads) is covered by ~14 MFMAs instead of 2.  The first group of the next
         // tile is fetched right behind the barrier that publishes it, in front of the last group's MFMAs.
+        // f64 (FDB = false) keeps ONE set plus the carried first-group set: its wave tile needs 2-3x the fragment registers
+        // (16x16 MFMA tiles) and the second set cost the fused f64 kernels a wave per SIMD for no measurable gain; there
+        // group kg > 0 reads its own fragments at the start of the group (set 0) and group 0 runs on the carried set 1.
+        constexpr bool FDB = (sizeof(T) == 4);
         T af[2][TR][M::VEC], bf[2][TC][M::VEC];
 #pragma unroll
-        for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[0][i], smem, wr * WTR + i * MT, 0, lane);
+        for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[FDB ? 0 : 1][i], smem, wr * WTR + i * MT, 0, lane);
 #pragma unroll
-        for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[0][j], smem + BR * BK, wc * WTC + j * MT, 0, lane);
+        for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[FDB ? 0 : 1][j], smem + BR * BK, wc * WTC + j * MT, 0, lane);
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
             const T *a_s = smem + cur * STAGE, *b_s = a_s + BR * BK;
@@ -428,16 +434,23 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
             static_for<NG>([&](auto KGC) {
                 constexpr int kg = decltype(KGC)::value;
                 constexpr bool last = (kg == NG - 1);
-                constexpr int fc = kg & 1, fn = fc ^ 1;
+                constexpr int fc = FDB ? (kg & 1) : (kg == 0 ? 1 : 0);   // set the MFMAs of this group read
+                constexpr int fn = FDB ? (fc ^ 1) : 1;                    // set the next group's / next tile's first fragments go to
                 constexpr bool stA = (kg == 0), stB = (kg == (NG > 2 ? 1 : 0));
                 // (issuing the global loads one k-group earlier, right behind their ds_write, measured no faster: the loads
                 // are not what the loop waits for)
                 constexpr bool ldA = (kg == NG / 2), ldB = (kg == (NG > 2 ? NG / 2 + 1 : NG / 2));
-                if constexpr (!last) {
+                if constexpr (FDB && !last) {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[fn][i], a_s, wr * WTR + i * MT, kg + 1, lane);
 #pragma unroll
                     for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[fn][j], b_s, wc * WTC + j * MT, kg + 1, lane);
+                }
+                if constexpr (!FDB && kg != 0) {
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[0][i], a_s, wr * WTR + i * MT, kg, lane);
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[0][j], b_s, wc * WTC + j * MT, kg, lane);
                 }
                 if constexpr (stA) LoadA::store(ra, a_n, tid);
                 if constexpr (stB) LoadB::store(rb, b_n, tid);
@@ -467,12 +480,12 @@ __global__ __launch_bounds__(WGR *WGC * 64) void gemm_mfma_kernel(GemmArgs<T> g,
                                       ((LB == KCONTIG || kstrided_micro<T, BC, NT>()) ? TC : TC * M::VEC);
                 constexpr int NW0 = (stA ? LoadA::PER_THREAD : 0) + (stB ? LoadB::PER_THREAD : 0);
                 constexpr int NL0 = (ldA ? LoadA::PER_THREAD : 0) + (ldB ? LoadB::PER_THREAD : 0);
-                constexpr int LEAD = (last || 2 * (NW0 + NL0) + 2 > NMFMA) ? 0 : 2;
+                constexpr int LEAD = (!FDB || last || 2 * (NW0 + NL0) + 2 > NMFMA) ? 0 : 2;
                 constexpr int ROOM = (NMFMA - LEAD) / 2;
                 constexpr int NW = (NW0 <= ROOM) ? NW0 : ROOM;
                 constexpr int NL = (NW + NL0 <= ROOM) ? NL0 : (ROOM - NW);
                 if constexpr (LEAD > 0) __builtin_amdgcn_sched_group_barrier(0x8, LEAD, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
+                if constexpr (FDB || kg != 0) __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
                 sched_pairs<0x200, NW>();
                 sched_pairs<0x20, NL>();
                 if constexpr (NMFMA - LEAD - 2 * (NW + NL) > 0)
@@ -523,7 +536,7 @@ template <typename T> struct EpiStore {
     rsrc_t rd;
     LaneAddr<T> la;
     struct Pre {};
-    static constexpr bool EARLY = false;
+    static constexpr bool EARLY = false, HEAVY = false;
     __device__ __forceinline__ void setup(int split, const TileCtx &t) {
         int64_t ldc;
         if (split >= 0) { dst = C + (int64_t)split * slab_stride; ldc = ld; }
@@ -572,6 +585,7 @@ template <typename T, int STATS> struct EpiMultUpdate {
     }
     struct Pre { T nu, ov; };
     static constexpr bool EARLY = true;   // prefetch() does not depend on begin()
+    static constexpr bool HEAVY = true;   // 128 x 128 tiles leave one wave per SIMD: always run on half-size tiles
     __device__ __forceinline__ Pre prefetch(int ro, int co) const {
         const uint32_t so = la.soff(ro, co);
         T nu = buf_ld<T>(rnum, la.lb, so);
@@ -628,7 +642,7 @@ template <typename T> struct EpiClampStore {
     __device__ __forceinline__ void setup(int, const TileCtx &t) { rout = tile_rsrc(out, ld, t); la.init(t, ld); }
     __device__ __forceinline__ void begin() {}
     struct Pre {};
-    static constexpr bool EARLY = false;
+    static constexpr bool EARLY = false, HEAVY = false;
     __device__ __forceinline__ Pre prefetch(int, int) const { return Pre{}; }
     __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &) {
         buf_st(rout, la.lb, la.soff(ro, co), (v < (T)0) ? (T)0 : v);
@@ -646,7 +660,7 @@ template <typename T> struct EpiSubStore {
     __device__ __forceinline__ void setup(int, const TileCtx &t) { rsub = tile_rsrc(sub, ld, t); rout = tile_rsrc(out, ld, t); la.init(t, ld); }
     __device__ __forceinline__ void begin() {}
     struct Pre { T s; };
-    static constexpr bool EARLY = true;
+    static constexpr bool EARLY = true, HEAVY = false;
     __device__ __forceinline__ Pre prefetch(int ro, int co) const { return Pre{buf_ld<T>(rsub, la.lb, la.soff(ro, co))}; }
     __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &pre) { buf_st(rout, la.lb, la.soff(ro, co), v - pre.s); }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
@@ -663,7 +677,7 @@ template <typename T> struct EpiRatio {
     __device__ __forceinline__ void setup(int, const TileCtx &t) { rx = tile_rsrc(X, ld, t); rq = tile_rsrc(Q, ld, t); la.init(t, ld); }
     __device__ __forceinline__ void begin() {}
     struct Pre { T x; };
-    static constexpr bool EARLY = true;
+    static constexpr bool EARLY = true, HEAVY = false;
     __device__ __forceinline__ Pre prefetch(int ro, int co) const { return Pre{buf_ld<T>(rx, la.lb, la.soff(ro, co))}; }
     __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &pre) { buf_st(rq, la.lb, la.soff(ro, co), pre.x / (v + delta)); }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
@@ -699,7 +713,7 @@ template <typename T, int KL> struct EpiObjective {
     __device__ __forceinline__ void setup(int, const TileCtx &t) { rx = tile_rsrc(X, ld, t); la.init(t, ld); }
     __device__ __forceinline__ void begin() { sum = 0.0; }
     struct Pre { T x; };
-    static constexpr bool EARLY = true;
+    static constexpr bool EARLY = true, HEAVY = false;
     __device__ __forceinline__ Pre prefetch(int ro, int co) const { return Pre{buf_ld<T>(rx, la.lb, la.soff(ro, co))}; }
     __device__ __forceinline__ void apply(int, int, T v, int /*jt*/, const Pre &pre) {
         const T x = pre.x;

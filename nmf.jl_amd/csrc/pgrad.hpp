@@ -47,7 +47,7 @@ template <typename T> struct EpiGradNorm {
     double *partial;   // one per block
     double sum;
     struct Pre { T b, z; };
-    static constexpr bool EARLY = true;
+    static constexpr bool EARLY = true, HEAVY = true;
     rsrc_t rb, rz, rg;
     LaneAddr<T> la;
     __device__ __forceinline__ void setup(int, const TileCtx &t) {
@@ -82,7 +82,7 @@ template <typename T> struct EpiPgStep {
     int zp_valid;
     double s1, s2, s3;
     struct Pre { T z, g; };
-    static constexpr bool EARLY = true;
+    static constexpr bool EARLY = true, HEAVY = true;
     rsrc_t rz, rg;
     LaneAddr<T> la;
     __device__ __forceinline__ void setup(int, const TileCtx &t) { rz = tile_rsrc(Z, ld, t); rg = tile_rsrc(G, ld, t); la.init(t, ld); }

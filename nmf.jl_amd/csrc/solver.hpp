@@ -15,6 +15,7 @@
 #include <limits>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/nmfx.h"
@@ -362,7 +363,12 @@ template <typename T> class Solver : public SolverBase {
         auto note = [&] { last_tiles_r = g.tiles_r; last_blocks = g.tiles_r * g.tiles_c * g.splits; };
         // Short contractions (the k x k Gram products: 8 k-tiles) are dominated by prologue/epilogue latency; give
         // them half-size tiles so >= 2 blocks per CU are resident and one block's epilogue overlaps another's MFMAs.
-        const bool small_k = (Kdim <= 1024) && splits == 1 && seg.tail_tiles == 0 && ((R / 128) * (C / 128) < 2 * (int64_t)num_cu);
+        // Epilogues whose 128 x 128 instantiation is left at ONE wave per SIMD always run on half-size tiles (2-3 waves):
+        // f64 with anything but a plain store (128 accumulator registers per lane), and the update / gradient / line-search
+        // epilogues in f32 (Epi::HEAVY; see scripts/kernel_regs.py).
+        constexpr bool prefer_half = ((sizeof(T) == 8) && !std::is_same<Epi, EpiStore<T>>::value) || Epi::HEAVY;
+        const bool small_k = (Kdim <= 1024) && splits == 1 && seg.tail_tiles == 0 &&
+                             (prefer_half || (R / 128) * (C / 128) < 2 * (int64_t)num_cu);
         timed(name, flops, bytes, [&] {
             if (small_k && R % 64 == 0 && C % 64 == 0 && std::max(R / 64 * (C / 128), R / 128 * (C / 64)) < 2 * (int64_t)num_cu) {
                 // even the half-size tiles leave CUs idle (e.g. the 4096 x 512 projected-gradient products of a C5 shard:

@@ -48,6 +48,7 @@ if __name__ == "__main__":
     if "c3f64" in which: run(8192, 8192, 256, np.float64, "multmse", 5)
     if "c4shard" in which: run(16384, 16384, 256, np.float32, "projals", 5)
     if "c5shard" in which: run(8192, 4096, 512, np.float64, "alspgrad", 2, maxsub=10)
+    if "c5full" in which: run(32768, 4096, 512, np.float64, "alspgrad", 2, maxsub=10)
     if "shards" in which:      # per-rank shapes of the C3 problem at 2/4/8 GPUs (local compute + 1-rank all-reduce)
         for nl in (8192, 4096, 2048): run(16384, nl, 256, np.float32, "multmse", 30, comm=True)
     if "alsf32" in which: run(4096, 4096, 64, np.float32, "alspgrad", 2, maxsub=20)

@@ -126,6 +126,23 @@ int nmfx_solve(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, void *W_host, void
 int nmfx_alspgrad_subsolve(nmfx_ctx *ctx, int which, const nmfx_opts *opts, void *W_host, void *H_host,
                            nmfx_result *out);
 
+/* ---- nnmf() front end on the device: the parts of nnmf that touch the big arrays, done
+ * next to the resident X so that `replicates` restarts never re-upload it -------------------------------------------
+ *   nmfx_check_nonneg     all(t -> t >= zero(T), A) for A = X (which 0), W (1), H (2): the ArgumentError checks of
+ *                         src/interf.jl:15, 28, 31 (NaN counts as a violation, as in the reference)
+ *   nmfx_randinit         randinit(X, k; normalize, zeroh), src/initialization.jl:4-17: W = rand(T,p,k) with columns
+ *                         scaled to sum 1 when normalize, H = rand(T,k,n) or zeros.  Julia's RNG stream cannot be
+ *                         reproduced outside Julia; the generator is Philox4x32-10 keyed by `seed`, one call per element,
+ *                         counter = the element's global column-major index (H columns offset by h_col_offset, the first
+ *                         global column of this context's shard), so a sharded run draws the same global matrices.
+ *   nmfx_solve_replicates solve_replicates!, src/interf.jl:85-101: replicate 1 solves from the given W, H; replicates
+ *                         2..R from randinit(seed + r - 1, normalize = 1, zeroh); the result with the strictly smallest
+ *                         objvalue wins and is returned in W, H / *out; *best_replicate (nullable) = its 1-based index. */
+int nmfx_check_nonneg(nmfx_ctx *ctx, int which, int *all_nonneg);
+int nmfx_randinit(nmfx_ctx *ctx, uint64_t seed, int normalize, int zeroh, int64_t h_col_offset);
+int nmfx_solve_replicates(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, int replicates, uint64_t seed, int zeroh,
+                          int64_t h_col_offset, void *W_host, void *H_host, nmfx_result *out, int *best_replicate);
+
 /* ---- multi-GPU (column sharding, one process per GPU) -----------------------
  * The reference has no distributed path; this is the build's data-parallel extension.
  * Rank r owns columns [c0, c0+n_local) of X and H; W is replicated.  Per outer iteration

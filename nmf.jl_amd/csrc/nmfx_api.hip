@@ -8,6 +8,7 @@
 #include "solver_impl.hpp"
 #include "projals_impl.hpp"
 #include "alspgrad_impl.hpp"
+#include "frontend_impl.hpp"
 
 using namespace nmfx;
 
@@ -137,6 +138,24 @@ int nmfx_comm_init(nmfx_ctx *ctx, const void *unique_id_bytes, int rank, int nra
 int nmfx_objective(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, double *out) {
     if (!ctx || !opts || !out) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { *out = ctx->impl->objective(alg, *opts); });
+}
+
+int nmfx_check_nonneg(nmfx_ctx *ctx, int which, int *all_nonneg) {
+    if (!ctx || !all_nonneg) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { *all_nonneg = ctx->impl->check_nonneg(which) ? 1 : 0; });
+}
+
+int nmfx_randinit(nmfx_ctx *ctx, uint64_t seed, int normalize, int zeroh, int64_t h_col_offset) {
+    if (!ctx || h_col_offset < 0) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->randinit(seed, normalize != 0, zeroh != 0, h_col_offset); });
+}
+
+int nmfx_solve_replicates(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, int replicates, uint64_t seed, int zeroh,
+                          int64_t h_col_offset, void *W_host, void *H_host, nmfx_result *out, int *best_replicate) {
+    if (!ctx || !opts || !out || !W_host || !H_host || h_col_offset < 0) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        ctx->impl->solve_replicates(alg, *opts, replicates, seed, zeroh != 0, h_col_offset, W_host, H_host, out, best_replicate);
+    });
 }
 
 int nmfx_profile_enable(nmfx_ctx *ctx, int on) {

@@ -65,6 +65,10 @@ struct SolverBase {
     virtual void subsolve(int which, const nmfx_opts &o, nmfx_result *out) = 0;
     virtual void comm_init(const void *uid, int rank, int nranks) = 0;
     virtual double objective(int alg, const nmfx_opts &o) = 0;
+    virtual bool check_nonneg(int which) = 0;
+    virtual void randinit(uint64_t seed, bool normalize, bool zeroh, int64_t h_col_offset) = 0;
+    virtual void solve_replicates(int alg, const nmfx_opts &o, int replicates, uint64_t seed, bool zeroh, int64_t h_col_offset,
+                                  void *W_host, void *H_host, nmfx_result *out, int *best) = 0;
     virtual void profile_enable(int mode) = 0;
     virtual int profile_get(nmfx_kernel_stat *out, int max_entries) = 0;
 };
@@ -252,6 +256,11 @@ template <typename T> class Solver : public SolverBase {
     // ---------------------------------------------------------------- the loop
     void iterate(int alg, const nmfx_opts &o, nmfx_result *out, double *trace) override;
     void subsolve(int which, const nmfx_opts &o, nmfx_result *out) override;
+    // nnmf front end on the device (frontend_impl.hpp)
+    bool check_nonneg(int which) override;
+    void randinit(uint64_t seed, bool normalize, bool zeroh, int64_t h_col_offset) override;
+    void solve_replicates(int alg, const nmfx_opts &o, int replicates, uint64_t seed, bool zeroh, int64_t h_col_offset, void *W_host,
+                          void *H_host, nmfx_result *out, int *best) override;
     double objective(int alg, const nmfx_opts &o) override {
         require_ready();
         HIP_TRY(hipSetDevice(device));
@@ -273,6 +282,8 @@ template <typename T> class Solver : public SolverBase {
     DevBuf<T> work[8];   // algorithm-specific scratch (projals factor/inverse, alspgrad G/Zn/Zp/D/GD)
     DevBuf<double> stat_part, wstat, hstat, obj_part, obj_extra, obj_final, trace_dev;
     Ctrl *ctrl = nullptr, *ctrl_host = nullptr;
+    DevBuf<T> Wbest, Hbest;   // solve_replicates: the best replicate's factors
+    DevBuf<int> flagbuf;
     int wcur = 0, hcur = 0;
     int s_h = 1, s_w = 1, s_gw = 1, s_gh = 1;
     int stat_chunks_w = 1, stat_chunks_h = 1;

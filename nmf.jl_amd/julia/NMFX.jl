@@ -125,4 +125,29 @@ function solve!(alg::Union{NMF.MultUpdate{T},NMF.ProjectedALS{T},NMF.ALSPGrad{T}
     end
 end
 
+# ---- nnmf front end on the device (include/nmfx.h; src/interf.jl:15,28,31,85-101; src/initialization.jl:4-17) ----------
+# all(t -> t >= zero(T), A) for the resident X (which = 0), W (1), H (2)
+function check_nonneg(ctx::Context, which::Integer)
+    ok = Ref{Cint}(0)
+    check(ccall((:nmfx_check_nonneg, libnmfx), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}), ctx.h, which, ok), ctx.h)
+    ok[] != 0
+end
+
+# randinit(X, k; normalize, zeroh) into the resident W, H (Philox4x32-10 keyed by `seed`; Julia's own stream is not used)
+randinit!(ctx::Context, seed::Integer; normalize::Bool=false, zeroh::Bool=false, h_col_offset::Integer=0) =
+    check(ccall((:nmfx_randinit, libnmfx), Cint, (Ptr{Cvoid}, UInt64, Cint, Cint, Int64),
+                ctx.h, seed, normalize, zeroh, h_col_offset), ctx.h)
+
+# solve_replicates!(alginst, X, W, H; replicates, initH): X stays on the device, only the winner comes back
+function solve_replicates!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, H::Matrix{T};
+                           replicates::Integer, initH::Bool, seed::Integer) where T
+    res = Ref(CResult(0, 0, 0, 0.0, 0.0, 0, 0, 0.0))
+    best = Ref{Cint}(0)
+    st = ccall((:nmfx_solve_replicates, libnmfx), Cint,
+               (Ptr{Cvoid}, Cint, Ref{COpts}, Cint, UInt64, Cint, Int64, Ptr{T}, Ptr{T}, Ref{CResult}, Ref{Cint}),
+               ctx.h, alg, o, replicates, seed, !initH, 0, W, H, res, best)
+    check(st, ctx.h)
+    NMF.Result{T}(W, H, Int(res[].niters), res[].converged != 0, T(res[].objvalue))
+end
+
 end # module

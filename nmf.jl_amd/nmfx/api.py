@@ -253,6 +253,24 @@ class Context:
         self._ck(self.lib.nmfx_objective(self.h, alg, C.byref(opts), C.byref(out)))
         return out.value
 
+    # ---- nnmf front end on the device (include/nmfx.h)
+    def check_nonneg(self, which=0) -> bool:
+        """all(t -> t >= zero(T), A) for A = X (0), W (1), H (2) (src/interf.jl:15, 28, 31)."""
+        out = C.c_int32()
+        self._ck(self.lib.nmfx_check_nonneg(self.h, which, C.byref(out)))
+        return bool(out.value)
+
+    def randinit(self, seed, normalize=False, zeroh=False, h_col_offset=0):
+        """randinit(X, k; normalize, zeroh) (src/initialization.jl:4-17) into the resident W, H (Philox4x32-10)."""
+        self._ck(self.lib.nmfx_randinit(self.h, seed, int(normalize), int(zeroh), h_col_offset))
+
+    def solve_replicates(self, alg, opts: L.Opts, replicates, seed, zeroh, W, H, h_col_offset=0):
+        """solve_replicates! (src/interf.jl:85-101); W, H are the replicate-1 start and receive the winner."""
+        res, best = L.CResult(), C.c_int32()
+        self._ck(self.lib.nmfx_solve_replicates(self.h, alg, C.byref(opts), replicates, seed, int(zeroh), h_col_offset,
+                                                W.ctypes.data, H.ctypes.data, C.byref(res), C.byref(best)))
+        return res, best.value
+
     def comm_init(self, uid: bytes, rank: int, nranks: int):
         buf = C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)
         self._ck(self.lib.nmfx_comm_init(self.h, buf, rank, nranks))
@@ -343,13 +361,19 @@ _ALGS = ("multmse", "multdiv", "projals", "alspgrad")
 
 
 def nnmf(X, k, init="random", alg="multmse", maxiter=100, tol=None, replicates=1, W0=None, H0=None,
-         update_H=True, verbose=False, rng=None, track_objective=False):
+         update_H=True, verbose=False, rng=None, track_objective=False, seed=None):
     """nnmf(X, k; ...) (src/interf.jl:3-83) for the accelerated algorithms.
 
     Scope (SURVEY.md section 8): alg in {multmse, multdiv, projals, alspgrad}, init in {random, custom};
     the other algorithms / initialisers stay in Julia (the reference's defaults :greedycd / :nndsvdar are
-    outside the accelerated path and raise ArgumentError here)."""
+    outside the accelerated path and raise ArgumentError here).
+
+    seed=None: random draws come from `rng` (NumPy) on the host.  seed=int: the device front end is used instead --
+    X is uploaded first and checked for negatives there, init=:random and the replicate restarts are drawn by
+    nmfx_randinit (Philox4x32-10) next to the resident X, and only the winning replicate's factors come back."""
     T = X.dtype.type
+    if seed is not None:
+        return _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, verbose, int(seed))
     if not (np.issubdtype(X.dtype, np.floating) and np.all(X >= 0)):
         raise ArgumentError("The elements of X must be non-negative.")
     p, n = X.shape
@@ -411,3 +435,69 @@ def nnmf(X, k, init="random", alg="multmse", maxiter=100, tol=None, replicates=1
         for t, v in enumerate(ret.trace):
             print(f"{t:5d}    {v:13.6e}" + ("" if t == 0 else f"    {v - ret.trace[t - 1]:13.6e}"))
     return ret
+
+
+def _alg_instance(T, alg, maxiter, tol, verbose, update_H):
+    if alg == "projals":
+        return ProjectedALS(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    if alg == "alspgrad":
+        return ALSPGrad(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    if alg == "multmse":
+        return MultUpdate(T, obj="mse", maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    if alg == "multdiv":
+        return MultUpdate(T, obj="div", maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    if alg in ("cd", "greedycd", "spa"):
+        raise ArgumentError(f"alg=:{alg} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
+    raise ArgumentError("Invalid algorithm.")
+
+
+def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, verbose, seed):
+    """nnmf with the front end on the device: same checks, same order, same messages as src/interf.jl:15-101."""
+    T = X.dtype.type
+    if not np.issubdtype(X.dtype, np.floating):
+        raise ArgumentError("The elements of X must be non-negative.")
+    p, n = X.shape
+    if not k <= min(p, n):
+        raise ArgumentError("The value of k should not exceed min(size(X)).")
+    if not replicates >= 1:
+        raise ArgumentError("The value of replicates must be positive.")
+    if not update_H and init != "custom":
+        warnings.warn("Only W will be updated.")
+    tol = float(np.cbrt(_eps(T) / 100)) if tol is None else tol
+    if init == "custom":
+        if W0 is None or H0 is None:
+            raise ArgumentError("To use :custom initialization, set W0 and H0.")
+        if W0.shape != (p, k):
+            raise ArgumentError("Invalid size for W0.")
+        if H0.shape != (k, n):
+            raise ArgumentError("Invalid size for H0.")
+    elif init in ("nndsvd", "nndsvda", "nndsvdar", "spa"):
+        raise ArgumentError(f"init=:{init} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
+    elif init != "random":
+        raise ArgumentError("Invalid value for init.")
+    elif W0 is not None or H0 is not None:
+        warnings.warn("Ignore W0 and H0 except for :custom initialization.")
+    initH = alg != "projals"
+    inst = _alg_instance(T, alg, maxiter, tol, verbose, update_H)
+    with Context(T, p, n, k) as ctx:
+        ctx.set_X(np.asfortranarray(X))
+        if not ctx.check_nonneg(0):
+            raise ArgumentError("The elements of X must be non-negative.")
+        if init == "custom":
+            W = np.asfortranarray(W0, dtype=T).copy(order="F")
+            H = np.asfortranarray(H0, dtype=T).copy(order="F")
+            ctx.set_factors(W, H)
+            if not ctx.check_nonneg(1):
+                raise ArgumentError("The elements of W0 must be non-negative.")
+            if not ctx.check_nonneg(2):
+                raise ArgumentError("The elements of H0 must be non-negative.")
+        else:
+            W = np.empty((p, k), dtype=T, order="F")
+            H = np.empty((k, n), dtype=T, order="F")
+            ctx.randinit(seed, normalize=True, zeroh=not initH)
+            ctx.get_factors(W, H)
+        opts = make_opts(T, **inst._opts())
+        res, best = ctx.solve_replicates(inst._alg(), opts, replicates, seed, not initH, W, H)
+    out = _result(T, W, H, res, None)
+    out.info["best_replicate"] = best
+    return out

@@ -1,0 +1,136 @@
+"""nnmf front end on the device: non-negativity checks (src/interf.jl:15,28,31), randinit
+(src/initialization.jl:4-17) and solve_replicates! (src/interf.jl:85-101)."""
+import numpy as np
+import pytest
+
+import philox_ref
+from problems import uniform
+
+
+def test_philox_known_answers():
+    # Random123 known-answer vectors for philox4x32-10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox_ref.philox4x32_10(*[np.array([c]) for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+
+
+def test_twin_statistics_and_sharding():
+    W, H = philox_ref.randinit(np.float64, 50, 40, 7, seed=5, normalize=True)
+    assert W.min() >= 0 and H.min() >= 0 and H.max() < 1
+    np.testing.assert_allclose(W.sum(axis=0), 1.0, rtol=1e-14)
+    assert abs(H.mean() - 0.5) < 0.05
+    # a column shard draws the same numbers as the corresponding slice of the global H
+    _, Hs = philox_ref.randinit(np.float64, 50, 15, 7, seed=5, h_col_offset=25)
+    np.testing.assert_array_equal(Hs, H[:, 25:40])
+    _, Hz = philox_ref.randinit(np.float32, 50, 40, 7, seed=5, zeroh=True)
+    assert not Hz.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(37, 53, 5), (300, 129, 64), (257, 700, 130)])
+def test_randinit_matches_twin(built, T, shape):
+    import nmfx
+    p, n, k = shape
+    with nmfx.Context(T, p, n, k) as ctx:
+        for normalize, zeroh, off in [(False, False, 0), (True, False, 11), (True, True, 0)]:
+            ctx.randinit(1234, normalize=normalize, zeroh=zeroh, h_col_offset=off)
+            W = np.empty((p, k), dtype=T, order="F"); H = np.empty((k, n), dtype=T, order="F")
+            ctx.get_factors(W, H)
+            Wr, Hr = philox_ref.randinit(T, p, n, k, 1234, normalize=normalize, zeroh=zeroh, h_col_offset=off)
+            np.testing.assert_array_equal(H, Hr)               # bit-exact: same integer stream, same conversion
+            if normalize:
+                np.testing.assert_allclose(W, Wr, rtol=4 * np.finfo(T).eps)   # column sums: different summation order
+                np.testing.assert_allclose(W.sum(axis=0, dtype=np.float64), 1.0, rtol=64 * np.finfo(T).eps)
+            else:
+                np.testing.assert_array_equal(W, Wr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_check_nonneg(built, T):
+    import nmfx
+    p, n, k = 130, 70, 9
+    X, W0, H0 = uniform(p, n, k, T, seed=3)
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X); ctx.set_factors(W0, H0)
+        assert ctx.check_nonneg(0) and ctx.check_nonneg(1) and ctx.check_nonneg(2)
+        Xn = X.copy(order="F"); Xn[p - 1, n - 1] = -1e-30
+        ctx.set_X(Xn)
+        assert not ctx.check_nonneg(0)
+        Xn[p - 1, n - 1] = np.nan                                # all(t -> t >= 0) is false for NaN too
+        ctx.set_X(Xn)
+        assert not ctx.check_nonneg(0)
+        Xz = X.copy(order="F"); Xz[0, 0] = 0.0; Xz[5, 5] = -0.0   # -0.0 >= 0 holds
+        ctx.set_X(Xz)
+        assert ctx.check_nonneg(0)
+        Hn = H0.copy(order="F"); Hn[k - 1, 0] = -1.0
+        ctx.set_factors(W0, Hn)
+        assert ctx.check_nonneg(1) and not ctx.check_nonneg(2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg,T", [("multmse", np.float32), ("multdiv", np.float64), ("projals", np.float64), ("alspgrad", np.float64)])
+def test_solve_replicates_is_min_over_restarts(built, alg, T):
+    """solve_replicates! = replicate 1 from the given start, 2..R from randinit(seed + r - 1); strictly smaller objective wins."""
+    import nmfx
+    p, n, k, R, seed = 60, 90, 4, 4, 77
+    X, W0, H0 = uniform(p, n, k, T, seed=21)
+    W0 = np.asfortranarray(W0 / W0.sum(axis=0, keepdims=True))
+    zeroh = alg == "projals"
+    if alg in ("multmse", "multdiv"):
+        inst = nmfx.MultUpdate(T, obj=alg[4:], maxiter=15, tol=1e-12)
+    elif alg == "projals":
+        inst = nmfx.ProjectedALS(T, maxiter=15, tol=1e-12)
+    else:
+        inst = nmfx.ALSPGrad(T, maxiter=6, tol=1e-12, maxsubiter=20)
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        runs = []
+        for r in range(1, R + 1):
+            if r == 1:
+                W, H = W0.copy(order="F"), H0.copy(order="F")
+            else:
+                ctx.randinit(seed + r - 1, normalize=True, zeroh=zeroh)
+                W = np.empty((p, k), dtype=T, order="F"); H = np.empty((k, n), dtype=T, order="F")
+                ctx.get_factors(W, H)
+            res = ctx.solve(inst._alg(), nmfx.make_opts(T, **inst._opts()), W, H)[0]
+            runs.append((res.objvalue, W, H, res.niters))
+        best = 0
+        for r in range(1, R):
+            if runs[best][0] > runs[r][0]:
+                best = r
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        res, bi = ctx.solve_replicates(inst._alg(), nmfx.make_opts(T, **inst._opts()), R, seed, zeroh, W, H)
+        assert bi == best + 1
+        assert res.objvalue == runs[best][0] and res.niters == runs[best][3]
+        np.testing.assert_array_equal(W, runs[best][1])
+        np.testing.assert_array_equal(H, runs[best][2])
+        assert len({round(r[0], 12) for r in runs}) > 1          # the restarts really differ
+
+
+@pytest.mark.gpu
+def test_nnmf_device_front_end(built):
+    import nmfx
+    T = np.float64
+    X, _, _ = uniform(48, 64, 3, T, seed=9)
+    r1 = nmfx.nnmf(X, 3, init="random", alg="multmse", maxiter=40, replicates=3, seed=11)
+    r2 = nmfx.nnmf(X, 3, init="random", alg="multmse", maxiter=40, replicates=3, seed=11)
+    assert r1.objvalue == r2.objvalue and np.array_equal(r1.W, r2.W)            # reproducible from the seed
+    assert 1 <= r1.info["best_replicate"] <= 3
+    single = nmfx.nnmf(X, 3, init="random", alg="multmse", maxiter=40, replicates=1, seed=11)
+    assert r1.objvalue <= single.objvalue
+    assert (r1.W >= 0).all() and (r1.H >= 0).all()
+    np.testing.assert_allclose(0.5 * np.sum((X - r1.W @ r1.H) ** 2), r1.objvalue, rtol=1e-10)
+    Xn = X.copy(); Xn[3, 4] = -0.5
+    with pytest.raises(nmfx.ArgumentError, match="elements of X must be non-negative"):
+        nmfx.nnmf(Xn, 3, init="random", alg="multmse", seed=1)
+    W0 = np.abs(np.random.default_rng(0).random((48, 3))); H0 = np.random.default_rng(1).random((3, 64)); H0[1, 1] = -1
+    with pytest.raises(nmfx.ArgumentError, match="elements of H0 must be non-negative"):
+        nmfx.nnmf(X, 3, init="custom", alg="multmse", W0=W0, H0=H0, seed=1)
+    # projals starts from H = 0 (src/interf.jl:39): the front end must not draw H
+    rp = nmfx.nnmf(X, 3, init="random", alg="projals", maxiter=10, seed=5)
+    assert np.isfinite(rp.objvalue)

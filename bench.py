@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--p", type=int, default=16384)
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--k", type=int, default=256)
-    ap.add_argument("--alg", default="multmse", choices=["multmse", "multdiv", "projals", "alspgrad"])
+    ap.add_argument("--alg", default="multmse", choices=["multmse", "multdiv", "projals", "alspgrad", "cd", "greedycd"])
     ap.add_argument("--maxsubiter", type=int, default=10, help="alspgrad: inner iteration cap per sub-solve (reference default 200)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -108,7 +108,7 @@ def main():
     Xt, W0, H0 = synth(p, n, k, c0, c1, tdtype, device, normalize_w0=(a.alg != "projals"))
     torch.cuda.synchronize()
 
-    algid = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3}[a.alg]
+    algid = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3, "cd": 4, "greedycd": 5}[a.alg]
     ctx = nmfx.Context(T, p, nl, k, device=local_rank)
     ctx.set_X_device(Xt.data_ptr(), p)
     if world > 1:
@@ -148,7 +148,9 @@ def main():
 
     if rank == 0:
         ms = dt / a.steps * 1e3
-        if a.alg == "multmse":
+        if a.alg in ("multmse", "cd", "greedycd"):
+            # cd / greedycd: the same two big GEMMs and Grams; the row sweeps add 2k^2(p+n) (cd) or a data-dependent
+            # number of greedy steps (reported below), both priced like the multmse update products
             f_alg = 4.0 * p * n * k + 4.0 * k * k * (p + n)
         elif a.alg == "multdiv":
             f_alg = 8.0 * p * n * k
@@ -199,6 +201,8 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline and a.alg == "multmse":
             out["cpu_baseline"] = cpu_baseline(p, n, k, T, Xt, W0, H0, a.cpu_sample_cols)
+        if a.alg == "greedycd":
+            out["greedy_steps_per_step"] = res.inner_iters / a.steps
         if a.alg == "alspgrad":
             out["config"]["maxsubiter"] = a.maxsubiter
             out["inner_iters_per_step"] = res.inner_iters / a.steps

@@ -33,8 +33,10 @@ enum { NMFX_F32 = 0, NMFX_F64 = 1 };
  *   MultUpdate{T}(obj=:mse)  src/multupd.jl:9-52   (nnmf alg=:multmse, src/interf.jl:65-66)
  *   MultUpdate{T}(obj=:div)  src/multupd.jl:9-52   (alg=:multdiv,  src/interf.jl:67-68)
  *   ProjectedALS{T}          src/projals.jl:18-39  (alg=:projals,  src/interf.jl:61-62)
- *   ALSPGrad{T}              src/alspgrad.jl:352-383 (alg=:alspgrad, src/interf.jl:63-64) */
-enum { NMFX_ALG_MULTMSE = 0, NMFX_ALG_MULTDIV = 1, NMFX_ALG_PROJALS = 2, NMFX_ALG_ALSPGRAD = 3 };
+ *   ALSPGrad{T}              src/alspgrad.jl:352-383 (alg=:alspgrad, src/interf.jl:63-64)
+ *   CoordinateDescent{T}     src/coorddesc.jl:23-51  (alg=:cd,       src/interf.jl:69-70)   -- SURVEY.md section 8f rank 2
+ *   GreedyCD{T}              src/greedycd.jl:10-35   (alg=:greedycd, src/interf.jl:71-72; nnmf's default) */
+enum { NMFX_ALG_MULTMSE = 0, NMFX_ALG_MULTDIV = 1, NMFX_ALG_PROJALS = 2, NMFX_ALG_ALSPGRAD = 3, NMFX_ALG_CD = 4, NMFX_ALG_GREEDYCD = 5 };
 
 /* status codes; the host shim maps them to the reference's exceptions:
  *   BAD_ARG       -> ArgumentError       (src/multupd.jl:27-31, src/interf.jl:15-33)
@@ -75,6 +77,11 @@ typedef struct {
     double delta;
     double tolg;              /* initial ALSPGradUpd.tolg (decays *0.1, src/alspgrad.jl:409-421) */
     double beta, sigma;
+    /* CoordinateDescentUpd's resolved regularisation (src/coorddesc.jl:62-82): l1 = alpha*l1ratio, l2 = alpha*(1-l1ratio)
+     * for W (regularization in {:both, :transformation}) and H ({:both, :components}); GreedyCD uses lambda_w / lambda_h
+     * as its L1 coefficients (src/greedycd.jl:15-16).  shuffle=true (a Julia-RNG permutation of the components) is not
+     * offered: the sweep always runs in component order. */
+    double l1_w, l2_w, l1_h, l2_h;
 } nmfx_opts;
 
 /* NMF.Result{T} minus the matrices (src/common.jl:21-27), plus measurement fields */
@@ -84,7 +91,7 @@ typedef struct {
     int32_t status;           /* nmfx_status of the solve (NOT_POSDEF / ALPHA_NONFINITE raised on device) */
     double objvalue;          /* Result.objvalue, already rounded to T (src/common.jl:33) */
     double seconds_loop;      /* device time of the iteration loop (hipEvent), excludes H2D/D2H */
-    int64_t inner_iters;      /* alspgrad: executed sub-solver iterations (H and W sides) */
+    int64_t inner_iters;      /* alspgrad: executed sub-solver iterations (H and W sides); greedycd: executed greedy steps */
     int64_t backtracks;       /* alspgrad: executed back-tracking steps */
     double final_tolg;        /* alspgrad: tolg after decay */
 } nmfx_result;

@@ -1,0 +1,281 @@
+// cd.hpp -- row-parallel kernels of the two coordinate-descent updaters:
+//   CoordinateDescent  _update_coord_descent!   src/coorddesc.jl:107-158
+//   GreedyCD           _update_GreedyCD!        src/greedycd.jl:91-163
+// Both updaters first form the k x k Gram P and the numerator Z with the big GEMMs (shared with the other algorithms) and
+// then run a sequential-in-the-components sweep over every sample row -- and the rows are INDEPENDENT: row i only reads
+// P, Z(i, :) and its own W(i, :).  One wavefront owns one sample row (CD: a few rows, to share the Gram-row loads); the
+// k components live in registers, component r on lane r % 64 slot r / 64; dot products over the components are
+// butterfly reductions (fixed order, so results do not depend on the launch).
+//
+// "Sample-major view": the updaters are written for W (p x k, element (i, t) at W[i + t*ld]) and are re-used for H through
+// the transposed views Ht, X' (coorddesc.jl:168-172, greedycd.jl:170-174): element (j, t) of Ht is H[t + j*ld].  A view is
+// (pointer, sample stride, component stride).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace nmfx {
+
+template <typename T> struct SampleView {
+    T *p;
+    int64_t ss, cs;   // sample stride, component stride
+    __device__ __forceinline__ T &at(int64_t i, int64_t t) const { return p[i * ss + t * cs]; }
+};
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_xor(v, off, 64);
+        v = (o > v) ? o : v;
+    }
+    return v;
+}
+
+// exactly-rounded single operations (no fused multiply-add contraction): the greedy sweep restates the reference's
+// expressions operation by operation
+__device__ __forceinline__ float op_mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double op_mul(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float op_add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double op_add(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ float op_sub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ double op_sub(double a, double b) { return __dsub_rn(a, b); }
+
+// ---------------------------------------------------------------------------
+// CoordinateDescent sweep (src/coorddesc.jl:130-156).  For every sample row i, components t = 1..k in order:
+//     grad = -Z'(i,t) + sum_r P(t,r) W(i,r)          Z' = Z - l1 (:121-123), P already carries + l2 on its diagonal (:118-120)
+//     hess = P(t,t);  if hess != 0:  W(i,t) = max(W(i,t) - grad/hess, 0)
+// (The reference loops t outer / i inner; rows do not interact, so i outer / t inner gives the same W.  The scalar
+// `violation` it accumulates is stored in the state but never read -- nmf_skeleton! stops on stop_condition -- and is not
+// computed here.)  A wave owns R rows; the dot product is a 64-lane butterfly instead of the reference's left-to-right sum.
+// ---------------------------------------------------------------------------
+template <typename T, int KMAX, int R>
+__global__ __launch_bounds__(256) void cd_sweep_kernel(SampleView<const T> Wold, SampleView<T> Wnew, SampleView<const T> Z,
+                                                       const T *__restrict__ P, int64_t ldp, int64_t nsamples, int k, T l1,
+                                                       const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+    if (i0 >= nsamples) return;
+    const int km = (k + 63) / 64;
+    T w[R][KMAX], z[R][KMAX];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) {
+            const int c = lane + 64 * m;
+            const bool ok = (m < km) && (c < k) && (i0 + r < nsamples);
+            w[r][m] = ok ? Wold.at(i0 + r, c) : (T)0;
+            z[r][m] = ok ? (T)(Z.at(i0 + r, c) - l1) : (T)0;
+        }
+#pragma unroll
+    for (int m0 = 0; m0 < KMAX; ++m0) {
+        if (m0 < km) {
+            const int tend = (k - 64 * m0 < 64) ? (k - 64 * m0) : 64;
+            for (int tl = 0; tl < tend; ++tl) {
+                const int t = 64 * m0 + tl;
+                T a[KMAX];
+#pragma unroll
+                for (int m = 0; m < KMAX; ++m) a[m] = (m < km && lane + 64 * m < k) ? P[(int64_t)t * ldp + lane + 64 * m] : (T)0;
+                const T hess = __shfl(a[m0], tl, 64);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    T part = (T)0;
+#pragma unroll
+                    for (int m = 0; m < KMAX; ++m) part += a[m] * w[r][m];
+                    const T grad = wave_sum(part) - __shfl(z[r][m0], tl, 64);
+                    const T wt = __shfl(w[r][m0], tl, 64);
+                    T nw = wt - grad / hess;
+                    nw = (nw > (T)0) ? nw : ((nw != nw) ? nw : (T)0);      // max(., zero(grad)); NaN propagates
+                    if (hess != (T)0 && lane == tl) w[r][m0] = nw;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) {
+            const int c = lane + 64 * m;
+            if ((m < km) && (c < k) && (i0 + r < nsamples)) Wnew.at(i0 + r, c) = w[r][m];
+        }
+}
+
+// ---------------------------------------------------------------------------
+// GreedyCD (src/greedycd.jl:91-163).  Per sample row i (registers: W, G, S, D rows):
+//     S(r) = max(0, W(r) - G(r)/(eps + P(r,r))) - W(r);   D(r) = -G(r) S(r) - 0.5 P(r,r) S(r)^2        (:120-125, :150-153)
+//     q = argmax_r D(r)  (first index on ties, like Julia's argmax)
+// p_init = max over ALL rows of D(i, q_i), floor -1 (:127-132)   -> greedy_pinit_kernel + one tiny reduction
+// then at most k^2 steps per row (:137-158): stop when D(q) < nu * p_init;  Wnew(q) += S(q);  G(r) += S(q) P(q, r);
+// recompute S, D;  q = argmax.   Finally W = max(W + Wnew, 0) (:160-161).
+// G arrives as W*P - Z from the GEMM; + lambda (:113-115) is applied on load.
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void greedy_sd(T w, T g, T prr, T epsT, T &s, T &d) {
+    T t = op_sub(w, g / op_add(epsT, prr));
+    t = (t > (T)0) ? t : ((t != t) ? t : (T)0);
+    s = op_sub(t, w);
+    d = op_sub(op_mul(-g, s), op_mul(op_mul((T)0.5, prr), op_mul(s, s)));
+}
+
+// (value, index) arg-max over the wave with first-index tie break; invalid slots carry index INT_MAX and value -inf
+template <typename T> __device__ __forceinline__ void wave_argmax(T &v, int &idx) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(idx, off, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+template <typename T, int KMAX> struct GreedyRow {
+    T w[KMAX], g[KMAX], s[KMAX], d[KMAX], prr[KMAX];
+    __device__ __forceinline__ void load(const SampleView<const T> &W, const SampleView<const T> &G, const T *P, int64_t ldp,
+                                         int64_t i, int k, int km, int lane, T lambda, T epsT) {
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) {
+            const int c = lane + 64 * m;
+            const bool ok = (m < km) && (c < k);
+            w[m] = ok ? W.at(i, c) : (T)0;
+            g[m] = ok ? G.at(i, c) : (T)0;
+            if (ok && lambda > (T)0) g[m] = op_add(g[m], lambda);
+            prr[m] = ok ? P[(int64_t)c * ldp + c] : (T)1;
+            greedy_sd(w[m], g[m], prr[m], epsT, s[m], d[m]);
+        }
+    }
+    __device__ __forceinline__ void argmax(int k, int km, int lane, T &best, int &q) const {
+        best = -INFINITY;
+        q = 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) {
+            const int c = lane + 64 * m;
+            if ((m < km) && (c < k) && (d[m] > best)) { best = d[m]; q = c; }   // ascending c per lane: first index wins locally
+        }
+        wave_argmax(best, q);
+    }
+};
+
+// per-block maxima of D(i, q_i)  ->  part[blockIdx.x]
+template <typename T, int KMAX>
+__global__ __launch_bounds__(256) void greedy_pinit_kernel(SampleView<const T> W, SampleView<const T> G, const T *__restrict__ P,
+                                                           int64_t ldp, int64_t nsamples, int k, T lambda, T epsT, T *part,
+                                                           const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ T sm[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int km = (k + 63) / 64;
+    T best = (T)-1;   // p_init = convert(T, -1.0)
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i < nsamples) {
+        GreedyRow<T, KMAX> row;
+        row.load(W, G, P, ldp, i, k, km, lane, lambda, epsT);
+        T v; int q;
+        row.argmax(k, km, lane, v, q);
+        best = (v > best) ? v : best;
+    }
+    if (lane == 0) sm[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T b = sm[0];
+        for (int wv = 1; wv < 4; ++wv) b = (sm[wv] > b) ? sm[wv] : b;
+        part[blockIdx.x] = b;
+    }
+}
+
+// pinit[0] = max(part[0..n))  (one block)
+template <typename T> __global__ void greedy_pinit_reduce_kernel(const T *part, int n, T *pinit, const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ T sm[4];
+    T b = (T)-1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) b = (part[i] > b) ? part[i] : b;
+    b = wave_max(b);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) b = (sm[wv] > b) ? sm[wv] : b;
+        pinit[0] = b;
+    }
+}
+
+template <typename T, int KMAX>
+__global__ __launch_bounds__(256) void greedy_sweep_kernel(SampleView<const T> Wold, SampleView<T> Wout, SampleView<const T> G,
+                                                           const T *__restrict__ P, int64_t ldp, int64_t nsamples, int k, T lambda,
+                                                           T epsT, const T *pinit, long long *steps_total, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= nsamples) return;
+    const int km = (k + 63) / 64;
+    GreedyRow<T, KMAX> row;
+    row.load(Wold, G, P, ldp, i, k, km, lane, lambda, epsT);
+    T wnew[KMAX];
+#pragma unroll
+    for (int m = 0; m < KMAX; ++m) wnew[m] = (T)0;
+    const T thresh = op_mul((T)0.001, pinit[0]);   // nu * p_init
+    T dq; int q;
+    row.argmax(k, km, lane, dq, q);
+    const long long max_steps = (long long)k * k;
+    long long step = 0;
+    for (; step < max_steps; ++step) {
+        if (dq < thresh) break;
+        // S(q): owned by lane q % 64, slot q / 64
+        const int ql = q & 63, qm = q >> 6;
+        T sq_owner = (T)0;
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) if (m == qm) sq_owner = row.s[m];
+        const T sq = __shfl(sq_owner, ql, 64);
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) {
+            const int c = lane + 64 * m;
+            const bool ok = (m < km) && (c < k);
+            if (m == qm && lane == ql) wnew[m] = op_add(wnew[m], sq);
+            if (ok) {
+                const T pq = P[(int64_t)q * ldp + c];
+                row.g[m] = op_add(row.g[m], op_mul(sq, pq));
+                greedy_sd(row.w[m], row.g[m], row.prr[m], epsT, row.s[m], row.d[m]);
+            }
+        }
+        row.argmax(k, km, lane, dq, q);
+    }
+    if (steps_total != nullptr && lane == 0 && step > 0) atomicAdd((unsigned long long *)steps_total, (unsigned long long)step);
+#pragma unroll
+    for (int m = 0; m < KMAX; ++m) {
+        const int c = lane + 64 * m;
+        if ((m < km) && (c < k)) {
+            T v = op_add(row.w[m], wnew[m]);
+            v = (v < (T)0) ? (T)0 : v;      // projectnn!
+            Wout.at(i, c) = v;
+        }
+    }
+}
+
+// sum_i |x_i| partials (norm(W, 1), greedycd.jl:81-86): Float64 accumulation, one partial per block
+template <typename T> __global__ void sumabs_kernel(const T *x, int64_t count, double *partial, const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const T v = x[i];
+        s += (double)(v < (T)0 ? -v : v);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// extra[slot] = T(lambda * T(sum partial))   (GreedyCD's L1 regulariser terms, greedycd.jl:81-86)
+template <typename T>
+__global__ void finish_sumabs_kernel(const double *partial, int n, T lambda, double *extra, int slot, const int *done) {
+    NMFX_DONE_GUARD(done);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    extra[slot] = (double)(T)(lambda * (T)s);
+}
+
+}  // namespace nmfx

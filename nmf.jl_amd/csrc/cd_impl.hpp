@@ -1,0 +1,129 @@
+// cd_impl.hpp -- kernel sequences of CoordinateDescent (src/coorddesc.jl:160-181) and GreedyCD (src/greedycd.jl:165-177).
+// Both update W FIRST (from the current H), then H (from the new W) -- the opposite order of the other updaters.
+//   W side:  [X;H] H'  -> Z = XH' (p x k), P = HH' (k x k)   one fused GEMM launch (+ the packed all-reduce when sharded)
+//   H side:  [X;W]' W  -> Z = (W'X) viewed as X'W (n x k),   P = W'W
+// then the row-parallel sweep of cd.hpp over the samples (rows of W / columns of H).
+#pragma once
+#include "cd.hpp"
+#include "solver.hpp"
+
+namespace nmfx {
+
+template <typename T> template <typename F> void Solver<T>::with_kmax(F &&f) {
+    if (k <= 64) f(std::integral_constant<int, 1>{});
+    else if (k <= 128) f(std::integral_constant<int, 2>{});
+    else if (k <= 256) f(std::integral_constant<int, 4>{});
+    else if (k <= 512) f(std::integral_constant<int, 8>{});
+    else if (k <= 1024) f(std::integral_constant<int, 16>{});
+    else throw StatusError{NMFX_ERR_UNSUPPORTED, "cd / greedycd: k > 1024 is not supported (components of a sample row live in registers)"};
+}
+
+// ---------------------------------------------------------------------------
+// CoordinateDescent
+// ---------------------------------------------------------------------------
+template <typename T> void Solver<T>::enqueue_cd(const nmfx_opts &o, long long t) {
+    (void)t;
+    const int *done = done_flag();
+    {   // ---- W (coorddesc.jl:166): HHt = H*Ht, XHt = X*Ht (:109-115)
+        const T *Hp = H[hcur].p;
+        const T *Wo = W[wcur].p;
+        T *Wn = W[wcur ^ 1].p;
+        times_ht(X.p, Hp, true, done);
+        allreduce_w_side(false, done);
+        if (o.l2_w > 0)   // :118-120
+            hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, gramH_p, K, (int)k, (T)o.l2_w, done);
+        timed("cd_sweep_W", 2.0 * p * k * k, 3.0 * P * K * sizeof(T), [&] {
+            with_kmax([&](auto KM) {
+                constexpr int KMAX = decltype(KM)::value, R = (KMAX <= 4) ? 4 : 2;
+                const unsigned blocks = (unsigned)((p + 4 * R - 1) / (4 * R));
+                hipLaunchKernelGGL((cd_sweep_kernel<T, KMAX, R>), dim3(blocks), dim3(256), 0, stream, SampleView<const T>{Wo, 1, P},
+                                   SampleView<T>{Wn, 1, P}, SampleView<const T>{numW_p, 1, P}, gramH_p, K, p, (int)k, (T)o.l1_w, done);
+            });
+            HIP_TRY(hipGetLastError());
+        });
+        stats_w(Wn, Wo, done);
+        wcur ^= 1;
+    }
+    if (o.update_H) {   // ---- H (:169-174) through the transposed views
+        const T *Wp = W[wcur].p;
+        const T *Ho = H[hcur].p;
+        T *Hn = H[hcur ^ 1].p;
+        wt_times(Wp, X.p, true, done);
+        if (o.l2_h > 0)
+            hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, gramW_p, K, (int)k, (T)o.l2_h, done);
+        timed("cd_sweep_H", 2.0 * n * k * k, 3.0 * K * N * sizeof(T), [&] {
+            with_kmax([&](auto KM) {
+                constexpr int KMAX = decltype(KM)::value, R = (KMAX <= 4) ? 4 : 2;
+                const unsigned blocks = (unsigned)((n + 4 * R - 1) / (4 * R));
+                hipLaunchKernelGGL((cd_sweep_kernel<T, KMAX, R>), dim3(blocks), dim3(256), 0, stream, SampleView<const T>{Ho, K, 1},
+                                   SampleView<T>{Hn, K, 1}, SampleView<const T>{numH_p, K, 1}, gramW_p, K, n, (int)k, (T)o.l1_h, done);
+            });
+            HIP_TRY(hipGetLastError());
+        });
+        stats_h(Hn, Ho, done);
+        allreduce_hstat(done);
+        hcur ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GreedyCD
+// ---------------------------------------------------------------------------
+template <typename T>
+void Solver<T>::greedy_side(const char *tag, SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> G, const T *Pm, int64_t nsamples,
+                            T lambda, bool sharded_samples, const int *done) {
+    const T epsT = std::numeric_limits<T>::epsilon();
+    const unsigned blocks = (unsigned)((nsamples + 3) / 4);
+    work[3].ensure((size_t)blocks + 8);
+    T *part = work[3].p, *pinit = work[3].p + blocks;
+    timed(tag, 0.0, 4.0 * (double)nsamples * K * sizeof(T), [&] {
+        with_kmax([&](auto KM) {
+            constexpr int KMAX = decltype(KM)::value;
+            hipLaunchKernelGGL((greedy_pinit_kernel<T, KMAX>), dim3(blocks), dim3(256), 0, stream, Zo, G, Pm, K, nsamples, (int)k, lambda,
+                               epsT, part, done);
+            hipLaunchKernelGGL(greedy_pinit_reduce_kernel<T>, dim3(1), dim3(256), 0, stream, part, (int)blocks, pinit, done);
+            if (sharded_samples && nranks > 1)   // p_init is the maximum over ALL samples (greedycd.jl:127-132)
+                RCCL_TRY(ncclAllReduce(pinit, pinit, 1, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclMax, comm, stream));
+            hipLaunchKernelGGL((greedy_sweep_kernel<T, KMAX>), dim3(blocks), dim3(256), 0, stream, Zo, Zn, G, Pm, K, nsamples, (int)k,
+                               lambda, epsT, pinit, &ctrl->inner_iters, done);
+        });
+        HIP_TRY(hipGetLastError());
+    });
+}
+
+template <typename T> void Solver<T>::enqueue_greedycd(const nmfx_opts &o, long long t) {
+    (void)t;
+    const int *done = done_flag();
+    {   // ---- W (greedycd.jl:168): P = Ht'Ht, Z = X*Ht, G = W*P - Z (:108-112)
+        const T *Hp = H[hcur].p;
+        const T *Wo = W[wcur].p;
+        T *Wn = W[wcur ^ 1].p;
+        times_ht(X.p, Hp, true, done);
+        allreduce_w_side(false, done);
+        work[0].ensure((size_t)std::max(P * K, K * N));
+        T *G = work[0].p;
+        EpiSubStore<T> e{numW_p, G, P};
+        gemm<KSTRIDED, KSTRIDED>("gemm_WP_subZ", gramH_p, K, K, Wo, P, P, K, 1, false, e, done, 3.0 * P * K * sizeof(T));
+        greedy_side("greedy_W", SampleView<const T>{Wo, 1, P}, SampleView<T>{Wn, 1, P}, SampleView<const T>{G, 1, P}, gramH_p, p,
+                    (T)o.lambda_w, false, done);
+        stats_w(Wn, Wo, done);
+        wcur ^= 1;
+    }
+    if (o.update_H) {   // ---- H (:171-174)
+        const T *Wp = W[wcur].p;
+        const T *Ho = H[hcur].p;
+        T *Hn = H[hcur ^ 1].p;
+        wt_times(Wp, X.p, true, done);
+        work[0].ensure((size_t)std::max(P * K, K * N));
+        T *G = work[0].p;
+        EpiSubStore<T> e{numH_p, G, K};
+        gemm<KCONTIG, KCONTIG>("gemm_PH_subZ", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, 3.0 * K * N * sizeof(T));
+        greedy_side("greedy_H", SampleView<const T>{Ho, K, 1}, SampleView<T>{Hn, K, 1}, SampleView<const T>{G, K, 1}, gramW_p, n,
+                    (T)o.lambda_h, true, done);
+        stats_h(Hn, Ho, done);
+        allreduce_hstat(done);
+        hcur ^= 1;
+    }
+}
+
+}  // namespace nmfx

@@ -9,6 +9,7 @@
 #include "projals_impl.hpp"
 #include "alspgrad_impl.hpp"
 #include "frontend_impl.hpp"
+#include "cd_impl.hpp"
 
 using namespace nmfx;
 

@@ -21,6 +21,7 @@
 #include "../../include/nmfx.h"
 #include "gemm_mfma.hpp"
 #include "kernels.hpp"
+#include "cd.hpp"
 
 namespace nmfx {
 struct PgState;
@@ -577,6 +578,16 @@ template <typename T> class Solver : public SolverBase {
     void enqueue_multmse(const nmfx_opts &o, long long t);
     void enqueue_multdiv(const nmfx_opts &o, long long t);
     void enqueue_projals(const nmfx_opts &o, long long t);
+    // coordinate-descent updaters (cd_impl.hpp)
+    void enqueue_cd(const nmfx_opts &o, long long t);
+    void enqueue_greedycd(const nmfx_opts &o, long long t);
+    template <typename F> void with_kmax(F &&f);
+    void greedy_side(const char *tag, SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> G, const T *Pm, int64_t nsamples,
+                     T lambda, bool sharded_samples, const int *done);
+    void allreduce_hstat(const int *done) {   // CD order: H is updated AFTER the packed W-side all-reduce
+        (void)done;
+        if (nranks > 1) RCCL_TRY(ncclAllReduce(hstat.p, hstat.p, (size_t)2 * K, ncclDouble, ncclSum, comm, stream));
+    }
     void enqueue_check(const nmfx_opts &o, long long t) {
         hipLaunchKernelGGL(check_kernel<T>, dim3(1), dim3(256), 0, stream, ctrl, wstat.p,
                            o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t);

@@ -37,13 +37,28 @@ void Solver<T>::enqueue_objective(int alg, const nmfx_opts &o, double *dst, cons
             ++nextra;
         }
     }
+    if (alg == NMFX_ALG_GREEDYCD) {   // + lambda_w*norm(W,1) + lambda_h*norm(H,1)   (greedycd.jl:81-86)
+        const int nb = 1024;
+        if (o.lambda_w > 0) {
+            hipLaunchKernelGGL(sumabs_kernel<T>, dim3(nb), dim3(256), 0, stream, Wp, (int64_t)P * K, obj_part.p + nblk, done);
+            hipLaunchKernelGGL(finish_sumabs_kernel<T>, dim3(1), dim3(64), 0, stream, obj_part.p + nblk, nb, (T)o.lambda_w, obj_extra.p,
+                               nextra, done);
+            ++nextra;
+        }
+        if (o.lambda_h > 0) {
+            hipLaunchKernelGGL(sumabs_kernel<T>, dim3(nb), dim3(256), 0, stream, Hp, (int64_t)K * N, obj_part.p + nblk + nb, done);
+            hipLaunchKernelGGL(finish_sumabs_kernel<T>, dim3(1), dim3(64), 0, stream, obj_part.p + nblk + nb, nb, (T)o.lambda_h,
+                               obj_extra.p, nextra, done);
+            ++nextra;
+        }
+    }
     if (nranks > 1) {
         // the data term is a sum over column shards; regularisers: ||W||^2 is replicated, ||H||^2 is sharded.
         // Reduce the per-block partials to one value first, all-reduce it, then finish.
         hipLaunchKernelGGL(finish_objective_kernel<double>, dim3(1), dim3(256), 0, stream, obj_part.p, nblk, 1,
                            (const double *)nullptr, 0, obj_part.p, done);
         RCCL_TRY(ncclAllReduce(obj_part.p, obj_part.p, 1, ncclDouble, ncclSum, comm, stream));
-        if (alg == NMFX_ALG_PROJALS && o.lambda_h > 0) {
+        if ((alg == NMFX_ALG_PROJALS || alg == NMFX_ALG_GREEDYCD) && o.lambda_h > 0) {
             // sharded ||H||^2 term: sum the already-scaled shard terms (norm in T per shard; documented deviation)
             const int slot = (o.lambda_w > 0) ? 1 : 0;
             RCCL_TRY(ncclAllReduce(obj_extra.p + slot, obj_extra.p + slot, 1, ncclDouble, ncclSum, comm, stream));
@@ -166,7 +181,11 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         if (!(o.lambda_w >= 0)) throw StatusError{NMFX_ERR_BAD_ARG, "lambda_w must be non-negative."};
         if (!(o.lambda_h >= 0)) throw StatusError{NMFX_ERR_BAD_ARG, "lambda_h must be non-negative."};
     }
-    if (alg < 0 || alg > 3) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid algorithm."};
+    if (alg == NMFX_ALG_GREEDYCD) {   // src/greedycd.jl:27-28
+        if (!(o.lambda_w >= 0)) throw StatusError{NMFX_ERR_BAD_ARG, "lambda_w must be non-negative."};
+        if (!(o.lambda_h >= 0)) throw StatusError{NMFX_ERR_BAD_ARG, "lambda_h must be non-negative."};
+    }
+    if (alg < 0 || alg > NMFX_ALG_GREEDYCD) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid algorithm."};
     HIP_TRY(hipSetDevice(device));
     std::memset(out, 0, sizeof *out);
     if (alg == NMFX_ALG_ALSPGRAD) { run_alspgrad(o, out, trace); return; }
@@ -193,9 +212,13 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
             case NMFX_ALG_MULTMSE: enqueue_multmse(o, t); break;
             case NMFX_ALG_MULTDIV: enqueue_multdiv(o, t); break;
             case NMFX_ALG_PROJALS: enqueue_projals(o, t); break;
+            case NMFX_ALG_CD: enqueue_cd(o, t); break;
+            case NMFX_ALG_GREEDYCD: enqueue_greedycd(o, t); break;
         }
+        // common.jl:79 -- enqueued BEFORE the stop check: the check raises the `done` flag that turns every later kernel
+        // into a no-op, and the objective of the converging iteration itself must still be evaluated
+        if (track) enqueue_objective(alg, o, trace_dev.p + t, done_flag());
         enqueue_check(o, t);                                               // common.jl:73
-        if (track) enqueue_objective(alg, o, trace_dev.p + t, done_flag());   // common.jl:79
         if (t % check_every == 0 || t == o.maxiter) {
             HIP_TRY(hipMemcpyAsync(ctrl_host, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));

@@ -30,6 +30,10 @@ struct COpts
     tolg::Float64
     beta::Float64
     sigma::Float64
+    l1_w::Float64      # CoordinateDescentUpd's resolved regularisation (src/coorddesc.jl:62-82)
+    l2_w::Float64
+    l1_h::Float64
+    l2_h::Float64
 end
 
 # struct nmfx_result
@@ -44,7 +48,7 @@ struct CResult
     final_tolg::Float64
 end
 
-const ALG_MULTMSE, ALG_MULTDIV, ALG_PROJALS, ALG_ALSPGRAD = Int32(0), Int32(1), Int32(2), Int32(3)
+const ALG_MULTMSE, ALG_MULTDIV, ALG_PROJALS, ALG_ALSPGRAD, ALG_CD, ALG_GREEDYCD = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4), Int32(5)
 dtype_code(::Type{Float32}) = Int32(0)
 dtype_code(::Type{Float64}) = Int32(1)
 
@@ -96,8 +100,10 @@ function run!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, H::Matrix{T})
     return NMF.Result{T}(W, H, Int(r.niters), r.converged != 0, T(r.objvalue))     # src/common.jl:21-35
 end
 
-opts(T; maxiter, tol, update_H, lambda_w=0.0, lambda_h=0.0, maxsubiter=200, tolg=eps(T)^(1/4)) =
-    COpts(maxiter, update_H, 0, maxsubiter, 20, 4, tol, lambda_w, lambda_h, sqrt(eps(T)), tolg, T(0.2), T(0.01))
+opts(T; maxiter, tol, update_H, lambda_w=0.0, lambda_h=0.0, maxsubiter=200, tolg=eps(T)^(1/4),
+     l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0) =
+    COpts(maxiter, update_H, 0, maxsubiter, 20, 4, tol, lambda_w, lambda_h, sqrt(eps(T)), tolg, T(0.2), T(0.01),
+          l1_w, l2_w, l1_h, l2_h)
 
 # ---- solve! methods: same signatures as src/multupd.jl:45, src/projals.jl:37, src/alspgrad.jl:381, with a
 # ---- leading device Context.  `solve!(alg, X, W, H)` without a Context creates one for the call.
@@ -115,7 +121,21 @@ solve!(ctx::Context{T}, alg::NMF.ALSPGrad{T}, W::Matrix{T}, H::Matrix{T}) where 
     run!(ctx, ALG_ALSPGRAD, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
                                  maxsubiter=alg.maxsubiter, tolg=alg.tolg), W, H)
 
-function solve!(alg::Union{NMF.MultUpdate{T},NMF.ProjectedALS{T},NMF.ALSPGrad{T}},
+# CoordinateDescent (src/coorddesc.jl:54-56): the l1/l2 pairs are resolved exactly like CoordinateDescentUpd's constructor
+# (src/coorddesc.jl:62-82); shuffle = true needs a permutation from Julia's RNG and stays on the CPU path.
+function solve!(ctx::Context{T}, alg::NMF.CoordinateDescent{T}, W::Matrix{T}, H::Matrix{T}) where T
+    alg.shuffle && throw(ArgumentError("shuffle=true is not offered by the device path"))
+    u = NMF.CoordinateDescentUpd{T}(alg.α, alg.l₁ratio, alg.regularization, alg.shuffle, alg.update_H)
+    run!(ctx, ALG_CD, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
+                           l1_w=u.l₁W, l2_w=u.l₂W, l1_h=u.l₁H, l2_h=u.l₂H), W, H)
+end
+
+# GreedyCD (src/greedycd.jl:34-35)
+solve!(ctx::Context{T}, alg::NMF.GreedyCD{T}, W::Matrix{T}, H::Matrix{T}) where T =
+    run!(ctx, ALG_GREEDYCD, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
+                                 lambda_w=alg.lambda_w, lambda_h=alg.lambda_h), W, H)
+
+function solve!(alg::Union{NMF.MultUpdate{T},NMF.ProjectedALS{T},NMF.ALSPGrad{T},NMF.CoordinateDescent{T},NMF.GreedyCD{T}},
                 X::Matrix{T}, W::Matrix{T}, H::Matrix{T}; device::Integer=0) where T
     ctx = Context{T}(X, size(W, 2); device=device)
     try

@@ -1,9 +1,9 @@
 """nmfx -- host-side mirror of the NMF.jl interface over libnmfx.so (MI355X, hand-written HIP)."""
-from .api import (ALSPGrad, ArgumentError, Context, DimensionMismatch, MultUpdate, NMFXError, PosDefException,
+from .api import (ALSPGrad, ArgumentError, Context, CoordinateDescent, GreedyCD, DimensionMismatch, MultUpdate, NMFXError, PosDefException,
                   ProjectedALS, Result, alspgrad_updateh, alspgrad_updatew, comm_unique_id, make_opts, nmf_checksize,
                   nnmf, randinit, solve)
 from . import _lib, dist
 
-__all__ = ["ALSPGrad", "ArgumentError", "Context", "DimensionMismatch", "MultUpdate", "NMFXError", "PosDefException",
+__all__ = ["ALSPGrad", "ArgumentError", "Context", "CoordinateDescent", "GreedyCD", "DimensionMismatch", "MultUpdate", "NMFXError", "PosDefException",
            "ProjectedALS", "Result", "alspgrad_updateh", "alspgrad_updatew", "comm_unique_id", "make_opts",
            "nmf_checksize", "nnmf", "randinit", "solve", "_lib", "dist"]

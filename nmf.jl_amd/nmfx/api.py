@@ -134,6 +134,60 @@ class ALSPGrad:
                     tolg=self.tolg)
 
 
+class CoordinateDescent:
+    """CoordinateDescent{T}(; maxiter, verbose, tol, update_H, α, regularization, l₁ratio, shuffle)  (src/coorddesc.jl:23-51);
+    the resolved l1/l2 pairs are those of CoordinateDescentUpd (src/coorddesc.jl:62-82).  shuffle=True (a permutation drawn
+    from Julia's RNG) is outside the device path."""
+
+    def __init__(self, T, maxiter=100, verbose=False, tol=None, update_H=True, alpha=0.0, regularization="both",
+                 l1ratio=0.0, shuffle=False):
+        T = np.dtype(T).type
+        if shuffle:
+            raise ArgumentError("shuffle=true is not offered by the device path (component order is fixed)")
+        if regularization not in ("both", "components", "transformation", "none"):
+            raise ArgumentError("Invalid value for regularization.")
+        self.T, self.maxiter, self.verbose = T, int(maxiter), bool(verbose)
+        self.tol = float(T(np.cbrt(_eps(T)) if tol is None else tol))
+        self.update_H = bool(update_H)
+        a, l1r = T(alpha), T(l1ratio)
+        aH = a if regularization in ("both", "components") else T(0)
+        aW = a if regularization in ("both", "transformation") else T(0)
+        self.l1_w, self.l2_w = float(T(aW * l1r)), float(T(aW * (T(1) - l1r)))
+        self.l1_h, self.l2_h = float(T(aH * l1r)), float(T(aH * (T(1) - l1r)))
+
+    def _alg(self):
+        return L.ALG_CD
+
+    def _opts(self):
+        return dict(maxiter=self.maxiter, tol=self.tol, update_H=self.update_H, l1_w=self.l1_w, l2_w=self.l2_w,
+                    l1_h=self.l1_h, l2_h=self.l2_h)
+
+
+class GreedyCD:
+    """GreedyCD{T}(; maxiter, verbose, tol, update_H, lambda_w, lambda_h)  (src/greedycd.jl:10-32)."""
+
+    def __init__(self, T, maxiter=100, verbose=False, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.0):
+        T = np.dtype(T).type
+        tol = float(T(np.cbrt(_eps(T)))) if tol is None else tol
+        if not maxiter > 1:
+            raise ArgumentError("maxiter must be greater than 1.")
+        if not tol > 0:
+            raise ArgumentError("tol must be positive.")
+        if not lambda_w >= 0:
+            raise ArgumentError("lambda_w must be non-negative.")
+        if not lambda_h >= 0:
+            raise ArgumentError("lambda_h must be non-negative.")
+        self.T, self.maxiter, self.verbose = T, int(maxiter), bool(verbose)
+        self.tol, self.update_H = float(T(tol)), bool(update_H)
+        self.lambda_w, self.lambda_h = float(T(lambda_w)), float(T(lambda_h))
+
+    def _alg(self):
+        return L.ALG_GREEDYCD
+
+    def _opts(self):
+        return dict(maxiter=self.maxiter, tol=self.tol, update_H=self.update_H, lambda_w=self.lambda_w, lambda_h=self.lambda_h)
+
+
 @dataclass
 class Result:
     """NMF.Result{T} (src/common.jl:21-38).  W and H are the caller's arrays, updated in place."""
@@ -158,13 +212,15 @@ class Result:
 
 
 def make_opts(T, maxiter=100, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.0, delta=None, maxsubiter=200,
-              traceiter=20, tolg=None, beta=0.2, sigma=0.01, track_objective=False, check_every=4) -> L.Opts:
+              traceiter=20, tolg=None, beta=0.2, sigma=0.01, track_objective=False, check_every=4,
+              l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0) -> L.Opts:
     T = np.dtype(T).type
     return L.Opts(int(maxiter), int(bool(update_H)), int(bool(track_objective)), int(maxsubiter), int(traceiter),
                   int(check_every),
                   float(T(np.cbrt(_eps(T)) if tol is None else tol)), float(lambda_w), float(lambda_h),
                   float(T(math.sqrt(_eps(T))) if delta is None else delta),
-                  float(T(_eps(T) ** 0.25) if tolg is None else tolg), float(T(beta)), float(T(sigma)))
+                  float(T(_eps(T) ** 0.25) if tolg is None else tolg), float(T(beta)), float(T(sigma)),
+                  float(l1_w), float(l2_w), float(l1_h), float(l2_h))
 
 
 def nmf_checksize(X, W, H):
@@ -416,7 +472,11 @@ def nnmf(X, k, init="random", alg="multmse", maxiter=100, tol=None, replicates=1
         inst = MultUpdate(T, obj="mse", maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
     elif alg == "multdiv":
         inst = MultUpdate(T, obj="div", maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
-    elif alg in ("cd", "greedycd", "spa"):
+    elif alg == "cd":
+        inst = CoordinateDescent(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    elif alg == "greedycd":
+        inst = GreedyCD(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    elif alg == "spa":
         raise ArgumentError(f"alg=:{alg} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
     else:
         raise ArgumentError("Invalid algorithm.")
@@ -446,7 +506,11 @@ def _alg_instance(T, alg, maxiter, tol, verbose, update_H):
         return MultUpdate(T, obj="mse", maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
     if alg == "multdiv":
         return MultUpdate(T, obj="div", maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
-    if alg in ("cd", "greedycd", "spa"):
+    if alg == "cd":
+        return CoordinateDescent(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    if alg == "greedycd":
+        return GreedyCD(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
+    if alg == "spa":
         raise ArgumentError(f"alg=:{alg} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
     raise ArgumentError("Invalid algorithm.")
 

@@ -21,7 +21,8 @@ class _COpts(C.Structure):
     _fields_ = [("maxiter", C.c_int), ("update_H", C.c_int), ("track_objective", C.c_int),
                 ("maxsubiter", C.c_int), ("traceiter", C.c_int), ("_pad", C.c_int),
                 ("tol", C.c_double), ("lambda_w", C.c_double), ("lambda_h", C.c_double),
-                ("delta", C.c_double), ("tolg", C.c_double), ("beta", C.c_double), ("sigma", C.c_double)]
+                ("delta", C.c_double), ("tolg", C.c_double), ("beta", C.c_double), ("sigma", C.c_double),
+                ("l1_w", C.c_double), ("l2_w", C.c_double), ("l1_h", C.c_double), ("l2_h", C.c_double)]
 
 
 class _CResult(C.Structure):
@@ -61,7 +62,8 @@ def solve(alg, X, W, H, opts: Opts | None = None) -> Result:
     k = W.shape[1]
     o = resolve_opts(alg, T, opts or Opts())
     co = _COpts(o.maxiter, int(o.update_H), int(o.track_objective), o.maxsubiter, o.traceiter, 0,
-                o.tol, o.lambda_w, o.lambda_h, o.delta, o.tolg, float(T(o.beta)), float(T(o.sigma)))
+                o.tol, o.lambda_w, o.lambda_h, o.delta, o.tolg, float(T(o.beta)), float(T(o.sigma)),
+                o.l1_w, o.l2_w, o.l1_h, o.l2_h)
     res = _CResult()
     trace = np.full(o.maxiter + 1, np.nan)
     fn = getattr(lib(), f"nmf_oracle_solve_{_sfx(X.dtype)}")

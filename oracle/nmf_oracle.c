@@ -26,6 +26,7 @@
 typedef struct {
     int maxiter, update_H, track_objective, maxsubiter, traceiter, _pad;
     double tol, lambda_w, lambda_h, delta, tolg, beta, sigma;   /* all resolved by the caller */
+    double l1_w, l2_w, l1_h, l2_h;                              /* CoordinateDescentUpd (coorddesc.jl:62-82) */
 } oracle_opts;
 
 typedef struct {

@@ -2,7 +2,8 @@
 
 Literal CPU restatement of the NMF.jl hot path (JuliaStats/NMF.jl v1.0.3):
 the `nmf_skeleton!` driver and the `update_wh!` bodies of MultUpdate (MSE and
-KL divergence), ProjectedALS and ALSPGrad.  Only `tests/`,
+KL divergence), ProjectedALS and ALSPGrad, plus
+CoordinateDescent with shuffle = false and GreedyCD.  Only `tests/`,
 `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import
 this module; the shipped solver (libnmfx.so) never does.
 
@@ -11,7 +12,9 @@ PARITY PINNING STATUS
     cannot run here.  The oracle is pinned against every known-answer test the
     reference's own test-suite holds for this path (test/testproblems.jl:6-13,
     test/multupd.jl:3-22, test/alspgrad.jl:3-25, test/utils.jl:6-63,
-    test/interf.jl:33-37) -- see tests/test_oracle_kat.py -- and against an
+    test/interf.jl:33-37, test/coorddesc.jl:5-8, test/greedycd.jl:5-20; the
+    shuffle = true half of test/coorddesc.jl:10-14 needs Julia's RNG and is run
+    in component order) -- see tests/test_oracle_kat.py -- and against an
     independent second restatement in C (oracle/nmf_oracle.c).
   * `Result.objvalue`: PARITY UNPINNED.  It is computed by StatsBase.sqL2dist /
     StatsBase.gkldiv (compat 0.25-0.34, not vendored, no Manifest; call sites
@@ -34,8 +37,8 @@ from dataclasses import dataclass, field
 import numpy as np
 from scipy.linalg import lapack
 
-MULTMSE, MULTDIV, PROJALS, ALSPGRAD = 0, 1, 2, 3
-ALG_NAMES = {"multmse": MULTMSE, "multdiv": MULTDIV, "projals": PROJALS, "alspgrad": ALSPGRAD}
+MULTMSE, MULTDIV, PROJALS, ALSPGRAD, CD, GREEDYCD = 0, 1, 2, 3, 4, 5
+ALG_NAMES = {"multmse": MULTMSE, "multdiv": MULTDIV, "projals": PROJALS, "alspgrad": ALSPGRAD, "cd": CD, "greedycd": GREEDYCD}
 
 
 def eps(T):
@@ -58,6 +61,11 @@ class Opts:
     beta: float = 0.2
     sigma: float = 0.01
     track_objective: bool = False   # verbose-style per-iteration objective (common.jl:76-82)
+    # CoordinateDescentUpd's resolved regularisation (coorddesc.jl:62-82); shuffle is not modelled (component order 1..k)
+    l1_w: float = 0.0
+    l2_w: float = 0.0
+    l1_h: float = 0.0
+    l2_h: float = 0.0
 
 
 @dataclass
@@ -86,6 +94,11 @@ def resolve_opts(alg: int, T, o: Opts) -> Opts:
         if alg == MULTDIV:                                # multupd.jl:37-40
             r.lambda_w = max(r.lambda_w, float(T(math.sqrt(e))))
             r.lambda_h = max(r.lambda_h, float(T(math.sqrt(e))))
+    elif alg == GREEDYCD:
+        if r.lambda_w < 0:
+            r.lambda_w = 0.0                              # greedycd.jl:22-23
+        if r.lambda_h < 0:
+            r.lambda_h = 0.0
     elif alg == PROJALS:
         if r.lambda_w < 0:
             r.lambda_w = float(T(np.cbrt(e)))             # projals.jl:30-31
@@ -361,7 +374,120 @@ class _ALSPGrad:
         self.WH = W @ H                                           # :424
 
 
-_UPDATERS = {MULTMSE: _MultMSE, MULTDIV: _MultDiv, PROJALS: _ProjALS, ALSPGRAD: _ALSPGrad}
+# ----------------------------------------------------------------------------
+# CoordinateDescent (src/coorddesc.jl) and GreedyCD (src/greedycd.jl) -- SURVEY.md section 8f rank 2
+# ----------------------------------------------------------------------------
+
+def _update_coord_descent(X, W, H, l1_reg, l2_reg):
+    """_update_coord_descent! (coorddesc.jl:107-158) for shuffle = false: updates W in place, returns the violation.
+    `H` is k x n (any strides).  The reference's t-outer / i-inner loops are kept; the inner loop over samples i is
+    vectorised (rows do not interact) and the sum over r runs left to right in T exactly like :143-145."""
+    T = X.dtype.type
+    Ht = H.T
+    HHt = H @ Ht                                                   # :111
+    XHt = X @ Ht                                                   # :117
+    k = H.shape[0]
+    if l2_reg > 0:
+        HHt[np.diag_indices(k)] += T(l2_reg)                       # :118-120
+    if l1_reg > 0:
+        XHt = XHt - T(l1_reg)                                      # :121-123
+    violation = T(0)
+    for t in range(k):                                             # :133 (permutation = 1:n_components)
+        grad = -XHt[:, t]                                          # :141
+        for r in range(k):                                         # :143-145
+            grad = grad + HHt[t, r] * W[:, r]
+        pg = np.where(W[:, t] == 0, np.minimum(T(0), grad), grad)  # :148
+        for v in np.abs(pg):                                       # :149  (sequential accumulation over i, in T)
+            violation = T(violation + v)
+        hess = HHt[t, t]                                           # :152
+        if hess != 0:
+            W[:, t] = np.maximum(W[:, t] - grad / hess, T(0))      # :153-155
+    return violation
+
+
+class _CoordDesc:
+    """src/coorddesc.jl:84-181."""
+
+    def __init__(self, T, o, X, W, H):
+        self.T, self.o = T, o
+        self.violation = T(0)
+
+    def objv(self, X, W, H):
+        return float(self.T(0.5 * sqL2dist(X, W @ H)))             # :101-104
+
+    def update(self, X, W, H):
+        T, o = self.T, self.o
+        v = _update_coord_descent(X, W, H, o.l1_w, o.l2_w)                       # :166
+        if o.update_H:
+            Ht = H.T                                                                # a view: the update lands in H
+            v = T(v + _update_coord_descent(X.T, Ht, W.T, o.l1_h, o.l2_h))      # :169-174
+        self.violation = v
+
+
+def _greedy_sd(w, g, prr, T):
+    """S and D of greedycd.jl:122-123 / :151-152 (elementwise, operation by operation in T)."""
+    s = np.maximum(T(0), w - g / (T(eps(T)) + prr)) - w
+    d = -g * s - (T(0.5) * prr) * (s * s)
+    return s, d
+
+
+def _update_greedycd(X, W, Ht, lam, counters):
+    """_update_GreedyCD! (greedycd.jl:91-163): W (samples x k) updated in place from Ht (other-side samples x k)."""
+    T = X.dtype.type
+    ns, k = W.shape
+    P = Ht.T @ Ht                                                  # :108
+    Z = X @ Ht                                                     # :109
+    G = W @ P - Z                                                  # :110-111
+    if lam > 0:
+        G = G + T(lam)                                             # :112-114
+    prr = np.diag(P).copy()
+    S, D = _greedy_sd(W, G, prr[None, :], T)                       # :117-122
+    q = np.argmax(D, axis=1)                                       # :125-129 (first maximum, like Julia's argmax)
+    p_init = max(T(-1.0), D[np.arange(ns), q].max()) if ns else T(-1.0)
+    Wnew = np.zeros_like(W)                                        # :131
+    nu = T(0.001)
+    thresh = T(nu * p_init)
+    steps = 0
+    for i in range(ns):                                            # :134
+        qi = int(q[i])
+        w, g, s, d = W[i].copy(), G[i].copy(), S[i].copy(), D[i].copy()
+        for _ in range(k * k):                                     # :136
+            if d[qi] < thresh:                                     # :137-139
+                break
+            Wnew[i, qi] += s[qi]                                   # :141
+            g = g + s[qi] * P[qi]                                  # :143-145
+            s, d = _greedy_sd(w, g, prr, T)                        # :147-150
+            qi = int(np.argmax(d))                                 # :152
+            steps += 1
+    counters["greedy_steps"] = counters.get("greedy_steps", 0) + steps
+    W[...] = np.maximum(W + Wnew, T(0))                            # :156-157  copyto!(W, W + Wnew); projectnn!(W)
+
+
+class _GreedyCD:
+    """src/greedycd.jl:37-177."""
+
+    def __init__(self, T, o, X, W, H):
+        self.T, self.o = T, o
+        self.cnt = {}
+
+    def objv(self, X, W, H):
+        T, o = self.T, self.o
+        r = 0.5 * sqL2dist(X, W @ H)                               # :79-80
+        if o.lambda_w > 0:
+            r += float(T(T(o.lambda_w) * T(np.abs(W).sum(dtype=np.float64))))   # :81-83  lambda_w * norm(W, 1)
+        if o.lambda_h > 0:
+            r += float(T(T(o.lambda_h) * T(np.abs(H).sum(dtype=np.float64))))   # :84-86
+        return float(T(r))
+
+    def update(self, X, W, H):
+        o = self.o
+        _update_greedycd(X, W, H.T, o.lambda_w, self.cnt)          # :168
+        if o.update_H:
+            Ht = H.T                                               # view: in-place update of H
+            _update_greedycd(X.T, Ht, W, o.lambda_h, self.cnt)     # :171-174
+
+
+_UPDATERS = {MULTMSE: _MultMSE, MULTDIV: _MultDiv, PROJALS: _ProjALS, ALSPGRAD: _ALSPGrad, CD: _CoordDesc, GREEDYCD: _GreedyCD}
 
 
 def alspgrad_updateh(X, W, H, maxiter=1000, traceiter=20, tolg=None, beta=0.2, sigma=0.01):

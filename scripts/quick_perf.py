@@ -15,7 +15,7 @@ def run(p, n, k, T, alg_name, iters=10, maxsub=200, comm=False):
     W0 = np.asfortranarray(W0)
     H0 = np.asfortranarray(rng.random((k, n)).astype(T))
     print(f"gen {time.time()-t0:.1f}s", flush=True)
-    algs = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3}
+    algs = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3, "cd": 4, "greedycd": 5}
     with nmfx.Context(T, p, n, k) as ctx:
         t0 = time.time(); ctx.set_X(X); print(f"upload X {time.time()-t0:.2f}s", flush=True)
         if comm:
@@ -28,7 +28,7 @@ def run(p, n, k, T, alg_name, iters=10, maxsub=200, comm=False):
         t0 = time.time(); res, _ = ctx.iterate(algs[alg_name], o); wall = time.time() - t0
         fl = {"multmse": 4.0*p*n*k + 4.0*k*k*(p+n), "multdiv": 8.0*p*n*k,
               "projals": 4.0*p*n*k + 2.0*k*k*(p+n) + 2.0*k*k*n + 2.0*p*k*k + float(k)**3,
-              "alspgrad": 4.0*p*n*k + 2.0*k*k*(p+n)}[alg_name]
+              "alspgrad": 4.0*p*n*k + 2.0*k*k*(p+n), "cd": 4.0*p*n*k + 4.0*k*k*(p+n), "greedycd": 4.0*p*n*k + 4.0*k*k*(p+n)}[alg_name]
         print(f"   inner={res.inner_iters} backtracks={res.backtracks}")
         print(f"{alg_name} {p}x{n} k={k} {np.dtype(T).name}: {res.seconds_loop/iters*1e3:.3f} ms/iter (wall {wall/iters*1e3:.3f}) "
               f"-> {fl*iters/res.seconds_loop/1e12:.1f} TFLOP/s alg; objv {res.objvalue:.6e}", flush=True)
@@ -48,6 +48,9 @@ if __name__ == "__main__":
     if "c3f64" in which: run(8192, 8192, 256, np.float64, "multmse", 5)
     if "c4shard" in which: run(16384, 16384, 256, np.float32, "projals", 5)
     if "c5shard" in which: run(8192, 4096, 512, np.float64, "alspgrad", 2, maxsub=10)
+    if "cd" in which: run(16384, 16384, 256, np.float32, "cd", 10)
+    if "gcd" in which: run(16384, 16384, 256, np.float32, "greedycd", 5)
+    if "cd2" in which: run(4096, 4096, 64, np.float32, "cd", 20); run(4096, 4096, 64, np.float32, "greedycd", 10)
     if "c5full" in which: run(32768, 4096, 512, np.float64, "alspgrad", 2, maxsub=10)
     if "shards" in which:      # per-rank shapes of the C3 problem at 2/4/8 GPUs (local compute + 1-rank all-reduce)
         for nl in (8192, 4096, 2048): run(16384, nl, 256, np.float32, "multmse", 30, comm=True)

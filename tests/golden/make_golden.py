@@ -24,11 +24,17 @@ CASES = {
     "multdiv": ("multdiv", 48, 80, 6, 40, dict()),
     "projals": ("projals", 64, 96, 5, 25, dict(lambda_w=0.05, lambda_h=0.05)),
     "alspgrad": ("alspgrad", 40, 56, 4, 12, dict()),
+    # SURVEY.md section 8f rank 2 (added later; `python make_golden.py cd greedycd` writes only these)
+    "cd": ("cd", 48, 80, 6, 20, dict(l1_w=2.5e-4, l2_w=7.5e-4, l1_h=2.5e-4, l2_h=7.5e-4)),
+    "greedycd": ("greedycd", 64, 96, 5, 8, dict(lambda_w=1e-4, lambda_h=2e-4)),   # f32 greedy sweeps are chaotic near a fit: short run
 }
 
 
 def main():
+    only = set(sys.argv[1:])
     for name, (alg, p, n, k, maxiter, extra) in CASES.items():
+        if only and name not in only:
+            continue
         for T in (np.float64, np.float32):
             # projals: plain U[0,1) W0 (not column-normalised) keeps W'W + lambda*I well conditioned in f32;
             # with normalised columns the first least-squares step amplifies f32 rounding to ~3e-3 between
@@ -43,14 +49,14 @@ def main():
             rel = np.max(np.abs(tn - tc) / np.abs(tn))
             # multiplicative updates are well conditioned; the Cholesky / line-search paths amplify rounding
             lim = {"multmse": (1e-12, 2e-6), "multdiv": (1e-12, 2e-6), "projals": (1e-9, 1e-3),
-                   "alspgrad": (1e-9, 1e-3)}[name][0 if T == np.float64 else 1]
+                   "alspgrad": (1e-9, 1e-3), "cd": (1e-12, 1e-4), "greedycd": (1e-11, 2e-4)}[name][0 if T == np.float64 else 1]
             print(f"{name:9s} {T.__name__}: niters {rn.niters}/{rc.niters} objective rel diff numpy-vs-C {rel:.2e}")
             assert rn.niters == rc.niters and rel < lim, (name, T, rel)
             ro = orc.resolve_opts(orc.ALG_NAMES[alg], T, o)
             np.savez_compressed(os.path.join(HERE, f"{name}_{np.dtype(T).name}.npz"), X=X, W0=W0, H0=H0,
                                 trace=tn, niters=rn.niters, converged=rn.converged, W=Wn, H=Hn, objvalue=rn.objvalue,
                                 opts=np.array([ro.maxiter, ro.tol, ro.lambda_w, ro.lambda_h, ro.delta, ro.tolg]),
-                                alg=alg)
+                                opts_cd=np.array([ro.l1_w, ro.l2_w, ro.l1_h, ro.l2_h]), alg=alg)
 
 
 if __name__ == "__main__":

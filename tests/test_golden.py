@@ -14,21 +14,26 @@ from problems import rel_trace_err
 HERE = os.path.dirname(os.path.abspath(__file__))
 FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
 # objective-trajectory tolerance (relative, every iteration): (f64, f32)
-TOL_CPU = {"multmse": (1e-11, 5e-6), "multdiv": (1e-11, 5e-6), "projals": (1e-8, 2e-3), "alspgrad": (1e-8, 2e-3)}
-TOL_GPU = {"multmse": (1e-10, 1e-5), "multdiv": (1e-10, 1e-5), "projals": (1e-7, 2e-3), "alspgrad": (1e-7, 2e-3)}
+TOL_CPU = {"multmse": (1e-11, 5e-6), "multdiv": (1e-11, 5e-6), "projals": (1e-8, 2e-3), "alspgrad": (1e-8, 2e-3),
+           "cd": (1e-11, 2e-4), "greedycd": (1e-10, 5e-4)}
+TOL_GPU = {"multmse": (1e-10, 1e-5), "multdiv": (1e-10, 1e-5), "projals": (1e-7, 2e-3), "alspgrad": (1e-7, 2e-3),
+           "cd": (1e-10, 5e-4), "greedycd": (1e-9, 1e-3)}
+ALGS = ("multmse", "multdiv", "projals", "alspgrad", "cd", "greedycd")
 
 
 def _load(path):
     z = np.load(path)
     alg = str(z["alg"])
     maxiter, tol, lw, lh, delta, tolg = z["opts"]
-    return z, alg, dict(maxiter=int(maxiter), tol=float(tol), lambda_w=float(lw), lambda_h=float(lh),
-                        delta=float(delta), tolg=float(tolg))
+    kw = dict(maxiter=int(maxiter), tol=float(tol), lambda_w=float(lw), lambda_h=float(lh), delta=float(delta), tolg=float(tolg))
+    if "opts_cd" in z.files:
+        kw.update(dict(zip(("l1_w", "l2_w", "l1_h", "l2_h"), (float(v) for v in z["opts_cd"]))))
+    return z, alg, kw
 
 
 def test_fixture_inventory():
     names = {os.path.basename(f) for f in FILES}
-    assert names == {f"{a}_{d}.npz" for a in ("multmse", "multdiv", "projals", "alspgrad") for d in ("float32", "float64")}
+    assert names == {f"{a}_{d}.npz" for a in ALGS for d in ("float32", "float64")}
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
@@ -57,8 +62,13 @@ def test_hip_path_reproduces_goldens(built, path):
         inst = nmfx.MultUpdate(T, obj=alg[4:], maxiter=kw["maxiter"], tol=kw["tol"], lambda_w=kw["lambda_w"], lambda_h=kw["lambda_h"])
     elif alg == "projals":
         inst = nmfx.ProjectedALS(T, maxiter=kw["maxiter"], tol=kw["tol"], lambda_w=kw["lambda_w"], lambda_h=kw["lambda_h"])
-    else:
+    elif alg == "alspgrad":
         inst = nmfx.ALSPGrad(T, maxiter=kw["maxiter"], tol=kw["tol"], tolg=kw["tolg"])
+    elif alg == "cd":
+        inst = nmfx.CoordinateDescent(T, maxiter=kw["maxiter"], tol=kw["tol"])
+        inst.l1_w, inst.l2_w, inst.l1_h, inst.l2_h = kw["l1_w"], kw["l2_w"], kw["l1_h"], kw["l2_h"]
+    else:
+        inst = nmfx.GreedyCD(T, maxiter=kw["maxiter"], tol=kw["tol"], lambda_w=kw["lambda_w"], lambda_h=kw["lambda_h"])
     r = nmfx.solve(inst, X, W, H, track_objective=True)
     tol = TOL_GPU[alg][0 if T == np.float64 else 1]
     assert r.niters == int(z["niters"]) and r.converged == bool(z["converged"])

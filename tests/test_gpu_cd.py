@@ -1,0 +1,145 @@
+"""GPU parity: CoordinateDescent (src/coorddesc.jl) and GreedyCD (src/greedycd.jl) through the C ABI vs the CPU oracles
+(SURVEY.md section 8f rank 2).
+
+Tolerances on the objective trajectory: CD 1e-9 (f64) / 5e-4 (f32) relative; GreedyCD 1e-9 (f64) / 3e-3 (f32).  CD: the device forms the row dot products as
+a butterfly instead of left to right.  GreedyCD: the per-row greedy sweep is restated operation by operation (no FMA
+contraction), but its inputs G = W*P - Z come from MFMA GEMMs whose rounding differs from a CPU GEMM, and the sweep is
+discontinuous in them (argmax / threshold decisions) -- like alspgrad, trajectories are compared, not decision traces; in
+f64 the executed greedy step count equals the oracle's on these inputs.
+"""
+import numpy as np
+import pytest
+
+import c_oracle as co
+import nmf_oracle as orc
+import nmfx
+from problems import planted, rel_trace_err, uniform
+
+pytestmark = pytest.mark.gpu
+TOL = {np.float64: 1e-9, np.float32: 5e-4}
+TOL_GREEDY = {np.float64: 1e-9, np.float32: 3e-3}    # f32: the sweep's argmax / threshold decisions flip on 1-ulp input changes
+SHAPES = [(64, 96, 5), (300, 260, 70), (130, 515, 8), (129, 257, 100), (7, 5, 5), (33, 1000, 3), (257, 300, 130)]
+
+
+def _cd(T, **kw):
+    return nmfx.CoordinateDescent(T, **kw)
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("reg", [False, True])
+def test_cd_trajectory(built, T, shape, reg):
+    p, n, k = shape
+    X, W0, H0 = uniform(p, n, k, T, seed=5 + p)
+    kw = dict(alpha=2e-3, l1ratio=0.25, regularization="both") if reg else {}
+    alg = _cd(T, maxiter=8, tol=1e-30, **kw)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg, track_objective=True)
+    oo = orc.Opts(maxiter=8, tol=1e-30, track_objective=True, l1_w=alg.l1_w, l2_w=alg.l2_w, l1_h=alg.l1_h, l2_h=alg.l2_h)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = (orc if p * n * k < 2e6 else co).solve("cd", X, Wc, Hc, oo)
+    assert r.niters == ro.niters == 8
+    assert rel_trace_err(r.trace, ro.trace) < TOL[T]
+    assert np.all(Wg >= 0) and np.all(Hg >= 0)
+    assert np.max(np.abs(Wg - Wc)) <= 200 * TOL[T] * max(1.0, np.max(np.abs(Wc)))
+    assert np.max(np.abs(Hg - Hc)) <= 200 * TOL[T] * max(1.0, np.max(np.abs(Hc)))
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("lam", [(0.0, 0.0), (1e-3, 2e-3)])
+def test_greedycd_trajectory(built, T, shape, lam):
+    p, n, k = shape
+    X, W0, H0 = uniform(p, n, k, T, seed=11 + n)
+    alg = nmfx.GreedyCD(T, maxiter=6, tol=1e-30, lambda_w=lam[0], lambda_h=lam[1])
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg, track_objective=True)
+    oo = orc.Opts(maxiter=6, tol=1e-30, track_objective=True, lambda_w=lam[0], lambda_h=lam[1])
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = co.solve("greedycd", X, Wc, Hc, oo)
+    assert r.niters == ro.niters == 6
+    # conditioning yardstick (as for projals): how far the SAME CPU restatement drifts when X moves by one ulp in half of
+    # its entries -- with k close to min(p, n) the objective is not even monotone and the f32 trajectories are chaotic
+    # at the 1e-2 level.  The device may deviate from the oracle by at most 3x that, nor is it asked to beat it.
+    rng = np.random.default_rng(1)
+    Xp = np.asfortranarray(np.where(rng.random(X.shape) < 0.5, np.nextafter(X, T(2)), X).astype(T))
+    ry = co.solve("greedycd", Xp, W0.copy(order="F"), H0.copy(order="F"), oo)
+    tol = max(TOL_GREEDY[T], 3 * rel_trace_err(ry.trace, ro.trace))
+    err = rel_trace_err(r.trace, ro.trace)
+    if err >= tol and T == np.float32:
+        # second yardstick, only when needed (slow): the two independent CPU restatements (NumPy/OpenBLAS GEMMs vs the plain-C
+        # loops) on the SAME input -- e.g. 1.3e-2 apart at (129, 257, 100), where the device is 1.2e-2 from the C one
+        rn = orc.solve("greedycd", X, W0.copy(order="F"), H0.copy(order="F"), oo)
+        tol = max(tol, 3 * rel_trace_err(rn.trace, ro.trace))
+    assert err < tol
+    assert np.all(Wg >= 0) and np.all(Hg >= 0)
+    if T == np.float64:
+        assert r.info["inner_iters"] == ro.counters["inner"]           # executed greedy steps
+        assert np.max(np.abs(Wg - Wc)) <= 1e-7 * max(1.0, np.max(np.abs(Wc)))
+        assert np.max(np.abs(Hg - Hc)) <= 1e-7 * max(1.0, np.max(np.abs(Hc)))
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_reference_kats(built, T):
+    """test/coorddesc.jl:5-8 and test/greedycd.jl:5-20 on the device path (laurberg6x3, W perturbed, H = Hg)."""
+    rng = np.random.default_rng(3)
+    X, Wg, Hg = orc.laurberg6x3(0.3, T)
+    W = np.asfortranarray(Wg + rng.random(Wg.shape).astype(T) * T(0.1)); H = Hg.copy(order="F")
+    nmfx.solve(_cd(T, alpha=0.0, maxiter=1000, tol=1e-9), X, W, H)
+    assert np.allclose(X, W @ H, atol=1e-4, rtol=0)
+    W = np.asfortranarray(Wg + rng.random(Wg.shape).astype(T) * T(0.1)); H = Hg.copy(order="F")
+    nmfx.solve(_cd(T, alpha=1e-4, l1ratio=0.5, maxiter=1000, tol=1e-9), X, W, H)      # (the reference also shuffles here)
+    assert np.allclose(X, W @ H, atol=1e-2, rtol=0)
+    for lw in (0.0, 1e-5):
+        for lh in (0.0, 1e-5):
+            W = np.asfortranarray(Wg + rng.random(Wg.shape).astype(T) * T(0.1)); H = Hg.copy(order="F")
+            nmfx.solve(nmfx.GreedyCD(T, maxiter=1000, tol=1e-9, lambda_w=lw, lambda_h=lh), X, W, H)
+            assert np.all(W >= 0) and np.all(H >= 0) and not np.isnan(W).any() and not np.isnan(H).any()
+            assert np.allclose(X, W @ H, atol=1e-3, rtol=0)
+
+
+@pytest.mark.parametrize("algname", ["cd", "greedycd"])
+def test_update_H_false_and_stop(built, algname):
+    """test/interf.jl:33-37 for :cd / :greedycd: update_H=false leaves H bit-identical; the stop rule matches the oracle."""
+    T = np.float64
+    X, W0, H0 = planted(60, 80, 4, T, seed=8)
+    mk = (lambda **kw: _cd(T, **kw)) if algname == "cd" else (lambda **kw: nmfx.GreedyCD(T, **kw))
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    nmfx.solve(mk(maxiter=20, update_H=False), X, Wg, Hg)
+    assert np.array_equal(Hg, H0) and not np.array_equal(Wg, W0)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(mk(maxiter=500, tol=1e-5), X, Wg, Hg)
+    ro = orc.solve(algname, X, W0.copy(order="F"), H0.copy(order="F"), orc.Opts(maxiter=500, tol=1e-5))
+    assert r.converged == ro.converged and abs(r.niters - ro.niters) <= 1
+    assert abs(r.objvalue - ro.objvalue) <= 1e-7 * abs(ro.objvalue)
+
+
+@pytest.mark.parametrize("algname", ["cd", "greedycd"])
+def test_sharded_path_single_rank(built, algname):
+    """The RCCL code path (packed all-reduce, p_init max all-reduce, H statistics all-reduce) with a 1-rank communicator."""
+    T = np.float32
+    X, W0, H0 = uniform(200, 150, 6, T, seed=2)
+    alg = _cd(T, maxiter=5, tol=1e-30) if algname == "cd" else nmfx.GreedyCD(T, maxiter=5, tol=1e-30)
+    W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+    r1 = nmfx.solve(alg, X, W1, H1)
+    with nmfx.Context(T, 200, 150, 6) as ctx:
+        ctx.set_X(X)
+        ctx.comm_init(nmfx.comm_unique_id(), 0, 1)
+        W2, H2 = W0.copy(order="F"), H0.copy(order="F")
+        r2 = nmfx.solve(alg, X, W2, H2, ctx=ctx)
+    assert r1.objvalue == r2.objvalue and np.array_equal(W1, W2) and np.array_equal(H1, H2)
+
+
+def test_nnmf_default_algorithm(built):
+    """nnmf's default alg is :greedycd (src/interf.jl:6)."""
+    X, _, _ = uniform(50, 70, 4, np.float64, seed=4)
+    r = nmfx.nnmf(X, 4, init="random", alg="greedycd", maxiter=30, rng=np.random.default_rng(0))
+    assert np.isfinite(r.objvalue) and (r.W >= 0).all() and (r.H >= 0).all()
+    r2 = nmfx.nnmf(X, 4, init="random", alg="cd", maxiter=30, seed=3, replicates=2)
+    assert np.isfinite(r2.objvalue)
+
+
+def test_k_limit(built):
+    X, W0, H0 = uniform(1100, 1100, 1030, np.float32, seed=1)
+    with pytest.raises(nmfx.NMFXError, match="k > 1024"):
+        nmfx.solve(nmfx.GreedyCD(np.float32, maxiter=2), X, W0, H0)

@@ -32,7 +32,28 @@ def test_nnmf_argument_errors():
     with pytest.raises(nmfx.ArgumentError, match="Invalid algorithm"):
         nmfx.nnmf(X, 2, alg="bogus")
     with pytest.raises(nmfx.ArgumentError, match="outside the accelerated hot path"):
-        nmfx.nnmf(X, 2, alg="greedycd")
+        nmfx.nnmf(X, 2, alg="spa")
+    with pytest.raises(nmfx.ArgumentError, match="outside the accelerated hot path"):
+        nmfx.nnmf(X, 2, init="nndsvdar", alg="greedycd")
+
+
+def test_coordinate_descent_option_structs():
+    """CoordinateDescentUpd's l1/l2 resolution (src/coorddesc.jl:62-82) and GreedyCD's validation (src/greedycd.jl:24-29)."""
+    c = nmfx.CoordinateDescent(np.float64, alpha=1e-2, l1ratio=0.25, regularization="both")
+    assert (c.l1_w, c.l2_w, c.l1_h, c.l2_h) == (0.0025, 0.0075, 0.0025, 0.0075) and abs(c.tol - 6.06e-6) < 1e-8
+    c = nmfx.CoordinateDescent(np.float64, alpha=1e-2, l1ratio=0.25, regularization="components")
+    assert (c.l1_w, c.l2_w) == (0.0, 0.0) and (c.l1_h, c.l2_h) == (0.0025, 0.0075)
+    c = nmfx.CoordinateDescent(np.float64, alpha=1e-2, l1ratio=0.25, regularization="transformation")
+    assert (c.l1_w, c.l2_w) == (0.0025, 0.0075) and (c.l1_h, c.l2_h) == (0.0, 0.0)
+    c = nmfx.CoordinateDescent(np.float32)
+    assert (c.l1_w, c.l2_w, c.l1_h, c.l2_h) == (0.0, 0.0, 0.0, 0.0) and c.maxiter == 100
+    with pytest.raises(nmfx.ArgumentError, match="shuffle"):
+        nmfx.CoordinateDescent(np.float32, shuffle=True)
+    g = nmfx.GreedyCD(np.float32)
+    assert g.lambda_w == 0 and g.lambda_h == 0 and abs(g.tol - 4.92e-3) < 1e-5
+    for bad in (dict(maxiter=1), dict(tol=0), dict(lambda_w=-1), dict(lambda_h=-1)):
+        with pytest.raises(nmfx.ArgumentError):
+            nmfx.GreedyCD(np.float32, **bad)
 
 
 def test_option_struct_defaults_and_validation():

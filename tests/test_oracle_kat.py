@@ -7,6 +7,8 @@ Reference tests ported (file:line under /root/reference/test):
   alspgrad.jl:3-25       sub-solver KATs + solve! smoke
   utils.jl:6-15,29-34,48-63   adddiag!, projectnn!, pdsolve!, pdrsolve!
   interf.jl:33-37        update_H=false leaves H untouched
+  coorddesc.jl:5-14      CoordinateDescent KATs (the shuffle = true one runs in component order: Julia's RNG is not available)
+  greedycd.jl:5-20       GreedyCD KATs (lambda_w, lambda_h in {0, 1e-5})
 """
 import numpy as np
 import pytest
@@ -57,6 +59,35 @@ def test_alspgrad_subsolver_kat(impl, T):
     assert r.niters >= 1 and np.isfinite(r.objvalue)
 
 
+@pytest.mark.parametrize("impl", ["numpy", "c"])
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_coorddesc_kat(impl, T):
+    """test/coorddesc.jl:5-14."""
+    rng = np.random.default_rng(2)
+    X, Wg, Hg = orc.laurberg6x3(0.3, T)
+    W = np.asfortranarray(Wg + rng.random(Wg.shape).astype(T) * T(0.1)); H = Hg.copy(order="F")
+    ORACLES[impl].solve("cd", X, W, H, orc.Opts(maxiter=1000, tol=1e-9))
+    assert np.allclose(X, W @ H, atol=1e-4, rtol=0)
+    W = np.asfortranarray(Wg + rng.random(Wg.shape).astype(T) * T(0.1)); H = Hg.copy(order="F")
+    # alpha = 1e-4, l1ratio = 0.5, regularization = :both  ->  l1 = l2 = 5e-5 on both sides (coorddesc.jl:62-82)
+    ORACLES[impl].solve("cd", X, W, H, orc.Opts(maxiter=1000, tol=1e-9, l1_w=5e-5, l2_w=5e-5, l1_h=5e-5, l2_h=5e-5))
+    assert np.allclose(X, W @ H, atol=1e-2, rtol=0)
+
+
+@pytest.mark.parametrize("impl", ["numpy", "c"])
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("lw", [0.0, 1e-5])
+@pytest.mark.parametrize("lh", [0.0, 1e-5])
+def test_greedycd_kat(impl, T, lw, lh):
+    """test/greedycd.jl:5-20."""
+    rng = np.random.default_rng(6)
+    X, Wg, Hg = orc.laurberg6x3(0.3, T)
+    W = np.asfortranarray(Wg + rng.random(Wg.shape).astype(T) * T(0.1)); H = Hg.copy(order="F")
+    ORACLES[impl].solve("greedycd", X, W, H, orc.Opts(maxiter=1000, tol=1e-9, lambda_w=lw, lambda_h=lh))
+    assert np.all(W >= 0) and np.all(H >= 0) and not np.isnan(W).any() and not np.isnan(H).any()
+    assert np.allclose(X, W @ H, atol=1e-3, rtol=0)
+
+
 def _pdmat(rng, n):
     g = rng.standard_normal((n, n))
     return np.asfortranarray(g.T @ g + 0.1 * np.eye(n))
@@ -98,7 +129,7 @@ def test_utils_kat_c():
 
 
 @pytest.mark.parametrize("impl", ["numpy", "c"])
-@pytest.mark.parametrize("alg", ["multmse", "multdiv", "projals", "alspgrad"])
+@pytest.mark.parametrize("alg", ["multmse", "multdiv", "projals", "alspgrad", "cd", "greedycd"])
 def test_update_H_false_keeps_H(impl, alg):
     rng = np.random.default_rng(4)
     T = np.float64
@@ -125,10 +156,10 @@ def test_stop_condition_agrees():
             assert co.stop_condition(W, pW, H, pH, tol) == expect
 
 
-@pytest.mark.parametrize("T,lims", [(np.float64, (1e-12, 1e-12, 1e-9, 1e-9)), (np.float32, (2e-6, 2e-6, 2e-3, 1e-3))])
+@pytest.mark.parametrize("T,lims", [(np.float64, (1e-12, 1e-12, 1e-9, 1e-9, 1e-12, 1e-11)), (np.float32, (2e-6, 2e-6, 2e-3, 1e-3, 1e-4, 2e-3))])
 def test_two_restatements_agree(T, lims):
     """The C and NumPy restatements are independent (own GEMM / Cholesky / reductions vs BLAS / LAPACK)."""
-    for alg, lim in zip(("multmse", "multdiv", "projals", "alspgrad"), lims):
+    for alg, lim in zip(("multmse", "multdiv", "projals", "alspgrad", "cd", "greedycd"), lims):
         X, W0, H0 = planted(33, 47, 4, T, seed=77, normalize=(alg != "projals"))
         extra = dict(lambda_w=0.05, lambda_h=0.05) if alg == "projals" else {}
         o = orc.Opts(maxiter=15, tol=1e-30, track_objective=True, **extra)

@@ -106,6 +106,70 @@ __global__ __launch_bounds__(256) void cd_sweep_kernel(SampleView<const T> Wold,
         }
 }
 
+// Same sweep, 16 lanes per sample row (4 rows per wavefront): lane l of a row's group holds the KPL = K/16 consecutive
+// components l*KPL .. l*KPL+KPL-1, so a Gram row is fetched with 16-byte loads, the dot product needs only a 4-step
+// butterfly, and the four rows of a wave share every shuffle instruction (the 64-lane form above spends most of its
+// issue slots in six-step reductions, one per row: 435 -> see DESIGN.md for the measured figure).  P must be K x K with
+// zero padding (it is: Gram of zero-padded factors), so rows are read unguarded.
+template <typename T, int KPLMAX>
+__global__ __launch_bounds__(256) void cd_sweep16_kernel(SampleView<const T> Wold, SampleView<T> Wnew, SampleView<const T> Z,
+                                                         const T *__restrict__ P, int64_t ldp, int64_t nsamples, int k, int kpl, T l1,
+                                                         const int *done) {
+    NMFX_DONE_GUARD(done);
+    constexpr int VEC = 16 / sizeof(T);
+    using vec_t = T __attribute__((ext_vector_type(VEC)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, l = lane & 15;
+    const int64_t i = ((int64_t)blockIdx.x * 4 + wave) * 4 + g;
+    const bool live = i < nsamples;
+    T w[KPLMAX], z[KPLMAX];
+#pragma unroll
+    for (int s = 0; s < KPLMAX; ++s) {
+        const int c = l * kpl + s;
+        const bool ok = live && (s < kpl) && (c < k);
+        w[s] = ok ? Wold.at(i, c) : (T)0;
+        z[s] = ok ? (T)(Z.at(i, c) - l1) : (T)0;
+    }
+    for (int lt = 0; lt < 16; ++lt) {
+        if (lt * kpl >= k) break;
+#pragma unroll
+        for (int s = 0; s < KPLMAX; ++s) {
+            const int t = lt * kpl + s;
+            if (s < kpl && t < k) {
+                T a[KPLMAX];
+                const T *prow = P + (int64_t)t * ldp + l * kpl;
+#pragma unroll
+                for (int v = 0; v < KPLMAX; v += VEC) {
+                    if (v < kpl) {
+                        const vec_t pv = *reinterpret_cast<const vec_t *>(prow + v);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) a[v + e] = pv[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) a[v + e] = (T)0;
+                    }
+                }
+                T part = (T)0;
+#pragma unroll
+                for (int v = 0; v < KPLMAX; ++v) part += a[v] * w[v];
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 16);
+                const T hess = __shfl(a[s], lt, 16);
+                const T grad = part - __shfl(z[s], lt, 16);
+                const T wt = __shfl(w[s], lt, 16);
+                T nw = wt - grad / hess;
+                nw = (nw > (T)0) ? nw : ((nw != nw) ? nw : (T)0);
+                if (hess != (T)0 && l == lt) w[s] = nw;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < KPLMAX; ++s) {
+        const int c = l * kpl + s;
+        if (live && (s < kpl) && (c < k)) Wnew.at(i, c) = w[s];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // GreedyCD (src/greedycd.jl:91-163).  Per sample row i (registers: W, G, S, D rows):
 //     S(r) = max(0, W(r) - G(r)/(eps + P(r,r))) - W(r);   D(r) = -G(r) S(r) - 0.5 P(r,r) S(r)^2        (:120-125, :150-153)

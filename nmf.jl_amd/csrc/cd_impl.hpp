@@ -21,6 +21,31 @@ template <typename T> template <typename F> void Solver<T>::with_kmax(F &&f) {
 // ---------------------------------------------------------------------------
 // CoordinateDescent
 // ---------------------------------------------------------------------------
+template <typename T>
+void Solver<T>::cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> Num, const T *Pm, int64_t nsamples, T l1,
+                         const int *done) {
+    const int kpl = (int)(K / 16);                       // K is 64 or a multiple of 128: kpl is a multiple of 4
+    const int reg_budget = (sizeof(T) == 4) ? 32 : 16;   // components per lane kept in registers (w, z, a: 3 arrays)
+    if (kpl <= reg_budget) {
+        const unsigned blocks = (unsigned)((nsamples + 15) / 16);
+        auto launch = [&](auto KP) {
+            constexpr int KPLMAX = decltype(KP)::value;
+            hipLaunchKernelGGL((cd_sweep16_kernel<T, KPLMAX>), dim3(blocks), dim3(256), 0, stream, Zo, Zn, Num, Pm, K, nsamples, (int)k, kpl,
+                               l1, done);
+        };
+        if (kpl <= 4) launch(std::integral_constant<int, 4>{});
+        else if (kpl <= 8) launch(std::integral_constant<int, 8>{});
+        else if (kpl <= 16) launch(std::integral_constant<int, 16>{});
+        else if constexpr (sizeof(T) == 4) launch(std::integral_constant<int, 32>{});   // (<double, 32> is never needed -- and never instantiated: it sends the register allocator into a minutes-long spin)
+    } else {
+        with_kmax([&](auto KM) {
+            constexpr int KMAX = decltype(KM)::value, R = (KMAX <= 4) ? 4 : 2;
+            const unsigned blocks = (unsigned)((nsamples + 4 * R - 1) / (4 * R));
+            hipLaunchKernelGGL((cd_sweep_kernel<T, KMAX, R>), dim3(blocks), dim3(256), 0, stream, Zo, Zn, Num, Pm, K, nsamples, (int)k, l1, done);
+        });
+    }
+}
+
 template <typename T> void Solver<T>::enqueue_cd(const nmfx_opts &o, long long t) {
     (void)t;
     const int *done = done_flag();
@@ -33,12 +58,7 @@ template <typename T> void Solver<T>::enqueue_cd(const nmfx_opts &o, long long t
         if (o.l2_w > 0)   // :118-120
             hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, gramH_p, K, (int)k, (T)o.l2_w, done);
         timed("cd_sweep_W", 2.0 * p * k * k, 3.0 * P * K * sizeof(T), [&] {
-            with_kmax([&](auto KM) {
-                constexpr int KMAX = decltype(KM)::value, R = (KMAX <= 4) ? 4 : 2;
-                const unsigned blocks = (unsigned)((p + 4 * R - 1) / (4 * R));
-                hipLaunchKernelGGL((cd_sweep_kernel<T, KMAX, R>), dim3(blocks), dim3(256), 0, stream, SampleView<const T>{Wo, 1, P},
-                                   SampleView<T>{Wn, 1, P}, SampleView<const T>{numW_p, 1, P}, gramH_p, K, p, (int)k, (T)o.l1_w, done);
-            });
+            cd_sweep(SampleView<const T>{Wo, 1, P}, SampleView<T>{Wn, 1, P}, SampleView<const T>{numW_p, 1, P}, gramH_p, p, (T)o.l1_w, done);
             HIP_TRY(hipGetLastError());
         });
         stats_w(Wn, Wo, done);
@@ -52,12 +72,7 @@ template <typename T> void Solver<T>::enqueue_cd(const nmfx_opts &o, long long t
         if (o.l2_h > 0)
             hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, gramW_p, K, (int)k, (T)o.l2_h, done);
         timed("cd_sweep_H", 2.0 * n * k * k, 3.0 * K * N * sizeof(T), [&] {
-            with_kmax([&](auto KM) {
-                constexpr int KMAX = decltype(KM)::value, R = (KMAX <= 4) ? 4 : 2;
-                const unsigned blocks = (unsigned)((n + 4 * R - 1) / (4 * R));
-                hipLaunchKernelGGL((cd_sweep_kernel<T, KMAX, R>), dim3(blocks), dim3(256), 0, stream, SampleView<const T>{Ho, K, 1},
-                                   SampleView<T>{Hn, K, 1}, SampleView<const T>{numH_p, K, 1}, gramW_p, K, n, (int)k, (T)o.l1_h, done);
-            });
+            cd_sweep(SampleView<const T>{Ho, K, 1}, SampleView<T>{Hn, K, 1}, SampleView<const T>{numH_p, K, 1}, gramW_p, n, (T)o.l1_h, done);
             HIP_TRY(hipGetLastError());
         });
         stats_h(Hn, Ho, done);

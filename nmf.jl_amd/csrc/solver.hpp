@@ -582,6 +582,7 @@ template <typename T> class Solver : public SolverBase {
     void enqueue_cd(const nmfx_opts &o, long long t);
     void enqueue_greedycd(const nmfx_opts &o, long long t);
     template <typename F> void with_kmax(F &&f);
+    void cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> Num, const T *Pm, int64_t nsamples, T l1, const int *done);
     void greedy_side(const char *tag, SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> G, const T *Pm, int64_t nsamples,
                      T lambda, bool sharded_samples, const int *done);
     void allreduce_hstat(const int *done) {   // CD order: H is updated AFTER the packed W-side all-reduce

@@ -13,6 +13,73 @@ def _stats(new, old, axis):
     return d, s
 
 
+def _cd_rows(Wv, P, Z):
+    """cd sweep of every sample row (rows of Wv), components in order (coorddesc.jl:133-156)."""
+    T = Wv.dtype.type
+    for t in range(P.shape[0]):
+        grad = Wv @ P[t] - Z[:, t]
+        if P[t, t] != 0:
+            Wv[:, t] = np.maximum(Wv[:, t] - grad / P[t, t], T(0))
+
+
+def _greedy_rows(Wv, P, G, lam, allmax):
+    """greedy sweep of every sample row (greedycd.jl:117-158); `allmax` reduces p_init over the ranks that share the rows."""
+    T = Wv.dtype.type
+    k = P.shape[0]
+    e = T(np.finfo(T).eps)
+    prr = np.diag(P).copy()
+    G = G + T(lam) if lam > 0 else G.copy()
+
+    def sd(w, g):
+        s = np.maximum(T(0), w - g / (e + prr)) - w
+        return s, -g * s - (T(0.5) * prr) * (s * s)
+
+    S, D = sd(Wv, G)
+    q = np.argmax(D, axis=1)
+    p_init = allmax(max(T(-1.0), D[np.arange(len(q)), q].max()))
+    out = Wv.copy()
+    for i in range(Wv.shape[0]):
+        w, g = Wv[i].copy(), G[i].copy()
+        s, d = S[i].copy(), D[i].copy()
+        qi = int(q[i])
+        wn = np.zeros(k, T)
+        for _ in range(k * k):
+            if d[qi] < T(0.001) * p_init:
+                break
+            wn[qi] += s[qi]
+            g = g + s[qi] * P[qi]
+            s, d = sd(w, g)
+            qi = int(np.argmax(d))
+        out[i] = np.maximum(w + wn, T(0))
+    Wv[...] = out
+
+
+def step_cd(alg, Xg, W, Hg, lam_w, lam_h, allreduce, allmax, update_H=True):
+    """CoordinateDescent (no regularisation) / GreedyCD: W FIRST from the all-reduced [X_g H_g' | H_g H_g'], then the local
+    H columns from the new W; GreedyCD's H-side p_init is a max over ALL columns -> one max all-reduce."""
+    T = Xg.dtype.type
+    k = W.shape[1]
+    preW, preH = W.copy(), Hg.copy()
+    pack = allreduce(np.concatenate([(Xg @ Hg.T).ravel(order="F"), (Hg @ Hg.T).ravel(order="F")]))
+    XHt = pack[: W.size].reshape(W.shape, order="F")
+    HHt = pack[W.size:].reshape((k, k), order="F")
+    if alg == "cd":
+        _cd_rows(W, HHt, XHt)
+    else:
+        _greedy_rows(W, HHt, W @ HHt - XHt, lam_w, lambda v: v)          # rows of W are replicated: local max is global
+    if update_H:
+        WtW, XtW = W.T @ W, Xg.T @ W
+        Ht = Hg.T                                                         # view
+        if alg == "cd":
+            _cd_rows(Ht, WtW, XtW)
+        else:
+            _greedy_rows(Ht, WtW, Ht @ WtW - XtW, lam_h, allmax)
+    dh, sh = _stats(Hg, preH, 1)
+    hs = allreduce(np.concatenate([dh, sh]))
+    dw, sw = _stats(W, preW, 0)
+    return dw, sw, hs[:k], hs[k:]
+
+
 def step(alg, Xg, W, Hg, lam_w, lam_h, delta, allreduce, update_H=True):
     T = Xg.dtype.type
     k = W.shape[1]

@@ -1,8 +1,8 @@
 """N>1 path on CPU: world_size=2 over gloo.
 
 What this pins without a GPU: (1) the column-sharded Gram-form formulation with ONE packed all-reduce per outer
-iteration reproduces the unsharded reference trajectory (oracle) for multmse / multdiv / projals, including ragged
-shards; (2) the host plumbing the GPU path uses (shard_range, packed layout, unique-id broadcast) under a real
+iteration reproduces the unsharded reference trajectory (oracle) for multmse / multdiv / projals / cd / greedycd (the
+last with its max all-reduce of p_init on the sharded H side), including ragged shards; (2) the host plumbing the GPU path uses (shard_range, packed layout, unique-id broadcast) under a real
 process group.  The RCCL call itself is exercised on the GPU box with nranks=1 (tests/test_gpu_comm.py) and on
 8 GPUs by the driver's scaling bench."""
 import os
@@ -51,11 +51,19 @@ def _worker(rank, world, port, alg, T_name, q):
     # unique-id broadcast used by nmfx.dist.init_comm (payload is opaque bytes)
     uid = nmfx.dist.broadcast_unique_id(lambda: bytes(range(128)))
     assert uid == bytes(range(128))
-    lam = 0.05 if alg == "projals" else 1e-4
+    def allmax(v):
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return T(t.item())
+
+    lam = 0.05 if alg == "projals" else (0.0 if alg in ("cd", "greedycd") else 1e-4)
     o = orc.resolve_opts(orc.ALG_NAMES[alg], T, orc.Opts(lambda_w=lam, lambda_h=lam))
     trace = [sm.objective(alg, Xg, W, Hg, allreduce)]
     for _ in range(6):
-        sm.step(alg, Xg, W, Hg, o.lambda_w, o.lambda_h, o.delta, allreduce)
+        if alg in ("cd", "greedycd"):
+            sm.step_cd(alg, Xg, W, Hg, o.lambda_w, o.lambda_h, allreduce, allmax)
+        else:
+            sm.step(alg, Xg, W, Hg, o.lambda_w, o.lambda_h, o.delta, allreduce)
         trace.append(sm.objective(alg, Xg, W, Hg, allreduce))
     Hs = [None] * world
     dist.all_gather_object(Hs, (c0, c1, Hg))
@@ -65,7 +73,7 @@ def _worker(rank, world, port, alg, T_name, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("alg", ["multmse", "multdiv", "projals"])
+@pytest.mark.parametrize("alg", ["multmse", "multdiv", "projals", "cd", "greedycd"])
 def test_sharded_formulation_matches_unsharded_reference(alg):
     T = np.float64
     ctx = mp.get_context("spawn")
@@ -79,7 +87,7 @@ def test_sharded_formulation_matches_unsharded_reference(alg):
         pr.join(timeout=60)
         assert pr.exitcode == 0
     X, W0, H0 = planted(37, 53, 4, T, seed=11, normalize=(alg != "projals"))
-    lam = 0.05 if alg == "projals" else 1e-4
+    lam = 0.05 if alg == "projals" else (0.0 if alg in ("cd", "greedycd") else 1e-4)
     Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
     ro = orc.solve(alg, X, Wc, Hc, orc.Opts(maxiter=6, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
     ref = np.array(ro.trace)

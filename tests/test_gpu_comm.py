@@ -34,3 +34,12 @@ def test_nranks1_comm_is_identity(built, alg_name):
     assert r0.niters == r1.niters
     assert np.array_equal(r0.trace, r1.trace)
     assert np.array_equal(W0_, W1) and np.array_equal(H0_, H1)
+
+
+def test_leading_dimension_limit(built):
+    """The fused epilogues address a wave tile with 32-bit byte offsets: 256 * ld * sizeof(T) must stay below 2^32
+     -- a larger p is refused up front with NMFX_ERR_UNSUPPORTED, before anything is allocated."""
+    with pytest.raises(nmfx.NMFXError, match="too large"):
+        nmfx.Context(np.float32, 4_194_304, 2, 2)
+    with pytest.raises(nmfx.NMFXError, match="too large"):
+        nmfx.Context(np.float64, 2_097_152, 2, 2)

@@ -118,3 +118,72 @@ def test_c3_multdiv_properties(built):
         t = np.where(pos, X * np.log(np.where(pos, X, 1) / WH) - X + WH, WH)
         ref = float(np.sum(t.astype(np.float64)))
         assert abs(trace[3] - ref) <= 2e-5 * abs(ref)
+
+
+def _cd_row_sweep(Wrows, P, Z):
+    """fp64 restatement of the CD sweep (coorddesc.jl:133-156) for a SAMPLE of rows: rows do not interact."""
+    W = Wrows.copy()
+    for t in range(P.shape[0]):
+        grad = W @ P[t] - Z[:, t]
+        if P[t, t] != 0:
+            W[:, t] = np.maximum(W[:, t] - grad / P[t, t], 0.0)
+    return W
+
+
+@pytest.mark.parametrize("alg", ["cd", "greedycd"])
+def test_c2_coordinate_descent_pieces(built, alg):
+    """C2 size (4096 x 4096, k = 64), f64.  Size-independent pieces of one outer iteration: the sweep of a sample row depends
+    only on that row of W (or column of H), the k x k Gram and the row of the numerator (plus, for GreedyCD, the global
+    scalar p_init, which a vectorised NumPy pass over all rows provides)."""
+    T = np.float64
+    p = n = 4096
+    k = 64
+    X, W0, H0 = planted(p, n, k, T, seed=77)
+    inst = nmfx.CoordinateDescent(T, maxiter=2, tol=1e-30) if alg == "cd" else nmfx.GreedyCD(T, maxiter=2, tol=1e-30)
+    algid = inst._alg()
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+        res, trace = ctx.solve(algid, nmfx.make_opts(T, maxiter=1, tol=1e-30, track_objective=True), W1, H1)
+        assert res.niters == 1
+        I = np.random.default_rng(0).choice(p, 24, replace=False)
+        J = np.random.default_rng(1).choice(n, 24, replace=False)
+        HHt, XHt = H0 @ H0.T, X @ H0.T
+        WtW, XtW = W1.T @ W1, X.T @ W1
+        if alg == "cd":
+            Wref = _cd_row_sweep(W0[I], HHt, XHt[I])
+            Href = _cd_row_sweep(H0.T[J], WtW, XtW[J]).T
+        else:
+            eps = np.finfo(T).eps
+
+            def sweep(Wv, P, Z, rows):
+                G = Wv @ P - Z
+                prr = np.diag(P)
+                S = np.maximum(0.0, Wv - G / (eps + prr)) - Wv
+                D = -G * S - (0.5 * prr) * (S * S)
+                p_init = max(-1.0, D.max(axis=1).max())
+                out = []
+                for i in rows:
+                    w, g = Wv[i].copy(), G[i].copy()
+                    wn = np.zeros(k)
+                    for _ in range(k * k):
+                        s = np.maximum(0.0, w - g / (eps + prr)) - w
+                        d = -g * s - (0.5 * prr) * (s * s)
+                        q = int(np.argmax(d))
+                        if d[q] < 0.001 * p_init:
+                            break
+                        wn[q] += s[q]
+                        g = g + s[q] * P[q]
+                    out.append(np.maximum(w + wn, 0.0))
+                return np.array(out)
+
+            Wref = sweep(W0, HHt, XHt, I)
+            Href = sweep(np.ascontiguousarray(H0.T), WtW, XtW, J).T
+        assert np.max(np.abs(W1[I] - Wref)) <= 1e-9 * max(1.0, np.max(np.abs(Wref)))
+        assert np.max(np.abs(H1[:, J] - Href)) <= 1e-9 * max(1.0, np.max(np.abs(Href)))
+        ref_obj = 0.5 * float(np.sum((X - W1 @ H1) ** 2))
+        assert abs(trace[1] - ref_obj) <= 1e-10 * ref_obj
+        assert np.all(W1 >= 0) and np.all(H1 >= 0)
+        # exact coordinate minimisation never increases the objective
+        res, tr2 = ctx.solve(algid, nmfx.make_opts(T, maxiter=4, tol=1e-30, track_objective=True), W1, H1)
+        assert np.all(np.diff(tr2[: res.niters + 1]) <= 1e-12 * tr2[0])

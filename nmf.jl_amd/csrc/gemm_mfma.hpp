@@ -416,15 +416,17 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
         // kg&1 while the ds_reads of group kg+1 (issued behind the first MFMA pair) fill the other set, so an LDS round
         // trip (~130-200 cycles for four b128 reads) is covered by ~14 MFMAs instead of 2.  The first group of the next
         // tile is fetched right behind the barrier that publishes it, in front of the last group's MFMAs.
-        // f64 (FDB = false) keeps ONE set plus the carried first-group set: its wave tile needs 2-3x the fragment registers
-        // (16x16 MFMA tiles) and the second set cost the fused f64 kernels a wave per SIMD for no measurable gain; there
-        // group kg > 0 reads its own fragments at the start of the group (set 0) and group 0 runs on the carried set 1.
+        // f64 (FDB = false) keeps ONE set: its wave tile needs 2-3x the fragment registers (16x16 MFMA tiles), and both the
+        // second set and the carried first-group set were measured as net losses there -- without them the 128 x 128 f64
+        // kernel fits two waves per SIMD (123 + 128 registers) and runs 2-4 % faster; every k-group reads its own
+        // fragments at the start of the group.
         constexpr bool FDB = (sizeof(T) == 4);
+        constexpr bool CARRY = FDB;   // first-group fragments of the next tile fetched behind the barrier
         T af[2][TR][M::VEC], bf[2][TC][M::VEC];
 #pragma unroll
-        for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[FDB ? 0 : 1][i], smem, wr * WTR + i * MT, 0, lane);
+        for (int i = 0; i < TR; ++i) if constexpr (CARRY) read_frag<T, LA, BR, NT>(af[FDB ? 0 : 1][i], smem, wr * WTR + i * MT, 0, lane);
 #pragma unroll
-        for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[FDB ? 0 : 1][j], smem + BR * BK, wc * WTC + j * MT, 0, lane);
+        for (int j = 0; j < TC; ++j) if constexpr (CARRY) read_frag<T, LB, BC, NT>(bf[FDB ? 0 : 1][j], smem + BR * BK, wc * WTC + j * MT, 0, lane);
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
             const T *a_s = smem + cur * STAGE, *b_s = a_s + BR * BK;
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
             static_for<NG>([&](auto KGC) {
                 constexpr int kg = decltype(KGC)::value;
                 constexpr bool last = (kg == NG - 1);
-                constexpr int fc = FDB ? (kg & 1) : (kg == 0 ? 1 : 0);   // set the MFMAs of this group read
+                constexpr int fc = FDB ? (kg & 1) : ((kg == 0 && CARRY) ? 1 : 0);   // set the MFMAs of this group read
                 constexpr int fn = FDB ? (fc ^ 1) : 1;                    // set the next group's / next tile's first fragments go to
                 constexpr bool stA = (kg == 0), stB = (kg == (NG > 2 ? 1 : 0));
                 // (issuing the global loads one k-group earlier, right behind their ds_write, measured no faster: the loads
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
 #pragma unroll
                     for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[fn][j], b_s, wc * WTC + j * MT, kg + 1, lane);
                 }
-                if constexpr (!FDB && kg != 0) {
+                if constexpr (!FDB && (kg != 0 || !CARRY)) {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[0][i], a_s, wr * WTR + i * MT, kg, lane);
 #pragma unroll
@@ -459,9 +461,9 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
                     // then fetch its first fragments while the MFMAs below still run on tile t's registers
                     __syncthreads();
 #pragma unroll
-                    for (int i = 0; i < TR; ++i) read_frag<T, LA, BR, NT>(af[fn][i], a_n, wr * WTR + i * MT, 0, lane);
+                    for (int i = 0; i < TR; ++i) if constexpr (CARRY) read_frag<T, LA, BR, NT>(af[fn][i], a_n, wr * WTR + i * MT, 0, lane);
 #pragma unroll
-                    for (int j = 0; j < TC; ++j) read_frag<T, LB, BC, NT>(bf[fn][j], b_n, wc * WTC + j * MT, 0, lane);
+                    for (int j = 0; j < TC; ++j) if constexpr (CARRY) read_frag<T, LB, BC, NT>(bf[fn][j], b_n, wc * WTC + j * MT, 0, lane);
                 }
                 if constexpr (ldA) LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, kn, tid, g.a_aux, xalpha);
                 if constexpr (ldB) LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, kn, tid, g.b_aux, xalpha);
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
                 constexpr int NW = (NW0 <= ROOM) ? NW0 : ROOM;
                 constexpr int NL = (NW + NL0 <= ROOM) ? NL0 : (ROOM - NW);
                 if constexpr (LEAD > 0) __builtin_amdgcn_sched_group_barrier(0x8, LEAD, 0);
-                if constexpr (FDB || kg != 0) __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
+                if constexpr (FDB || kg != 0 || !CARRY) __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
                 sched_pairs<0x200, NW>();
                 sched_pairs<0x20, NL>();
                 if constexpr (NMFMA - LEAD - 2 * (NW + NL) > 0)

@@ -144,11 +144,20 @@ int nmfx_alspgrad_subsolve(nmfx_ctx *ctx, int which, const nmfx_opts *opts, void
  *                         global column of this context's shard), so a sharded run draws the same global matrices.
  *   nmfx_solve_replicates solve_replicates!, src/interf.jl:85-101: replicate 1 solves from the given W, H; replicates
  *                         2..R from randinit(seed + r - 1, normalize = 1, zeroh); the result with the strictly smallest
- *                         objvalue wins and is returned in W, H / *out; *best_replicate (nullable) = its 1-based index. */
+ *                         objvalue wins and is returned in W, H / *out; *best_replicate (nullable) = its 1-based index.
+ *   nmfx_nndsvd           the part of nndsvd() (src/initialization.jl:74-101) behind `U, s, V = ...`: _nndsvd! (:26-72) with
+ *                         posnegnorm / scalepos! / scaleneg! (:103-137) on the device, filling the resident W (p x k) and
+ *                         H (k x n_local; zeros when zeroh).  U is p x k (ld p), s has k entries, V is n_local x k (ld
+ *                         n_local), all host, type T: the truncated SVD stays with the caller (the reference's
+ *                         RandomizedLinAlg.rsvd, or its `initdata`).  variant 0/1/2 = :std / :a / :ar; :a and :ar fill with
+ *                         mean(X) resp. mean(X)*0.01 (X must be resident; n_total = global column count for the mean),
+ *                         :ar multiplies by one Philox uniform per component (Julia's rand stream is not reproducible). */
 int nmfx_check_nonneg(nmfx_ctx *ctx, int which, int *all_nonneg);
 int nmfx_randinit(nmfx_ctx *ctx, uint64_t seed, int normalize, int zeroh, int64_t h_col_offset);
 int nmfx_solve_replicates(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, int replicates, uint64_t seed, int zeroh,
                           int64_t h_col_offset, void *W_host, void *H_host, nmfx_result *out, int *best_replicate);
+int nmfx_nndsvd(nmfx_ctx *ctx, const void *U_host, const void *s_host, const void *V_host, int variant, int zeroh, uint64_t seed,
+                int64_t n_total);
 
 /* ---- multi-GPU (column sharding, one process per GPU) -----------------------
  * The reference has no distributed path; this is the build's data-parallel extension.

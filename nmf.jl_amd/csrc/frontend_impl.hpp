@@ -120,6 +120,131 @@ template <typename T> void Solver<T>::randinit(uint64_t seed, bool normalize, bo
     have_F = true;
 }
 
+// ---------------------------------------------------------------------------
+// NNDSVD from a given truncated SVD (src/initialization.jl:26-101): the part of nndsvd() behind `U, s, V = ...`.  The SVD
+// itself (RandomizedLinAlg.rsvd, or the caller's `initdata`) stays with the host; _nndsvd! -- two column-norm passes and
+// one elementwise fill over the p x k and n x k factors -- runs here, next to the resident X whose mean the :a / :ar
+// variants need.
+// ---------------------------------------------------------------------------
+// out[2*j + {0,1}] = sum of squares of the positive / non-positive entries of column j (posnegnorm, :103-115); one block per column
+template <typename T> __global__ void posneg_sumsq_kernel(const T *A, int64_t rows, int64_t ld, double *out) {
+    __shared__ double sp[4], sn[4];
+    const T *col = A + (int64_t)blockIdx.x * ld;
+    double pn = 0.0, nn = 0.0;
+    for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) {
+        const T x = col[i];
+        const double q = (double)(T)(x * x);
+        if (x > (T)0) pn += q; else nn += q;
+    }
+    for (int off = 32; off > 0; off >>= 1) { pn += __shfl_down(pn, off, 64); nn += __shfl_down(nn, off, 64); }
+    if ((threadIdx.x & 63) == 0) { sp[threadIdx.x >> 6] = pn; sn[threadIdx.x >> 6] = nn; }
+    __syncthreads();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = sp[0] + sp[1] + sp[2] + sp[3]; out[2 * blockIdx.x + 1] = sn[0] + sn[1] + sn[2] + sn[3]; }
+}
+
+// partial[block] = sum of the logical rows x cols block of X (for mean(X), :41-42)
+template <typename T> __global__ void sum_block_kernel(const T *A, int64_t rows, int64_t cols, int64_t ld, double *partial) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < rows * cols; e += (int64_t)gridDim.x * blockDim.x)
+        s += (double)A[(e % rows) + (e / rows) * ld];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// per component j (:44-72): which sign pattern wins, the two scale factors and the fill value.
+// coef[4*j + {0,1,2,3}] = { cW, cH, sign (+1 / -1), vj }
+template <typename T>
+__global__ void nndsvd_coef_kernel(const double *unorm, const double *vnorm, const T *sv, const double *xsum, int nsum, double count,
+                                   int variant, uint64_t seed, int k, T *coef) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    double tot = 0.0;
+    for (int i = 0; i < nsum; ++i) tot += xsum[i];
+    const double mean = tot / count;
+    const T v0 = (variant == 0) ? (T)0 : (variant == 1) ? (T)mean : (T)(mean * 0.01);   // :41-42
+    const T xp = sqrt((T)unorm[2 * j]), xn = sqrt((T)unorm[2 * j + 1]);                   // posnegnorm in T
+    const T yp = sqrt((T)vnorm[2 * j]), yn = sqrt((T)vnorm[2 * j + 1]);
+    const T mp = xp * yp, mn = xn * yn;                                                    // :49-50
+    T vj = v0;
+    if (variant == 2) {                                                                    // :52-55  vj *= rand(T)
+        uint32_t w[4];
+        philox4x32_10((uint32_t)j, 0u, 2u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        vj = vj * philox_u01<T>(w);
+    }
+    if (mp >= mn) {                                                                        // :58-61
+        const T ss = sqrt(sv[j] * mp);
+        coef[4 * j] = ss / xp; coef[4 * j + 1] = ss / yp; coef[4 * j + 2] = (T)1;
+    } else {                                                                               // :62-65
+        const T ss = sqrt(sv[j] * mn);
+        coef[4 * j] = ss / xn; coef[4 * j + 1] = ss / yn; coef[4 * j + 2] = (T)-1;
+    }
+    coef[4 * j + 3] = vj;
+}
+
+// scalepos! / scaleneg! (:117-137): dst(i, j) = x > 0 ? x*c : v0   or   x < 0 ? -(x*c) : v0.
+// src is rows x k column-major (ld_src); dst element (i, j) at dst[i*ds_i + j*ds_j] (W: 1, P;  H from V: K, 1)
+template <typename T>
+__global__ void nndsvd_fill_kernel(const T *src, int64_t rows, int64_t ld_src, int k, const T *coef, int which, T *dst, int64_t ds_i,
+                                   int64_t ds_j) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * k) return;
+    const int64_t i = e % rows;
+    const int j = (int)(e / rows);
+    const T x = src[i + (int64_t)j * ld_src];
+    const T c = coef[4 * j + which], sg = coef[4 * j + 2], v0 = coef[4 * j + 3];
+    T y;
+    if (sg > (T)0) y = (x > (T)0) ? x * c : v0;
+    else y = (x < (T)0) ? -(x * c) : v0;
+    dst[i * ds_i + (int64_t)j * ds_j] = y;
+}
+
+template <typename T>
+void Solver<T>::nndsvd_init(const void *U_host, const void *s_host, const void *V_host, int variant, bool zeroh, uint64_t seed,
+                            int64_t n_total) {
+    if (variant < 0 || variant > 2) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for variant"};
+    if (variant != 0 && !have_X) throw StatusError{NMFX_ERR_STATE, "variants :a / :ar need mean(X): upload X first (nmfx_set_X)"};
+    if (n_total < n) throw StatusError{NMFX_ERR_BAD_ARG, "n_total must be the global column count (>= n_local)"};
+    HIP_TRY(hipSetDevice(device));
+    work[4].ensure((size_t)p * k);
+    work[5].ensure((size_t)n * k);
+    work[6].ensure((size_t)5 * k);
+    T *Ud = work[4].p, *Vd = work[5].p, *sd = work[6].p, *coef = work[6].p + k;
+    const int nsum = 1024;
+    nd_scratch.ensure((size_t)4 * k + nsum);
+    double *unorm = nd_scratch.p, *vnorm = nd_scratch.p + 2 * k, *xsum = nd_scratch.p + 4 * k;
+    HIP_TRY(hipMemcpyAsync(Ud, U_host, (size_t)p * k * sizeof(T), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(Vd, V_host, (size_t)n * k * sizeof(T), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(sd, s_host, (size_t)k * sizeof(T), hipMemcpyHostToDevice, stream));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMemsetAsync(W[i].p, 0, W[i].count * sizeof(T), stream));
+        HIP_TRY(hipMemsetAsync(H[i].p, 0, H[i].count * sizeof(T), stream));
+    }
+    hipLaunchKernelGGL(posneg_sumsq_kernel<T>, dim3((unsigned)k), dim3(256), 0, stream, Ud, p, p, unorm);
+    hipLaunchKernelGGL(posneg_sumsq_kernel<T>, dim3((unsigned)k), dim3(256), 0, stream, Vd, n, n, vnorm);
+    HIP_TRY(hipMemsetAsync(xsum, 0, nsum * sizeof(double), stream));
+    if (variant != 0) hipLaunchKernelGGL(sum_block_kernel<T>, dim3(nsum), dim3(256), 0, stream, X.p, p, n, P, xsum);
+    if (nranks > 1) {   // V rows (= columns of X, H) are sharded: the norms of V's columns and sum(X) are global quantities
+        RCCL_TRY(ncclGroupStart());
+        RCCL_TRY(ncclAllReduce(vnorm, vnorm, (size_t)2 * k, ncclDouble, ncclSum, comm, stream));
+        RCCL_TRY(ncclAllReduce(xsum, xsum, (size_t)nsum, ncclDouble, ncclSum, comm, stream));
+        RCCL_TRY(ncclGroupEnd());
+    }
+    hipLaunchKernelGGL(nndsvd_coef_kernel<T>, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, stream, unorm, vnorm, sd, xsum, nsum,
+                       (double)p * (double)n_total, variant, seed, (int)k, coef);
+    hipLaunchKernelGGL(nndsvd_fill_kernel<T>, dim3((unsigned)((p * k + 255) / 256)), dim3(256), 0, stream, Ud, p, p, (int)k, coef, 0,
+                       W[0].p, (int64_t)1, P);
+    if (!zeroh)
+        hipLaunchKernelGGL(nndsvd_fill_kernel<T>, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, stream, Vd, n, n, (int)k, coef, 1,
+                           H[0].p, K, (int64_t)1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    wcur = hcur = 0;
+    have_F = true;
+}
+
 // solve_replicates! (src/interf.jl:85-101): replicate 1 starts from the caller's W, H; replicates 2..R from fresh
 // randinit(normalize = true, zeroh) draws (seed + r - 1); the result with the smallest objective is kept
 // (`if minobjv > tmp.objvalue`, strictly smaller, so ties keep the earlier one).  X stays resident; the best factors are

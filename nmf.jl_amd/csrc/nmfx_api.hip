@@ -159,6 +159,12 @@ int nmfx_solve_replicates(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, int rep
     });
 }
 
+int nmfx_nndsvd(nmfx_ctx *ctx, const void *U_host, const void *s_host, const void *V_host, int variant, int zeroh, uint64_t seed,
+                int64_t n_total) {
+    if (!ctx || !U_host || !s_host || !V_host) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->nndsvd_init(U_host, s_host, V_host, variant, zeroh != 0, seed, n_total); });
+}
+
 int nmfx_profile_enable(nmfx_ctx *ctx, int on) {
     if (!ctx) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { ctx->impl->profile_enable(on); });

@@ -70,6 +70,8 @@ struct SolverBase {
     virtual void randinit(uint64_t seed, bool normalize, bool zeroh, int64_t h_col_offset) = 0;
     virtual void solve_replicates(int alg, const nmfx_opts &o, int replicates, uint64_t seed, bool zeroh, int64_t h_col_offset,
                                   void *W_host, void *H_host, nmfx_result *out, int *best) = 0;
+    virtual void nndsvd_init(const void *U_host, const void *s_host, const void *V_host, int variant, bool zeroh, uint64_t seed,
+                             int64_t n_total) = 0;
     virtual void profile_enable(int mode) = 0;
     virtual int profile_get(nmfx_kernel_stat *out, int max_entries) = 0;
 };
@@ -262,6 +264,8 @@ template <typename T> class Solver : public SolverBase {
     void randinit(uint64_t seed, bool normalize, bool zeroh, int64_t h_col_offset) override;
     void solve_replicates(int alg, const nmfx_opts &o, int replicates, uint64_t seed, bool zeroh, int64_t h_col_offset, void *W_host,
                           void *H_host, nmfx_result *out, int *best) override;
+    void nndsvd_init(const void *U_host, const void *s_host, const void *V_host, int variant, bool zeroh, uint64_t seed,
+                     int64_t n_total) override;
     double objective(int alg, const nmfx_opts &o) override {
         require_ready();
         HIP_TRY(hipSetDevice(device));
@@ -285,6 +289,7 @@ template <typename T> class Solver : public SolverBase {
     Ctrl *ctrl = nullptr, *ctrl_host = nullptr;
     DevBuf<T> Wbest, Hbest;   // solve_replicates: the best replicate's factors
     DevBuf<int> flagbuf;
+    DevBuf<double> nd_scratch;   // nndsvd_init: column norms and sum(X) partials
     int wcur = 0, hcur = 0;
     int s_h = 1, s_w = 1, s_gw = 1, s_gh = 1;
     int stat_chunks_w = 1, stat_chunks_h = 1;

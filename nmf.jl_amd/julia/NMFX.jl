@@ -158,6 +158,15 @@ randinit!(ctx::Context, seed::Integer; normalize::Bool=false, zeroh::Bool=false,
     check(ccall((:nmfx_randinit, libnmfx), Cint, (Ptr{Cvoid}, UInt64, Cint, Cint, Int64),
                 ctx.h, seed, normalize, zeroh, h_col_offset), ctx.h)
 
+# nndsvd(X, k; zeroh, variant, initdata) after its `U, s, V = ...` line (src/initialization.jl:83): the SVD stays in Julia
+# (rsvd(X, k) or initdata), _nndsvd! runs on the device and fills the resident W, H
+function nndsvd!(ctx::Context{T}, U::Matrix{T}, s::Vector{T}, V::Matrix{T}; variant::Symbol=:std, zeroh::Bool=false,
+                 seed::Integer=0, n_total::Integer=size(V, 1)) where T
+    ivar = variant == :std ? 0 : variant == :a ? 1 : variant == :ar ? 2 : throw(ArgumentError("Invalid value for variant"))
+    check(ccall((:nmfx_nndsvd, libnmfx), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}, Cint, Cint, UInt64, Int64),
+                ctx.h, U, s, V, ivar, zeroh, seed, n_total), ctx.h)
+end
+
 # solve_replicates!(alginst, X, W, H; replicates, initH): X stays on the device, only the winner comes back
 function solve_replicates!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, H::Matrix{T};
                            replicates::Integer, initH::Bool, seed::Integer) where T

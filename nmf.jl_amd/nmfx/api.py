@@ -327,6 +327,20 @@ class Context:
                                                 W.ctypes.data, H.ctypes.data, C.byref(res), C.byref(best)))
         return res, best.value
 
+    def nndsvd_init(self, U, s, V, variant="std", zeroh=False, seed=0, n_total=None):
+        """_nndsvd! (src/initialization.jl:26-72) on the device from a given truncated SVD: fills the resident W, H."""
+        T, k = self.T, self.k
+        U = np.asfortranarray(np.asarray(U)[:, :k], dtype=T)
+        V = np.asfortranarray(np.asarray(V)[:, :k], dtype=T)
+        s = np.ascontiguousarray(np.asarray(s)[:k], dtype=T)
+        if U.shape != (self.p, k) or V.shape != (self.n, k) or s.shape != (k,):
+            raise DimensionMismatch("U must be p x k, s of length k, V n x k")
+        ivar = {"std": 0, "a": 1, "ar": 2}.get(variant)
+        if ivar is None:
+            raise ArgumentError("Invalid value for variant")
+        self._ck(self.lib.nmfx_nndsvd(self.h, U.ctypes.data, s.ctypes.data, V.ctypes.data, ivar, int(zeroh), seed,
+                                      self.n if n_total is None else n_total))
+
     def comm_init(self, uid: bytes, rank: int, nranks: int):
         buf = C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)
         self._ck(self.lib.nmfx_comm_init(self.h, buf, rank, nranks))
@@ -416,8 +430,40 @@ def randinit(X, k, normalize=False, zeroh=False, rng=None):
 _ALGS = ("multmse", "multdiv", "projals", "alspgrad")
 
 
+def truncated_svd(X, k):
+    """(U, s, V) with X ~ U diag(s) V', k leading triplets: the host-side stand-in for the reference's rsvd(X, k)
+    (RandomizedLinAlg, src/initialization.jl:83) -- an exact LAPACK SVD instead of a randomized one."""
+    U, s, Vt = np.linalg.svd(np.asarray(X, dtype=np.float64), full_matrices=False)
+    T = X.dtype.type
+    return U[:, :k].astype(T), s[:k].astype(T), Vt[:k].T.astype(T)
+
+
+def nndsvd(X, k, zeroh=False, variant="std", initdata=None, seed=0, ctx: Context | None = None):
+    """nndsvd(X, k; zeroh, variant, initdata) (src/initialization.jl:74-101): the SVD comes from `initdata` = (U, s, V) or
+    from truncated_svd(X, k) on the host; _nndsvd! runs on the device."""
+    T = X.dtype.type
+    p, n = X.shape
+    if variant not in ("std", "a", "ar"):
+        raise ArgumentError("Invalid value for variant")
+    U, s, V = truncated_svd(X, k) if initdata is None else initdata
+    own = ctx is None
+    if own:
+        ctx = Context(T, p, n, k)
+        if variant != "std":
+            ctx.set_X(np.asfortranarray(X))
+    try:
+        ctx.nndsvd_init(U, s, V, variant=variant, zeroh=zeroh, seed=seed)
+        W = np.empty((p, k), dtype=T, order="F")
+        H = np.empty((k, n), dtype=T, order="F")
+        ctx.get_factors(W, H)
+    finally:
+        if own:
+            ctx.close()
+    return W, H
+
+
 def nnmf(X, k, init="random", alg="multmse", maxiter=100, tol=None, replicates=1, W0=None, H0=None,
-         update_H=True, verbose=False, rng=None, track_objective=False, seed=None):
+         update_H=True, verbose=False, rng=None, track_objective=False, seed=None, initdata=None):
     """nnmf(X, k; ...) (src/interf.jl:3-83) for the accelerated algorithms.
 
     Scope (SURVEY.md section 8): alg in {multmse, multdiv, projals, alspgrad}, init in {random, custom};
@@ -428,8 +474,9 @@ def nnmf(X, k, init="random", alg="multmse", maxiter=100, tol=None, replicates=1
     X is uploaded first and checked for negatives there, init=:random and the replicate restarts are drawn by
     nmfx_randinit (Philox4x32-10) next to the resident X, and only the winning replicate's factors come back."""
     T = X.dtype.type
-    if seed is not None:
-        return _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, verbose, int(seed))
+    if seed is not None or init in ("nndsvd", "nndsvda", "nndsvdar"):
+        return _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, verbose,
+                            int(0 if seed is None else seed), initdata)
     if not (np.issubdtype(X.dtype, np.floating) and np.all(X >= 0)):
         raise ArgumentError("The elements of X must be non-negative.")
     p, n = X.shape
@@ -515,7 +562,7 @@ def _alg_instance(T, alg, maxiter, tol, verbose, update_H):
     raise ArgumentError("Invalid algorithm.")
 
 
-def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, verbose, seed):
+def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, verbose, seed, initdata=None):
     """nnmf with the front end on the device: same checks, same order, same messages as src/interf.jl:15-101."""
     T = X.dtype.type
     if not np.issubdtype(X.dtype, np.floating):
@@ -535,9 +582,9 @@ def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, ve
             raise ArgumentError("Invalid size for W0.")
         if H0.shape != (k, n):
             raise ArgumentError("Invalid size for H0.")
-    elif init in ("nndsvd", "nndsvda", "nndsvdar", "spa"):
+    elif init == "spa":
         raise ArgumentError(f"init=:{init} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
-    elif init != "random":
+    elif init not in ("random", "nndsvd", "nndsvda", "nndsvdar"):
         raise ArgumentError("Invalid value for init.")
     elif W0 is not None or H0 is not None:
         warnings.warn("Ignore W0 and H0 except for :custom initialization.")
@@ -558,7 +605,11 @@ def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, ve
         else:
             W = np.empty((p, k), dtype=T, order="F")
             H = np.empty((k, n), dtype=T, order="F")
-            ctx.randinit(seed, normalize=True, zeroh=not initH)
+            if init == "random":
+                ctx.randinit(seed, normalize=True, zeroh=not initH)
+            else:                                                        # src/interf.jl:44-49
+                U, s, V = truncated_svd(X, k) if initdata is None else initdata
+                ctx.nndsvd_init(U, s, V, variant={"nndsvd": "std", "nndsvda": "a", "nndsvdar": "ar"}[init], zeroh=not initH, seed=seed)
             ctx.get_factors(W, H)
         opts = make_opts(T, **inst._opts())
         res, best = ctx.solve_replicates(inst._alg(), opts, replicates, seed, not initH, W, H)

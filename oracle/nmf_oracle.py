@@ -544,6 +544,58 @@ def solve(alg, X, W, H, opts: Opts | None = None) -> Result:
 
 
 # ----------------------------------------------------------------------------
+# NNDSVD from a given truncated SVD (src/initialization.jl:26-137) -- SURVEY.md section 8f rank 3, the part behind
+# `U, s, V = ...`.  The default `rsvd(X, k)` (RandomizedLinAlg, un-vendored, Julia RNG) is NOT restated: PARITY UNPINNED
+# for it; callers pass `initdata` (any SVD of X), as test/initialization.jl:45-49 and test/interf.jl:20 do.
+# ----------------------------------------------------------------------------
+
+def _posnegnorm(x):
+    """posnegnorm (:103-115): sequential T-precision sums of squares of the positive / non-positive entries."""
+    T = x.dtype.type
+    sq = x * x
+    pn = np.cumsum(np.where(x > 0, sq, T(0)), dtype=T)[-1] if x.size else T(0)
+    nn = np.cumsum(np.where(x > 0, T(0), sq), dtype=T)[-1] if x.size else T(0)
+    return T(np.sqrt(pn)), T(np.sqrt(nn))
+
+
+def nndsvd(X, k, zeroh=False, variant="std", initdata=None, rand_vj=None):
+    """nndsvd(X, k; zeroh, variant, initdata) (:74-101) with _nndsvd! (:26-72).  initdata = (U, s, V) with X ~ U diag(s) V'
+    (V is n x k); rand_vj: the k uniforms `rand(T)` draws for variant :ar (the caller supplies the stream)."""
+    T = X.dtype.type
+    p, n = X.shape
+    ivar = {"std": 0, "a": 1, "ar": 2}.get(variant)
+    if ivar is None:
+        raise ValueError("Invalid value for variant")
+    if initdata is None:
+        raise NotImplementedError("rsvd(X, k) is not restated (un-vendored RandomizedLinAlg + Julia RNG): pass initdata")
+    U, s, V = (np.asarray(a)[..., :k].astype(T) for a in initdata)                    # :83, :31-33
+    W = np.empty((p, k), dtype=T, order="F")
+    Ht = np.zeros((n, k), dtype=T, order="F")
+    mean = np.mean(X, dtype=np.float64)
+    v0 = T(0) if ivar == 0 else (T(mean) if ivar == 1 else T(mean * 0.01))           # :41-42
+    for j in range(k):                                                                # :44
+        x, y = U[:, j], V[:, j]
+        xp, xn = _posnegnorm(x)
+        yp, yn = _posnegnorm(y)
+        mp, mn = T(xp * yp), T(xn * yn)                                               # :49-50
+        vj = v0
+        if ivar == 2:
+            vj = T(vj * T(rand_vj[j]))                                                # :52-55
+        if mp >= mn:                                                                  # :58-61 / :68-70
+            ss = T(np.sqrt(T(s[j] * mp)))
+            W[:, j] = np.where(x > 0, x * T(ss / xp), vj)
+            if not zeroh:
+                Ht[:, j] = np.where(y > 0, y * T(ss / yp), vj)
+        else:                                                                         # :62-65 / :71-73
+            ss = T(np.sqrt(T(s[j] * mn)))
+            W[:, j] = np.where(x < 0, -(x * T(ss / xn)), vj)
+            if not zeroh:
+                Ht[:, j] = np.where(y < 0, -(y * T(ss / yn)), vj)
+    H = np.zeros((k, n), dtype=T, order="F") if zeroh else np.asfortranarray(Ht.T)    # :89-99
+    return W, H
+
+
+# ----------------------------------------------------------------------------
 # test problem (test/testproblems.jl:6-13)
 # ----------------------------------------------------------------------------
 

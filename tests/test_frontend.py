@@ -134,3 +134,86 @@ def test_nnmf_device_front_end(built):
     # projals starts from H = 0 (src/interf.jl:39): the front end must not draw H
     rp = nmfx.nnmf(X, 3, init="random", alg="projals", maxiter=10, seed=5)
     assert np.isfinite(rp.objvalue)
+
+
+# ---- NNDSVD from a given SVD (src/initialization.jl:26-137; SURVEY.md section 8f rank 3, the part behind `U, s, V = ...`)
+
+def _u01(T, w0, w1):
+    if np.dtype(T) == np.float32:
+        return np.float32(w0 >> np.uint32(8)) * np.float32(1.0 / 16777216.0)
+    return (np.float64(w0 >> np.uint32(5)) * 67108864.0 + np.float64(w1 >> np.uint32(6))) * (1.0 / 9007199254740992.0)
+
+
+def _rand_vj(T, k, seed):
+    """the k uniforms nndsvd_coef_kernel draws for variant :ar (counter = (j, 0, 2, 0))."""
+    j = np.arange(k, dtype=np.uint64)
+    w0, w1, _, _ = philox_ref.philox4x32_10(j, np.zeros(k, np.uint64), np.full(k, 2, np.uint64), np.zeros(k, np.uint64),
+                                            seed & 0xFFFFFFFF, seed >> 32)
+    return np.array([_u01(T, a, b) for a, b in zip(w0, w1)], dtype=T)
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_nndsvd_oracle_kats(T):
+    """test/initialization.jl:29-53 on the restatement (with initdata = an SVD of X, as :45-49 do)."""
+    import nmf_oracle as orc
+    rng = np.random.default_rng(7)
+    X = np.asfortranarray(rng.random((8, 12)).astype(T))
+
+    def svd(A):
+        U, s, Vt = np.linalg.svd(A.astype(np.float64), full_matrices=False)
+        return U.astype(T), s.astype(T), Vt.T.astype(T)
+
+    W, H = orc.nndsvd(X, 5, initdata=svd(X))
+    assert W.shape == (8, 5) and H.shape == (5, 12) and (W >= 0).all() and (H >= 0).all()
+    W2, H2 = orc.nndsvd(X, 5, zeroh=True, initdata=svd(X))
+    assert np.array_equal(W2, W) and not H2.any()
+    W2, H2 = orc.nndsvd(T(2) * X, 5, initdata=svd(T(2) * X))
+    tol = 200 * np.finfo(T).eps
+    np.testing.assert_allclose(W2, np.sqrt(T(2)) * W, rtol=tol, atol=tol)
+    np.testing.assert_allclose(H2, np.sqrt(T(2)) * H, rtol=tol, atol=tol)
+    Wr, _ = orc.nndsvd(X, 5, variant="ar", initdata=svd(X), rand_vj=rng.random(5).astype(T) + T(0.01))
+    assert (Wr > 0).all()
+    with pytest.raises(ValueError):
+        orc.nndsvd(X, 5, variant="bogus", initdata=svd(X))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("variant", ["std", "a", "ar"])
+@pytest.mark.parametrize("shape", [(8, 12, 5), (300, 129, 20), (130, 700, 64)])
+def test_nndsvd_matches_oracle(built, T, variant, shape):
+    import nmf_oracle as orc
+    import nmfx
+    p, n, k = shape
+    X, _, _ = uniform(p, n, k, T, seed=p)
+    F = nmfx.truncated_svd(X, k)
+    seed = 4242
+    rv = _rand_vj(T, k, seed)
+    for zeroh in (False, True):
+        W, H = nmfx.nndsvd(X, k, zeroh=zeroh, variant=variant, initdata=F, seed=seed)
+        Wo, Ho = orc.nndsvd(X, k, zeroh=zeroh, variant=variant, initdata=F, rand_vj=rv)
+        tol = 64 * np.finfo(T).eps       # column norms: the device sums the squares in Float64, the reference left to right in T
+        np.testing.assert_allclose(W, Wo, rtol=tol, atol=tol * np.abs(Wo).max())
+        np.testing.assert_allclose(H, Ho, rtol=tol, atol=tol * max(np.abs(Ho).max(), 1e-30))
+        assert (W >= 0).all() and (H >= 0).all()
+        if zeroh:
+            assert not H.any()
+        if variant == "ar":
+            assert (W > 0).all()
+
+
+@pytest.mark.gpu
+def test_nnmf_with_reference_defaults(built):
+    """nnmf(X, k) with the reference's default init (:nndsvdar) and algorithm (:greedycd) (src/interf.jl:4-6), and
+    init=:nndsvd with initdata like test/interf.jl:20."""
+    import nmfx
+    T = np.float64
+    X, _, _ = uniform(60, 90, 5, T, seed=12)
+    r = nmfx.nnmf(X, 5, init="nndsvdar", alg="greedycd", maxiter=50)
+    assert np.isfinite(r.objvalue) and (r.W >= 0).all() and (r.H >= 0).all()
+    rr = nmfx.nnmf(X, 5, init="random", alg="greedycd", maxiter=50, seed=1)
+    assert r.objvalue < 1.2 * rr.objvalue                       # an SVD-based start is at least in the same league as a random one
+    F = nmfx.truncated_svd(X, 5)
+    for alg in ("multmse", "multdiv", "projals", "alspgrad", "cd", "greedycd"):
+        ra = nmfx.nnmf(X, 5, init="nndsvd", alg=alg, maxiter=20, initdata=F)
+        assert np.isfinite(ra.objvalue) and (ra.W >= 0).all() and (ra.H >= 0).all()

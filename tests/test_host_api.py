@@ -34,7 +34,7 @@ def test_nnmf_argument_errors():
     with pytest.raises(nmfx.ArgumentError, match="outside the accelerated hot path"):
         nmfx.nnmf(X, 2, alg="spa")
     with pytest.raises(nmfx.ArgumentError, match="outside the accelerated hot path"):
-        nmfx.nnmf(X, 2, init="nndsvdar", alg="greedycd")
+        nmfx.nnmf(X, 2, init="spa", alg="greedycd")
 
 
 def test_coordinate_descent_option_structs():

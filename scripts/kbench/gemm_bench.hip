@@ -30,7 +30,7 @@ double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool 
     g.splits = splits; g.kchunk = (int)(Kd / splits); g.c_fastest = c_fastest; g.done = nullptr; 
     EpiStore<T> e{D, C, R * C, nullptr};
     T *D2 = nullptr;
-    if (g_stagger) {   // Gram tail: extra tiles A2 = B (the small operand), (C/BC)^2 tail tiles
+    if (g_stagger && C <= 1024) {   // Gram tail (only meaningful when the small operand is B): extra tiles A2 = B (the small operand), (C/BC)^2 tail tiles
         g.A2 = B; g.lda2 = ldb; g.r_split = R; g.tail_tiles = (int)(C / BR); g.tail_nkt = (int)(Kd / Mfma<T>::BK);
         const int blocks0 = g.tiles_r * g.tiles_c * splits;
         const int tt = g.tail_tiles * g.tiles_c;
@@ -75,6 +75,7 @@ double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool 
            (long long)Kd, splits, blocks, best * 1e3, tf, maxerr);
     fflush(stdout);
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(D));
+    if (D2) CK(hipFree(D2));
     return tf;
 }
 

@@ -122,6 +122,12 @@ int nmfx_get_factors(nmfx_ctx *ctx, void *W_host, void *H_host);
  * objv_trace: NULL or maxiter+1 doubles (entry t = objective after iteration t; entry 0 = initial). */
 int nmfx_iterate(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, nmfx_result *out, double *objv_trace);
 
+/* The other two columns of the reference's verbose table (src/common.jl:54-59, :76-82) for the LAST solve run with
+ * track_objective = 1: elapsed_s[t] = device time from the start of the loop to the end of iteration t (entry 0 = 0), and
+ * relchange[t] = the `(W & H).relchange` value, stop_condition's devmax (src/common.jl:93, :106; entry 0 = NaN).
+ * Either pointer may be NULL; *n_entries = number of entries written (= min(count, niters + 1); 0 when nothing was tracked). */
+int nmfx_get_iter_trace(nmfx_ctx *ctx, double *elapsed_s, double *relchange, int count, int *n_entries);
+
 /* NMF.solve!(alg, X, W, H) (src/multupd.jl:45-52, src/projals.jl:37-39, src/alspgrad.jl:381-383):
  * = nmfx_set_factors + nmfx_iterate + nmfx_get_factors; W and H are updated in place. */
 int nmfx_solve(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, void *W_host, void *H_host,

@@ -127,6 +127,7 @@ template <typename T> void Solver<T>::run_alspgrad(const nmfx_opts &o, nmfx_resu
     pg_backtracks = 0;
     long long inner = 0;
     T tolg = (T)o.tolg;                                                    // fresh ALSPGradUpd per solve! (:381-383)
+    begin_iter_trace(o);
     HIP_TRY(hipEventRecord(ev_beg, stream));
     if (track) enqueue_objective(NMFX_ALG_ALSPGRAD, o, trace_dev.p, nullptr);
     long long t = 0;
@@ -167,6 +168,7 @@ template <typename T> void Solver<T>::run_alspgrad(const nmfx_opts &o, nmfx_resu
         HIP_TRY(hipMemcpyAsync(&objv, obj_final.p, sizeof(double), hipMemcpyDeviceToHost, stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    end_iter_trace(o, t);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev_beg, ev_end));
     out->niters = t;

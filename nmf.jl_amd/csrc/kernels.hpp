@@ -141,10 +141,11 @@ __global__ void finalize_partials_kernel(const double *partial, int nchunks, int
 // wstat/hstat: [j*2] = dev, [j*2+1] = sum (hstat may be null when update_H is false).
 // The reference accumulates in T; the comparison is done in T on the rounded sums.
 template <typename T>
-__global__ void check_kernel(Ctrl *ctrl, const double *wstat, const double *hstat, int k, T tol, long long t) {
+__global__ void check_kernel(Ctrl *ctrl, const double *wstat, const double *hstat, int k, T tol, long long t, double *dev_out) {
     if (ctrl->done) return;
-    __shared__ int bad;
-    if (threadIdx.x == 0) bad = 0;
+    __shared__ int first_bad;
+    __shared__ T wmax[4];
+    if (threadIdx.x == 0) first_bad = k;
     __syncthreads();
     for (int j = threadIdx.x; j < k; j += blockDim.x) {
         const T dw = (T)wstat[2 * j], sw = (T)wstat[2 * j + 1];
@@ -153,12 +154,39 @@ __global__ void check_kernel(Ctrl *ctrl, const double *wstat, const double *hsta
             const T dh = (T)hstat[2 * j], sh = (T)hstat[2 * j + 1];
             b = b || (sqrt(dh) > tol * sqrt(sh));
         }
-        if (b) atomicOr(&bad, 1);
+        if (b) atomicMin(&first_bad, j);
     }
     __syncthreads();
+    const int jf = first_bad;
+    if (dev_out != nullptr) {
+        // devmax of stop_condition (common.jl:93, :106): running maximum of sqrt(max(dev_w/sum_w, dev_h/sum_h)) over the
+        // components visited BEFORE the early return, i.e. j <= first failing component.  (update_H = false: the reference's
+        // dev_h is exactly 0, so only the W ratio contributes.)
+        T m = (T)0;
+        const int jend = (jf < k) ? jf : k - 1;
+        for (int j = threadIdx.x; j <= jend; j += blockDim.x) {
+            T r = (T)wstat[2 * j] / (T)wstat[2 * j + 1];
+            if (hstat != nullptr) {
+                const T rh = (T)hstat[2 * j] / (T)hstat[2 * j + 1];
+                r = (rh > r) ? rh : r;
+            }
+            const T v = sqrt(r);
+            m = (v > m) ? v : m;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const T o = __shfl_down(m, off, 64);
+            m = (o > m) ? o : m;
+        }
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = (wmax[w] > m) ? wmax[w] : m;
+            dev_out[t] = (double)m;
+        }
+    }
     if (threadIdx.x == 0) {
         ctrl->niters = t;
-        if (!bad) { ctrl->converged = 1; ctrl->done = 1; }
+        if (jf >= k) { ctrl->converged = 1; ctrl->done = 1; }
     }
 }
 

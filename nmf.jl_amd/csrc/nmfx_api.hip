@@ -165,6 +165,11 @@ int nmfx_nndsvd(nmfx_ctx *ctx, const void *U_host, const void *s_host, const voi
     return guarded(ctx, [&] { ctx->impl->nndsvd_init(U_host, s_host, V_host, variant, zeroh != 0, seed, n_total); });
 }
 
+int nmfx_get_iter_trace(nmfx_ctx *ctx, double *elapsed_s, double *relchange, int count, int *n_entries) {
+    if (!ctx || !n_entries || count < 0) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { *n_entries = ctx->impl->get_iter_trace(elapsed_s, relchange, count); });
+}
+
 int nmfx_profile_enable(nmfx_ctx *ctx, int on) {
     if (!ctx) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { ctx->impl->profile_enable(on); });

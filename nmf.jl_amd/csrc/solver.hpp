@@ -70,6 +70,7 @@ struct SolverBase {
     virtual void randinit(uint64_t seed, bool normalize, bool zeroh, int64_t h_col_offset) = 0;
     virtual void solve_replicates(int alg, const nmfx_opts &o, int replicates, uint64_t seed, bool zeroh, int64_t h_col_offset,
                                   void *W_host, void *H_host, nmfx_result *out, int *best) = 0;
+    virtual int get_iter_trace(double *elapsed, double *relchange, int count) = 0;
     virtual void nndsvd_init(const void *U_host, const void *s_host, const void *V_host, int variant, bool zeroh, uint64_t seed,
                              int64_t n_total) = 0;
     virtual void profile_enable(int mode) = 0;
@@ -171,6 +172,7 @@ template <typename T> class Solver : public SolverBase {
         if (pg_host) (void)hipHostFree(pg_host);
         if (ctrl) (void)hipFree(ctrl);
         if (ctrl_host) (void)hipHostFree(ctrl_host);
+        for (hipEvent_t e : iter_events) (void)hipEventDestroy(e);
         (void)hipEventDestroy(ev_beg);
         (void)hipEventDestroy(ev_end);
         (void)hipStreamDestroy(stream);
@@ -290,6 +292,10 @@ template <typename T> class Solver : public SolverBase {
     DevBuf<T> Wbest, Hbest;   // solve_replicates: the best replicate's factors
     DevBuf<int> flagbuf;
     DevBuf<double> nd_scratch;   // nndsvd_init: column norms and sum(X) partials
+    DevBuf<double> dev_trace;    // per-iteration devmax of stop_condition when tracking
+    std::vector<hipEvent_t> iter_events;
+    std::vector<double> iter_elapsed, iter_relchange;
+    int iter_trace_len = 0;
     int wcur = 0, hcur = 0;
     int s_h = 1, s_w = 1, s_gw = 1, s_gh = 1;
     int stat_chunks_w = 1, stat_chunks_h = 1;
@@ -595,9 +601,46 @@ template <typename T> class Solver : public SolverBase {
         if (nranks > 1) RCCL_TRY(ncclAllReduce(hstat.p, hstat.p, (size_t)2 * K, ncclDouble, ncclSum, comm, stream));
     }
     void enqueue_check(const nmfx_opts &o, long long t) {
+        const bool track = o.track_objective != 0;
         hipLaunchKernelGGL(check_kernel<T>, dim3(1), dim3(256), 0, stream, ctrl, wstat.p,
-                           o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t);
+                           o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, track ? dev_trace.p : (double *)nullptr);
         HIP_TRY(hipGetLastError());
+        if (track) {   // verbose-style tracking also time-stamps every iteration (common.jl:77: elapsed = time() - start)
+            while (iter_events.size() <= (size_t)t) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                iter_events.push_back(e);
+            }
+            HIP_TRY(hipEventRecord(iter_events[(size_t)t], stream));
+        }
+    }
+    // per-iteration columns of the reference's verbose table for the last tracked solve (common.jl:54-59, :76-82)
+    void begin_iter_trace(const nmfx_opts &o) {
+        if (!o.track_objective) { iter_trace_len = 0; return; }
+        dev_trace.ensure((size_t)o.maxiter + 1);
+        std::vector<double> nanv((size_t)o.maxiter + 1, std::nan(""));
+        HIP_TRY(hipMemcpyAsync(dev_trace.p, nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    void end_iter_trace(const nmfx_opts &o, long long niters) {
+        if (!o.track_objective) return;
+        iter_trace_len = (int)niters + 1;
+        iter_elapsed.assign((size_t)iter_trace_len, 0.0);
+        iter_relchange.assign((size_t)iter_trace_len, std::nan(""));
+        for (long long t = 1; t <= niters; ++t) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ev_beg, iter_events[(size_t)t]));
+            iter_elapsed[(size_t)t] = ms * 1e-3;
+        }
+        HIP_TRY(hipMemcpy(iter_relchange.data(), dev_trace.p, (size_t)iter_trace_len * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    int get_iter_trace(double *elapsed, double *relchange, int count) override {
+        const int m = std::min(count, iter_trace_len);
+        for (int i = 0; i < m; ++i) {
+            if (elapsed) elapsed[i] = iter_elapsed[(size_t)i];
+            if (relchange) relchange[i] = iter_relchange[(size_t)i];
+        }
+        return m;
     }
     const int *done_flag() const { return &ctrl->done; }
 

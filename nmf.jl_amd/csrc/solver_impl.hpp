@@ -203,6 +203,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         HIP_TRY(hipStreamSynchronize(stream));
     }
     const int w0 = wcur, h0 = hcur;
+    begin_iter_trace(o);
     HIP_TRY(hipEventRecord(ev_beg, stream));
     if (track) enqueue_objective(alg, o, trace_dev.p, done_flag());        // common.jl:56
     long long t = 0;
@@ -245,6 +246,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         }
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    end_iter_trace(o, niters);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev_beg, ev_end));
     out->niters = niters;

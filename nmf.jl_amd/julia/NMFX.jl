@@ -145,6 +145,15 @@ function solve!(alg::Union{NMF.MultUpdate{T},NMF.ProjectedALS{T},NMF.ALSPGrad{T}
     end
 end
 
+# the `Elapsed time` and `(W & H).relchange` columns of the verbose table (src/common.jl:54-59, 76-82) of the last solve
+# that ran with track_objective = 1
+function iter_trace(ctx::Context, niters::Integer)
+    el = zeros(Float64, niters + 1); rc = fill(NaN, niters + 1); m = Ref{Cint}(0)
+    check(ccall((:nmfx_get_iter_trace, libnmfx), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint, Ref{Cint}),
+                ctx.h, el, rc, niters + 1, m), ctx.h)
+    el[1:m[]], rc[1:m[]]
+end
+
 # ---- nnmf front end on the device (include/nmfx.h; src/interf.jl:15,28,31,85-101; src/initialization.jl:4-17) ----------
 # all(t -> t >= zero(T), A) for the resident X (which = 0), W (1), H (2)
 function check_nonneg(ctx::Context, which::Integer)

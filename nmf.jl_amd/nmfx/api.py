@@ -341,6 +341,12 @@ class Context:
         self._ck(self.lib.nmfx_nndsvd(self.h, U.ctypes.data, s.ctypes.data, V.ctypes.data, ivar, int(zeroh), seed,
                                       self.n if n_total is None else n_total))
 
+    def iter_trace(self, count):
+        """(elapsed seconds, (W & H).relchange) per iteration of the last tracked solve (src/common.jl:76-82)."""
+        el, rc, m = np.zeros(count), np.full(count, np.nan), C.c_int32()
+        self._ck(self.lib.nmfx_get_iter_trace(self.h, el.ctypes.data, rc.ctypes.data, count, C.byref(m)))
+        return el[: m.value], rc[: m.value]
+
     def comm_init(self, uid: bytes, rank: int, nranks: int):
         buf = C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)
         self._ck(self.lib.nmfx_comm_init(self.h, buf, rank, nranks))
@@ -383,13 +389,28 @@ def solve(alg, X, W, H, ctx: Context | None = None, track_objective=False, check
     if own:
         ctx = Context(T, p, n, k)
         ctx.set_X(X)
+    track_objective = track_objective or bool(getattr(alg, "verbose", False))   # verbose = true evaluates every iteration
     try:
         o = make_opts(T, track_objective=track_objective, check_every=check_every, **alg._opts())
         res, trace = ctx.solve(alg._alg(), o, W, H)
-        return _result(T, W, H, res, trace)
+        out = _result(T, W, H, res, trace)
+        if track_objective:
+            out.info["elapsed"], out.info["relchange"] = ctx.iter_trace(int(res.niters) + 1)
+        if getattr(alg, "verbose", False):
+            print_verbose_table(out)
+        return out
     finally:
         if own:
             ctx.close()
+
+
+def print_verbose_table(r: Result, file=None):
+    """The table nmf_skeleton! prints with verbose = true (src/common.jl:54-59, :76-82), same columns and formats."""
+    el, rc = r.info["elapsed"], r.info["relchange"]
+    print("%-5s    %-13s    %-13s    %-13s    %-13s" % ("Iter", "Elapsed time", "objv", "objv.change", "(W & H).relchange"), file=file)
+    print("%5d    %13.6e    %13.6e" % (0, 0.0, r.trace[0]), file=file)
+    for t in range(1, len(r.trace)):
+        print("%5d    %13.6e    %13.6e    %13.6e    %13.6e" % (t, el[t], r.trace[t], r.trace[t] - r.trace[t - 1], rc[t]), file=file)
 
 
 def alspgrad_updateh(X, W, H, maxiter=1000, traceiter=20, tolg=None, beta=0.2, sigma=0.01):
@@ -537,10 +558,6 @@ def nnmf(X, k, init="random", alg="multmse", maxiter=100, tol=None, replicates=1
             tmp = solve(inst, X, Wr, Hr, ctx=ctx)
             if minobjv > tmp.objvalue:
                 ret, minobjv = tmp, tmp.objvalue
-    if verbose and ret.trace is not None:
-        print(f"{'Iter':<5s}    {'objv':<13s}    {'objv.change':<13s}")
-        for t, v in enumerate(ret.trace):
-            print(f"{t:5d}    {v:13.6e}" + ("" if t == 0 else f"    {v - ret.trace[t - 1]:13.6e}"))
     return ret
 
 
@@ -611,6 +628,20 @@ def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, ve
                 U, s, V = truncated_svd(X, k) if initdata is None else initdata
                 ctx.nndsvd_init(U, s, V, variant={"nndsvd": "std", "nndsvda": "a", "nndsvdar": "ar"}[init], zeroh=not initH, seed=seed)
             ctx.get_factors(W, H)
+        if verbose:
+            # the verbose table needs the per-iteration trace of every replicate: drive solve_replicates! from the host
+            # (same draws, same winner rule), X stays resident
+            ret, best = solve(inst, X, W, H, ctx=ctx), 1
+            for r in range(2, replicates + 1):
+                ctx.randinit(seed + r - 1, normalize=True, zeroh=not initH)
+                Wr = np.empty((p, k), dtype=T, order="F")
+                Hr = np.empty((k, n), dtype=T, order="F")
+                ctx.get_factors(Wr, Hr)
+                tmp = solve(inst, X, Wr, Hr, ctx=ctx)
+                if ret.objvalue > tmp.objvalue:
+                    ret, best = tmp, r
+            ret.info["best_replicate"] = best
+            return ret
         opts = make_opts(T, **inst._opts())
         res, best = ctx.solve_replicates(inst._alg(), opts, replicates, seed, not initH, W, H)
     out = _result(T, W, H, res, None)

@@ -78,6 +78,7 @@ class Result:
     objvalue: float
     trace: list = field(default_factory=list)   # objective at t=0..niters when tracked
     counters: dict = field(default_factory=dict)
+    relchange: list = field(default_factory=list)   # stop_condition's devmax per iteration when tracked (entry 0 = NaN)
 
 
 def resolve_opts(alg: int, T, o: Opts) -> Opts:
@@ -197,6 +198,25 @@ def stop_condition(W, preW, H, preH, tol):
     sh = np.cumsum((H + preH) ** 2, axis=1, dtype=H.dtype)[:, -1]
     bad = (np.sqrt(dw) > tol * np.sqrt(sw)) | (np.sqrt(dh) > tol * np.sqrt(sh))
     return not bool(np.any(bad))
+
+
+def stop_condition_dev(W, preW, H, preH, tol):
+    """(converged, devmax) exactly as src/common.jl:92-111 returns them: devmax is the running maximum of
+    sqrt(max(dev_w/sum_w, dev_h/sum_h)) over the components visited before the early `return false`."""
+    T = W.dtype.type
+    tol = T(tol)
+    dw = np.cumsum((W - preW) ** 2, axis=0, dtype=W.dtype)[-1, :]
+    sw = np.cumsum((W + preW) ** 2, axis=0, dtype=W.dtype)[-1, :]
+    dh = np.cumsum((H - preH) ** 2, axis=1, dtype=H.dtype)[:, -1]
+    sh = np.cumsum((H + preH) ** 2, axis=1, dtype=H.dtype)[:, -1]
+    bad = (np.sqrt(dw) > tol * np.sqrt(sw)) | (np.sqrt(dh) > tol * np.sqrt(sh))
+    jf = int(np.argmax(bad)) if bad.any() else len(bad) - 1
+    with np.errstate(divide="ignore", invalid="ignore"):
+        vals = np.sqrt(np.maximum(dw / sw, dh / sh))[: jf + 1]
+    devmax = T(0)
+    for v in vals:
+        devmax = max(devmax, v)                                   # Julia max(x, NaN) = NaN; Python max keeps the first: fine for finite data
+    return (not bool(bad.any())), float(devmax)
 
 
 # ----------------------------------------------------------------------------
@@ -526,9 +546,10 @@ def solve(alg, X, W, H, opts: Opts | None = None) -> Result:
     nmf_checksize(X, W, H)
     o = resolve_opts(alg, T, opts or Opts())
     upd = _UPDATERS[alg](T, o, X, W, H)                           # prepare_state :51
-    trace = []
+    trace, relchange = [], []
     if o.track_objective:
         trace.append(upd.objv(X, W, H))                           # :56
+        relchange.append(float("nan"))
     converged = False
     t = 0
     while (not converged) and t < o.maxiter:                      # :64
@@ -536,11 +557,14 @@ def solve(alg, X, W, H, opts: Opts | None = None) -> Result:
         preW = W.copy(order="F")                                  # :66-67
         preH = H.copy(order="F")
         upd.update(X, W, H)                                       # :70
-        converged = stop_condition(W, preW, H, preH, o.tol)       # :73
         if o.track_objective:
+            converged, dev = stop_condition_dev(W, preW, H, preH, o.tol)   # :73
+            relchange.append(dev)
             trace.append(upd.objv(X, W, H))                       # :79
+        else:
+            converged = stop_condition(W, preW, H, preH, o.tol)   # :73
     objv = trace[-1] if (o.track_objective and trace) else upd.objv(X, W, H)   # :85-87
-    return Result(W, H, t, converged, objv, trace, dict(getattr(upd, "cnt", {})))
+    return Result(W, H, t, converged, objv, trace, dict(getattr(upd, "cnt", {})), relchange)
 
 
 # ----------------------------------------------------------------------------

@@ -35,3 +35,29 @@ def test_tracked_objective_of_the_converging_iteration(built, alg):
     W2, H2 = W0.copy(order="F"), H0.copy(order="F")
     r2 = nmfx.solve(_inst(alg, T, maxiter=400, tol=tol), X, W2, H2)
     assert r2.niters == r.niters and r2.objvalue == r.objvalue and np.array_equal(W2, W)
+
+
+@pytest.mark.parametrize("alg", ["multmse", "projals", "alspgrad", "greedycd"])
+@pytest.mark.parametrize("update_H", [True, False])
+def test_verbose_table_columns(built, alg, update_H, capsys):
+    """The two extra columns of the reference's verbose table (src/common.jl:54-59, :76-82): elapsed time and
+    `(W & H).relchange` = stop_condition's devmax, INCLUDING its early-return semantics (maximum over the components up to
+    the first failing one)."""
+    T = np.float64
+    X, W0, H0 = planted(30, 45, 4, T, seed=5, normalize=(alg != "projals"))
+    inst = _inst(alg, T, maxiter=12, tol=1e-2, update_H=update_H)
+    W, H = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(inst, X, W, H, track_objective=True)
+    ro = orc.solve(alg, X, W0.copy(order="F"), H0.copy(order="F"), orc.Opts(maxiter=12, tol=1e-2, update_H=update_H, track_objective=True))
+    assert r.niters == ro.niters
+    el, rc = r.info["elapsed"], r.info["relchange"]
+    assert len(el) == len(rc) == r.niters + 1 and el[0] == 0 and np.isnan(rc[0])
+    assert np.all(np.diff(el) > 0) and el[-1] <= r.info["seconds_loop"] * 1.001
+    np.testing.assert_allclose(rc[1:], ro.relchange[1:], rtol=1e-6)
+    # verbose = true prints the table in the reference's format
+    inst.verbose = True
+    nmfx.solve(inst, X, W0.copy(order="F"), H0.copy(order="F"))
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert lines[0].split() == ["Iter", "Elapsed", "time", "objv", "objv.change", "(W", "&", "H).relchange"]
+    assert len(lines) == r.niters + 2 and len(lines[1].split()) == 3 and all(len(l.split()) == 5 for l in lines[2:])
+    assert lines[0].startswith("Iter     Elapsed time     objv             objv.change      (W & H).relchange")

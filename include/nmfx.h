@@ -154,7 +154,8 @@ int nmfx_alspgrad_subsolve(nmfx_ctx *ctx, int which, const nmfx_opts *opts, void
  *   nmfx_nndsvd           the part of nndsvd() (src/initialization.jl:74-101) behind `U, s, V = ...`: _nndsvd! (:26-72) with
  *                         posnegnorm / scalepos! / scaleneg! (:103-137) on the device, filling the resident W (p x k) and
  *                         H (k x n_local; zeros when zeroh).  U is p x k (ld p), s has k entries, V is n_local x k (ld
- *                         n_local), all host, type T: the truncated SVD stays with the caller (the reference's
+ *                         n_local), all host, type T (or all three NULL: use the SVD left resident by nmfx_rsvd_finish):
+ *                         the truncated SVD stays with the caller (the reference's
  *                         RandomizedLinAlg.rsvd, or its `initdata`).  variant 0/1/2 = :std / :a / :ar; :a and :ar fill with
  *                         mean(X) resp. mean(X)*0.01 (X must be resident; n_total = global column count for the mean),
  *                         :ar multiplies by one Philox uniform per component (Julia's rand stream is not reproducible). */
@@ -164,6 +165,21 @@ int nmfx_solve_replicates(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, int rep
                           int64_t h_col_offset, void *W_host, void *H_host, nmfx_result *out, int *best_replicate);
 int nmfx_nndsvd(nmfx_ctx *ctx, const void *U_host, const void *s_host, const void *V_host, int variant, int zeroh, uint64_t seed,
                 int64_t n_total);
+/* rsvd(X, k) of src/initialization.jl:83 (RandomizedLinAlg.jl, un-vendored; randomized range finder + SVD of the projected
+ * matrix) on the resident X.  Every p*n*k product is one of the hot path's GEMM launches: Y = X*Omega (the X*H' launch, Omega
+ * Gaussian from Philox), Q = orth(Y) (Gram-Schmidt with re-orthogonalisation), B = Q'X (the W'X launch), C = B*B' (k x k).
+ * The k x k symmetric eigenproblem stays with the host's LAPACK, like the reference's small svd:
+ *   nmfx_rsvd_begin   runs the device half and returns C (k x k, column-major, type T).  power_iters = 0 is the plain
+ *                     k-column sketch (no oversampling, no power iteration, like rsvd(X, k)'s defaults: good enough for an
+ *                     initialiser, up to ~30x the optimal rank-k error); each power iteration Y = X (X'Q) costs two more
+ *                     launches and brings the error to the optimum when the spectrum has a gap.
+ *   nmfx_rsvd_finish  takes the eigenvectors Ub (k x k, columns ordered by DESCENDING eigenvalue) and s = sqrt(eigenvalues)
+ *                     and forms U = Q*Ub (p x k) and V' = diag(1/s) Ub' B (k x n_local) on the device; U_out (p x k, ld p)
+ *                     and Vt_out (k x n_local, ld k) are optional downloads.  The triple stays resident:
+ *                     nmfx_nndsvd(ctx, NULL, NULL, NULL, ...) then runs _nndsvd! on it without a round trip.
+ * Julia's randn stream cannot be reproduced: parity with the reference's rsvd output is unpinned by construction. */
+int nmfx_rsvd_begin(nmfx_ctx *ctx, uint64_t seed, int64_t h_col_offset, int power_iters, void *C_host);
+int nmfx_rsvd_finish(nmfx_ctx *ctx, const void *Ub_host, const void *s_host, void *U_out, void *Vt_out);
 
 /* ---- multi-GPU (column sharding, one process per GPU) -----------------------
  * The reference has no distributed path; this is the build's data-parallel extension.

@@ -127,12 +127,14 @@ template <typename T> void Solver<T>::randinit(uint64_t seed, bool normalize, bo
 // variants need.
 // ---------------------------------------------------------------------------
 // out[2*j + {0,1}] = sum of squares of the positive / non-positive entries of column j (posnegnorm, :103-115); one block per column
-template <typename T> __global__ void posneg_sumsq_kernel(const T *A, int64_t rows, int64_t ld, double *out) {
+// (component j, sample i) lives at A[j*cs + i*ss]: host-uploaded U / V are column-major (cs = ld, ss = 1); the resident V' of
+// rsvd is k x n like H (cs = 1, ss = K)
+template <typename T> __global__ void posneg_sumsq_kernel(const T *A, int64_t rows, int64_t cs, int64_t ss, double *out) {
     __shared__ double sp[4], sn[4];
-    const T *col = A + (int64_t)blockIdx.x * ld;
+    const T *col = A + (int64_t)blockIdx.x * cs;
     double pn = 0.0, nn = 0.0;
     for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) {
-        const T x = col[i];
+        const T x = col[i * ss];
         const double q = (double)(T)(x * x);
         if (x > (T)0) pn += q; else nn += q;
     }
@@ -185,15 +187,15 @@ __global__ void nndsvd_coef_kernel(const double *unorm, const double *vnorm, con
 }
 
 // scalepos! / scaleneg! (:117-137): dst(i, j) = x > 0 ? x*c : v0   or   x < 0 ? -(x*c) : v0.
-// src is rows x k column-major (ld_src); dst element (i, j) at dst[i*ds_i + j*ds_j] (W: 1, P;  H from V: K, 1)
+// src element (sample i, component j) at src[j*cs + i*ss]; dst element (i, j) at dst[i*ds_i + j*ds_j] (W: 1, P;  H from V: K, 1)
 template <typename T>
-__global__ void nndsvd_fill_kernel(const T *src, int64_t rows, int64_t ld_src, int k, const T *coef, int which, T *dst, int64_t ds_i,
-                                   int64_t ds_j) {
+__global__ void nndsvd_fill_kernel(const T *src, int64_t rows, int64_t cs, int64_t ss, int k, const T *coef, int which, T *dst,
+                                   int64_t ds_i, int64_t ds_j) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * k) return;
     const int64_t i = e % rows;
     const int j = (int)(e / rows);
-    const T x = src[i + (int64_t)j * ld_src];
+    const T x = src[(int64_t)j * cs + i * ss];
     const T c = coef[4 * j + which], sg = coef[4 * j + 2], v0 = coef[4 * j + 3];
     T y;
     if (sg > (T)0) y = (x > (T)0) ? x * c : v0;
@@ -202,28 +204,20 @@ __global__ void nndsvd_fill_kernel(const T *src, int64_t rows, int64_t ld_src, i
 }
 
 template <typename T>
-void Solver<T>::nndsvd_init(const void *U_host, const void *s_host, const void *V_host, int variant, bool zeroh, uint64_t seed,
-                            int64_t n_total) {
+void Solver<T>::nndsvd_core(const T *Ud, int64_t ucs, int64_t uss, const T *Vd, int64_t vcs, int64_t vss, const T *sd, T *coef,
+                            int variant, bool zeroh, uint64_t seed, int64_t n_total) {
     if (variant < 0 || variant > 2) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for variant"};
     if (variant != 0 && !have_X) throw StatusError{NMFX_ERR_STATE, "variants :a / :ar need mean(X): upload X first (nmfx_set_X)"};
     if (n_total < n) throw StatusError{NMFX_ERR_BAD_ARG, "n_total must be the global column count (>= n_local)"};
-    HIP_TRY(hipSetDevice(device));
-    work[4].ensure((size_t)p * k);
-    work[5].ensure((size_t)n * k);
-    work[6].ensure((size_t)5 * k);
-    T *Ud = work[4].p, *Vd = work[5].p, *sd = work[6].p, *coef = work[6].p + k;
     const int nsum = 1024;
-    nd_scratch.ensure((size_t)4 * k + nsum);
-    double *unorm = nd_scratch.p, *vnorm = nd_scratch.p + 2 * k, *xsum = nd_scratch.p + 4 * k;
-    HIP_TRY(hipMemcpyAsync(Ud, U_host, (size_t)p * k * sizeof(T), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(Vd, V_host, (size_t)n * k * sizeof(T), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(sd, s_host, (size_t)k * sizeof(T), hipMemcpyHostToDevice, stream));
+    nd_scratch.ensure((size_t)4 * K + nsum + 4096);
+    double *unorm = nd_scratch.p, *vnorm = nd_scratch.p + 2 * K, *xsum = nd_scratch.p + 4 * K;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipMemsetAsync(W[i].p, 0, W[i].count * sizeof(T), stream));
         HIP_TRY(hipMemsetAsync(H[i].p, 0, H[i].count * sizeof(T), stream));
     }
-    hipLaunchKernelGGL(posneg_sumsq_kernel<T>, dim3((unsigned)k), dim3(256), 0, stream, Ud, p, p, unorm);
-    hipLaunchKernelGGL(posneg_sumsq_kernel<T>, dim3((unsigned)k), dim3(256), 0, stream, Vd, n, n, vnorm);
+    hipLaunchKernelGGL(posneg_sumsq_kernel<T>, dim3((unsigned)k), dim3(256), 0, stream, Ud, p, ucs, uss, unorm);
+    hipLaunchKernelGGL(posneg_sumsq_kernel<T>, dim3((unsigned)k), dim3(256), 0, stream, Vd, n, vcs, vss, vnorm);
     HIP_TRY(hipMemsetAsync(xsum, 0, nsum * sizeof(double), stream));
     if (variant != 0) hipLaunchKernelGGL(sum_block_kernel<T>, dim3(nsum), dim3(256), 0, stream, X.p, p, n, P, xsum);
     if (nranks > 1) {   // V rows (= columns of X, H) are sharded: the norms of V's columns and sum(X) are global quantities
@@ -234,15 +228,35 @@ void Solver<T>::nndsvd_init(const void *U_host, const void *s_host, const void *
     }
     hipLaunchKernelGGL(nndsvd_coef_kernel<T>, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, stream, unorm, vnorm, sd, xsum, nsum,
                        (double)p * (double)n_total, variant, seed, (int)k, coef);
-    hipLaunchKernelGGL(nndsvd_fill_kernel<T>, dim3((unsigned)((p * k + 255) / 256)), dim3(256), 0, stream, Ud, p, p, (int)k, coef, 0,
+    hipLaunchKernelGGL(nndsvd_fill_kernel<T>, dim3((unsigned)((p * k + 255) / 256)), dim3(256), 0, stream, Ud, p, ucs, uss, (int)k, coef, 0,
                        W[0].p, (int64_t)1, P);
     if (!zeroh)
-        hipLaunchKernelGGL(nndsvd_fill_kernel<T>, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, stream, Vd, n, n, (int)k, coef, 1,
-                           H[0].p, K, (int64_t)1);
+        hipLaunchKernelGGL(nndsvd_fill_kernel<T>, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, stream, Vd, n, vcs, vss, (int)k, coef,
+                           1, H[0].p, K, (int64_t)1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
     wcur = hcur = 0;
     have_F = true;
+}
+
+template <typename T>
+void Solver<T>::nndsvd_init(const void *U_host, const void *s_host, const void *V_host, int variant, bool zeroh, uint64_t seed,
+                            int64_t n_total) {
+    HIP_TRY(hipSetDevice(device));
+    if (U_host == nullptr) {   // the resident U, s, V' left by nmfx_rsvd_finish
+        if (rsvd_ready < 2) throw StatusError{NMFX_ERR_STATE, "no resident SVD: call nmfx_rsvd_begin / nmfx_rsvd_finish first"};
+        nndsvd_core(work[5].p, P, 1, work[7].p, 1, K, work[6].p, work[6].p + K, variant, zeroh, seed, n_total);
+        return;
+    }
+    rsvd_ready = 0;            // the scratch buffers are shared with rsvd
+    work[4].ensure((size_t)p * k);
+    work[5].ensure((size_t)std::max<int64_t>(n * k, 1));
+    work[6].ensure((size_t)5 * K);
+    T *Ud = work[4].p, *Vd = work[5].p, *sd = work[6].p, *coef = work[6].p + K;
+    HIP_TRY(hipMemcpyAsync(Ud, U_host, (size_t)p * k * sizeof(T), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(Vd, V_host, (size_t)n * k * sizeof(T), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(sd, s_host, (size_t)k * sizeof(T), hipMemcpyHostToDevice, stream));
+    nndsvd_core(Ud, p, 1, Vd, n, 1, sd, coef, variant, zeroh, seed, n_total);
 }
 
 // solve_replicates! (src/interf.jl:85-101): replicate 1 starts from the caller's W, H; replicates 2..R from fresh

@@ -10,6 +10,7 @@
 #include "alspgrad_impl.hpp"
 #include "frontend_impl.hpp"
 #include "cd_impl.hpp"
+#include "rsvd_impl.hpp"
 
 using namespace nmfx;
 
@@ -161,8 +162,19 @@ int nmfx_solve_replicates(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, int rep
 
 int nmfx_nndsvd(nmfx_ctx *ctx, const void *U_host, const void *s_host, const void *V_host, int variant, int zeroh, uint64_t seed,
                 int64_t n_total) {
-    if (!ctx || !U_host || !s_host || !V_host) return NMFX_ERR_BAD_ARG;
+    if (!ctx) return NMFX_ERR_BAD_ARG;
+    if ((U_host == nullptr) != (s_host == nullptr) || (U_host == nullptr) != (V_host == nullptr)) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { ctx->impl->nndsvd_init(U_host, s_host, V_host, variant, zeroh != 0, seed, n_total); });
+}
+
+int nmfx_rsvd_begin(nmfx_ctx *ctx, uint64_t seed, int64_t h_col_offset, int power_iters, void *C_host) {
+    if (!ctx || !C_host || h_col_offset < 0) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->rsvd_begin(seed, h_col_offset, power_iters, C_host); });
+}
+
+int nmfx_rsvd_finish(nmfx_ctx *ctx, const void *Ub_host, const void *s_host, void *U_out, void *Vt_out) {
+    if (!ctx || !Ub_host || !s_host) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->rsvd_finish(Ub_host, s_host, U_out, Vt_out); });
 }
 
 int nmfx_get_iter_trace(nmfx_ctx *ctx, double *elapsed_s, double *relchange, int count, int *n_entries) {

@@ -71,6 +71,8 @@ struct SolverBase {
     virtual void solve_replicates(int alg, const nmfx_opts &o, int replicates, uint64_t seed, bool zeroh, int64_t h_col_offset,
                                   void *W_host, void *H_host, nmfx_result *out, int *best) = 0;
     virtual int get_iter_trace(double *elapsed, double *relchange, int count) = 0;
+    virtual void rsvd_begin(uint64_t seed, int64_t h_col_offset, int power_iters, void *C_host) = 0;
+    virtual void rsvd_finish(const void *Ub_host, const void *s_host, void *U_out, void *Vt_out) = 0;
     virtual void nndsvd_init(const void *U_host, const void *s_host, const void *V_host, int variant, bool zeroh, uint64_t seed,
                              int64_t n_total) = 0;
     virtual void profile_enable(int mode) = 0;
@@ -268,6 +270,12 @@ template <typename T> class Solver : public SolverBase {
                           void *H_host, nmfx_result *out, int *best) override;
     void nndsvd_init(const void *U_host, const void *s_host, const void *V_host, int variant, bool zeroh, uint64_t seed,
                      int64_t n_total) override;
+    void nndsvd_core(const T *Ud, int64_t ucs, int64_t uss, const T *Vd, int64_t vcs, int64_t vss, const T *sd, T *coef, int variant,
+                     bool zeroh, uint64_t seed, int64_t n_total);
+    // randomized SVD of the resident X (rsvd_impl.hpp)
+    void rsvd_begin(uint64_t seed, int64_t h_col_offset, int power_iters, void *C_host) override;
+    void rsvd_finish(const void *Ub_host, const void *s_host, void *U_out, void *Vt_out) override;
+    int rsvd_ready = 0;   // 1: Q, B resident (after begin); 2: U, s, V' resident (after finish)
     double objective(int alg, const nmfx_opts &o) override {
         require_ready();
         HIP_TRY(hipSetDevice(device));

@@ -167,6 +167,22 @@ randinit!(ctx::Context, seed::Integer; normalize::Bool=false, zeroh::Bool=false,
     check(ccall((:nmfx_randinit, libnmfx), Cint, (Ptr{Cvoid}, UInt64, Cint, Cint, Int64),
                 ctx.h, seed, normalize, zeroh, h_col_offset), ctx.h)
 
+# rsvd(X, k) (src/initialization.jl:83) on the resident X: the device sketches / orthogonalises / projects, Julia's LAPACK solves
+# the k x k symmetric eigenproblem in between; the triple stays resident for nndsvd_resident!
+function rsvd!(ctx::Context{T}, k::Integer; seed::Integer=0, power_iters::Integer=0) where T
+    C = Matrix{T}(undef, k, k)
+    check(ccall((:nmfx_rsvd_begin, libnmfx), Cint, (Ptr{Cvoid}, UInt64, Int64, Cint, Ptr{T}), ctx.h, seed, 0, power_iters, C), ctx.h)
+    F = LinearAlgebra.eigen(LinearAlgebra.Symmetric((C + C') / 2))
+    ord = sortperm(F.values; rev=true)
+    s = T.(sqrt.(max.(F.values[ord], 0)))
+    Ub = Matrix{T}(F.vectors[:, ord])
+    check(ccall((:nmfx_rsvd_finish, libnmfx), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, Ub, s, C_NULL, C_NULL), ctx.h)
+    s
+end
+nndsvd_resident!(ctx::Context{T}; variant::Symbol=:std, zeroh::Bool=false, seed::Integer=0, n_total::Integer) where T =
+    check(ccall((:nmfx_nndsvd, libnmfx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, UInt64, Int64),
+                ctx.h, C_NULL, C_NULL, C_NULL, variant == :std ? 0 : variant == :a ? 1 : 2, zeroh, seed, n_total), ctx.h)
+
 # nndsvd(X, k; zeroh, variant, initdata) after its `U, s, V = ...` line (src/initialization.jl:83): the SVD stays in Julia
 # (rsvd(X, k) or initdata), _nndsvd! runs on the device and fills the resident W, H
 function nndsvd!(ctx::Context{T}, U::Matrix{T}, s::Vector{T}, V::Matrix{T}; variant::Symbol=:std, zeroh::Bool=false,

@@ -21,7 +21,7 @@ SYMBOLS = [
     "nmfx_create", "nmfx_destroy", "nmfx_last_error", "nmfx_version", "nmfx_set_X", "nmfx_set_X_device",
     "nmfx_set_factors", "nmfx_get_factors", "nmfx_iterate", "nmfx_solve", "nmfx_alspgrad_subsolve",
     "nmfx_comm_get_unique_id", "nmfx_comm_init", "nmfx_objective", "nmfx_profile_enable", "nmfx_profile_get",
-    "nmfx_device_info", "nmfx_check_nonneg", "nmfx_randinit", "nmfx_solve_replicates", "nmfx_nndsvd", "nmfx_get_iter_trace",
+    "nmfx_device_info", "nmfx_check_nonneg", "nmfx_randinit", "nmfx_solve_replicates", "nmfx_nndsvd", "nmfx_get_iter_trace", "nmfx_rsvd_begin", "nmfx_rsvd_finish",
 ]
 
 
@@ -87,6 +87,8 @@ def load():
     lib.nmfx_solve_replicates.argtypes = [vp, i32, C.POINTER(Opts), i32, C.c_uint64, i32, i64, vp, vp, C.POINTER(CResult),
                                           C.POINTER(i32)]
     lib.nmfx_nndsvd.argtypes = [vp, vp, vp, vp, i32, i32, C.c_uint64, i64]
+    lib.nmfx_rsvd_begin.argtypes = [vp, C.c_uint64, i64, i32, vp]
+    lib.nmfx_rsvd_finish.argtypes = [vp, vp, vp, vp, vp]
     lib.nmfx_get_iter_trace.argtypes = [vp, vp, vp, i32, C.POINTER(i32)]
     lib.nmfx_profile_enable.argtypes = [vp, i32]
     lib.nmfx_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32, C.POINTER(i32)]

@@ -327,9 +327,35 @@ class Context:
                                                 W.ctypes.data, H.ctypes.data, C.byref(res), C.byref(best)))
         return res, best.value
 
-    def nndsvd_init(self, U, s, V, variant="std", zeroh=False, seed=0, n_total=None):
-        """_nndsvd! (src/initialization.jl:26-72) on the device from a given truncated SVD: fills the resident W, H."""
+    def rsvd(self, seed=0, h_col_offset=0, download=True, power_iters=0):
+        """rsvd(X, k) (src/initialization.jl:83) on the resident X: the device does the p*n*k products and the
+        orthogonalisation, the k x k symmetric eigenproblem is solved here with LAPACK (like the reference's small svd).
+        Returns (U, s, V) with V n x k when download, else None; the triple stays resident for nndsvd_init(None, ...)."""
         T, k = self.T, self.k
+        Cm = np.empty((k, k), dtype=T, order="F")
+        self._ck(self.lib.nmfx_rsvd_begin(self.h, seed, h_col_offset, power_iters, Cm.ctypes.data))
+        ev, Ub = np.linalg.eigh(((Cm + Cm.T) * 0.5).astype(np.float64))
+        order = np.argsort(ev)[::-1]
+        s = np.sqrt(np.maximum(ev[order], 0.0)).astype(T)
+        Ub = np.asfortranarray(Ub[:, order].astype(T))
+        if not download:
+            self._ck(self.lib.nmfx_rsvd_finish(self.h, Ub.ctypes.data, s.ctypes.data, None, None))
+            return None
+        U = np.empty((self.p, k), dtype=T, order="F")
+        Vt = np.empty((k, self.n), dtype=T, order="F")
+        self._ck(self.lib.nmfx_rsvd_finish(self.h, Ub.ctypes.data, s.ctypes.data, U.ctypes.data, Vt.ctypes.data))
+        return U, s, np.asfortranarray(Vt.T)
+
+    def nndsvd_init(self, U, s, V, variant="std", zeroh=False, seed=0, n_total=None):
+        """_nndsvd! (src/initialization.jl:26-72) on the device from a given truncated SVD (U = s = V = None: the one
+        left resident by rsvd()): fills the resident W, H."""
+        T, k = self.T, self.k
+        ivar = {"std": 0, "a": 1, "ar": 2}.get(variant)
+        if ivar is None:
+            raise ArgumentError("Invalid value for variant")
+        if U is None:
+            self._ck(self.lib.nmfx_nndsvd(self.h, None, None, None, ivar, int(zeroh), seed, self.n if n_total is None else n_total))
+            return
         U = np.asfortranarray(np.asarray(U)[:, :k], dtype=T)
         V = np.asfortranarray(np.asarray(V)[:, :k], dtype=T)
         s = np.ascontiguousarray(np.asarray(s)[:k], dtype=T)
@@ -459,20 +485,38 @@ def truncated_svd(X, k):
     return U[:, :k].astype(T), s[:k].astype(T), Vt[:k].T.astype(T)
 
 
-def nndsvd(X, k, zeroh=False, variant="std", initdata=None, seed=0, ctx: Context | None = None):
-    """nndsvd(X, k; zeroh, variant, initdata) (src/initialization.jl:74-101): the SVD comes from `initdata` = (U, s, V) or
-    from truncated_svd(X, k) on the host; _nndsvd! runs on the device."""
+def rsvd(X, k, seed=0, ctx: Context | None = None, power_iters=0):
+    """rsvd(X, k) -> (U, s, V) on the device (Context.rsvd)."""
+    own = ctx is None
+    if own:
+        ctx = Context(X.dtype.type, X.shape[0], X.shape[1], k)
+        ctx.set_X(np.asfortranarray(X))
+    try:
+        return ctx.rsvd(seed, power_iters=power_iters)
+    finally:
+        if own:
+            ctx.close()
+
+
+def nndsvd(X, k, zeroh=False, variant="std", initdata=None, seed=0, ctx: Context | None = None, power_iters=0):
+    """nndsvd(X, k; zeroh, variant, initdata) (src/initialization.jl:74-101): the SVD comes from `initdata` = (U, s, V) or,
+    like the reference's default, from the randomized rsvd(X, k) -- run on the device, its result never leaves it;
+    _nndsvd! runs on the device."""
     T = X.dtype.type
     p, n = X.shape
     if variant not in ("std", "a", "ar"):
         raise ArgumentError("Invalid value for variant")
-    U, s, V = truncated_svd(X, k) if initdata is None else initdata
     own = ctx is None
     if own:
         ctx = Context(T, p, n, k)
-        if variant != "std":
+        if variant != "std" or initdata is None:
             ctx.set_X(np.asfortranarray(X))
     try:
+        if initdata is None:
+            ctx.rsvd(seed, download=False, power_iters=power_iters)
+            U = s = V = None
+        else:
+            U, s, V = initdata
         ctx.nndsvd_init(U, s, V, variant=variant, zeroh=zeroh, seed=seed)
         W = np.empty((p, k), dtype=T, order="F")
         H = np.empty((k, n), dtype=T, order="F")
@@ -625,7 +669,11 @@ def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, ve
             if init == "random":
                 ctx.randinit(seed, normalize=True, zeroh=not initH)
             else:                                                        # src/interf.jl:44-49
-                U, s, V = truncated_svd(X, k) if initdata is None else initdata
+                if initdata is None:
+                    ctx.rsvd(seed, download=False)                       # rsvd(X, k), src/initialization.jl:83
+                    U = s = V = None
+                else:
+                    U, s, V = initdata
                 ctx.nndsvd_init(U, s, V, variant={"nndsvd": "std", "nndsvda": "a", "nndsvdar": "ar"}[init], zeroh=not initH, seed=seed)
             ctx.get_factors(W, H)
         if verbose:

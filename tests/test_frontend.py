@@ -217,3 +217,55 @@ def test_nnmf_with_reference_defaults(built):
     for alg in ("multmse", "multdiv", "projals", "alspgrad", "cd", "greedycd"):
         ra = nmfx.nnmf(X, 5, init="nndsvd", alg=alg, maxiter=20, initdata=F)
         assert np.isfinite(ra.objvalue) and (ra.W >= 0).all() and (ra.H >= 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(300, 260, 8), (129, 515, 20), (700, 600, 70), (1100, 900, 130)])
+def test_rsvd_contract(built, T, shape):
+    """rsvd(X, k) on the device (src/initialization.jl:83).  Julia's randn stream is not reproducible, so the contract of the
+    randomized SVD is pinned instead: orthonormal U and V, non-negative descending s, and on a matrix of numerical rank k
+    (planted + 1 % noise) a reconstruction error close to the optimal rank-k truncation."""
+    import nmfx
+    from problems import planted
+    p, n, k = shape
+    X, _, _ = planted(p, n, k, T, seed=3 * p + n)
+    X64 = X.astype(np.float64)
+    sv = np.linalg.svd(X64, compute_uv=False)
+    best = np.sqrt(np.sum(sv[k:] ** 2))
+    eps = np.finfo(T).eps
+    for q, slack in ((0, None), (1, 1.05)):
+        U, s, V = nmfx.rsvd(X, k, seed=99, power_iters=q)
+        assert U.shape == (p, k) and V.shape == (n, k) and s.shape == (k,)
+        assert np.all(np.diff(s) <= 0) and s[-1] >= 0
+        assert np.abs(U.T.astype(np.float64) @ U - np.eye(k)).max() < 200 * eps
+        assert np.abs(V.T.astype(np.float64) @ V - np.eye(k)).max() < (2e-3 if T == np.float32 else 1e-9)
+        err = np.linalg.norm(X64 - (U.astype(np.float64) * s) @ V.T.astype(np.float64))
+        if slack is None:
+            # plain k-column sketch: the error is a random multiple of the optimum (a NumPy restatement of the same
+            # algorithm -- QR of X*Omega, no oversampling -- gives 3x .. 30x on these matrices); bound it by the energy
+            assert best <= err * (1 + 1e-9) and err <= 0.1 * sv[0]
+        else:
+            # one power iteration on a matrix with a spectral gap recovers the optimal rank-k error
+            assert err <= slack * best + 50 * eps * sv[0]
+            np.testing.assert_allclose(s, sv[:k], rtol=1e-3 if T == np.float32 else 1e-6)
+    # same seed -> same result
+    U2, s2, _ = nmfx.rsvd(X, k, seed=99, power_iters=1)
+    assert np.array_equal(U, U2) and np.array_equal(s, s2)
+
+
+@pytest.mark.gpu
+def test_nndsvd_default_svd_is_the_device_rsvd(built):
+    import nmfx
+    T = np.float64
+    X, _, _ = uniform(90, 120, 6, T, seed=4)
+    W, H = nmfx.nndsvd(X, 6)                      # no initdata: rsvd on the device, result never leaves it
+    assert W.shape == (90, 6) and H.shape == (6, 120) and (W >= 0).all() and (H >= 0).all()
+    W2, H2 = nmfx.nndsvd(X, 6, zeroh=True)
+    assert np.array_equal(W2, W) and not H2.any()  # test/initialization.jl:37-43 (same seed)
+    Wr, _ = nmfx.nndsvd(X, 6, variant="ar")
+    assert (Wr > 0).all()
+    # leading component: close to the exact SVD's (the randomized sketch captures the dominant direction)
+    We, _ = nmfx.nndsvd(X, 6, initdata=nmfx.truncated_svd(X, 6))
+    Wp, _ = nmfx.nndsvd(X, 6, power_iters=3)
+    assert np.abs(Wp[:, 0] - We[:, 0]).max() < 0.02 * np.abs(We[:, 0]).max()

@@ -11,6 +11,7 @@
 module NMFX
 
 using NMF
+import LinearAlgebra
 using LinearAlgebra: PosDefException
 
 const libnmfx = get(ENV, "NMFX_LIB", joinpath(@__DIR__, "..", "lib", "libnmfx.so"))

@@ -1,6 +1,6 @@
 """Shape sweep on the GPU box: every algorithm, both dtypes, awkward sizes, compared with the NumPy oracle."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for sub in ("nmf.jl_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, sub))
 import numpy as np

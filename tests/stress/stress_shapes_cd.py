@@ -1,6 +1,6 @@
 """extra shape sweep (cd / greedycd dispatch paths, odd k)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for sub in ("nmf.jl_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, sub))
 import numpy as np

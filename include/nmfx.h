@@ -82,7 +82,14 @@ typedef struct {
      * as its L1 coefficients (src/greedycd.jl:15-16).  shuffle=true (a Julia-RNG permutation of the components) is not
      * offered: the sweep always runs in component order. */
     double l1_w, l2_w, l1_h, l2_h;
+    /* arithmetic of the two p*n*k products.  NMFX_PREC_FP32 (0, default): v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64,
+     * the element type's own arithmetic.  NMFX_PREC_BF16X3 (1; f32 contexts with k >= 65, ignored otherwise): operands split
+     * into bf16 pairs, three bf16 MFMA products per term, fp32 accumulation (csrc/gemm_bf16x3.hpp) -- ~2.2x faster launches,
+     * GEMM error vs fp64 as small as the fp32 path's; opt-in because the inputs are rounded to 16 mantissa bits. */
+    int32_t precision;
+    int32_t reserved;
 } nmfx_opts;
+enum { NMFX_PREC_FP32 = 0, NMFX_PREC_BF16X3 = 1 };
 
 /* NMF.Result{T} minus the matrices (src/common.jl:21-27), plus measurement fields */
 typedef struct {

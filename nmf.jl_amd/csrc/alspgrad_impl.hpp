@@ -94,6 +94,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
 }
 
 template <typename T> void Solver<T>::subsolve(int which, const nmfx_opts &o, nmfx_result *out) {
+    precision = o.precision;
     require_ready();
     HIP_TRY(hipSetDevice(device));
     std::memset(out, 0, sizeof *out);

@@ -20,6 +20,7 @@
 
 #include "../../include/nmfx.h"
 #include "gemm_mfma.hpp"
+#include "gemm_bf16x3.hpp"
 #include "kernels.hpp"
 #include "cd.hpp"
 
@@ -472,8 +473,37 @@ template <typename T> class Solver : public SolverBase {
     // keep_slabs: leave the result as split-K slabs in the H region (caller consumes h_nslab slabs of stride h_stride).
     int h_nslab = 1;
     int64_t h_stride = 0;
+    // nmfx_opts.precision = NMFX_PREC_BF16X3: the two p*n*k products run on the bf16 matrix cores (gemm_bf16x3.hpp)
+    int precision = 0;
+    bool use_bf16x3() const { return precision == 1 && sizeof(T) == 4 && K % 128 == 0; }
+    template <int KS>
+    void launch_bf16x3(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim, int splits,
+                       bool c_fastest, T *D, int64_t ldd, int64_t slab_stride, const int *done) {
+        if constexpr (sizeof(T) == 4) {
+            const int tiles_r = (int)(R / 128), tiles_c = (int)(C / 128), tiles = tiles_r * tiles_c;
+            timed(name, 2.0 * (double)R * (double)C * (double)Kdim, (double)(R + C) * Kdim * sizeof(T), [&] {
+                hipLaunchKernelGGL((bf16x3::gemm_bf16x3_kernel<KS>), dim3((unsigned)(tiles * splits)), dim3(256), 0, stream,
+                                   reinterpret_cast<const float *>(A), reinterpret_cast<const float *>(B), reinterpret_cast<float *>(D), lda, ldb,
+                                   ldd, tiles_r, tiles_c, tiles, (int)(Kdim / splits), slab_stride, c_fastest ? 1 : 0, done);
+                HIP_TRY(hipGetLastError());
+            });
+            last_tiles_r = tiles_r; last_blocks = tiles * splits;
+        }
+    }
     void wt_times(const T *Wp, const T *Bmat, bool with_gram, const int *done, bool keep_slabs = false) {
         T *reg = slabs.p;
+        if (use_bf16x3()) {
+            h_nslab = s_h; h_stride = (int64_t)K * N;
+            launch_bf16x3<0>("gemm_WtX_bf16x3", Bmat, P, N, Wp, P, K, P, s_h, true, reg, K, h_stride, done);
+            if (!keep_slabs || h_nslab > 2) { reduce_slabs_from("reduce_WtX", numH_p, reg, h_stride, h_nslab, done); h_in_slabs = false; }
+            else h_in_slabs = true;
+            if (with_gram) {   // the k x k Gram stays on the fp32 path
+                EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
+                gemm<KCONTIG, KCONTIG>("gemm_WtW", Wp, P, K, Wp, P, K, P, s_gw, true, eg, done, (double)(P * K) * sizeof(T));
+                reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gw, done);
+            }
+            return;
+        }
         if (with_gram && fuse_gram && K % 128 == 0) {
             h_nslab = s_h; h_stride = (int64_t)K * N;
             const int tiles = (int)((N / 128) * (K / 128));
@@ -523,6 +553,18 @@ template <typename T> class Solver : public SolverBase {
     int64_t w_stride = 0;
     void times_ht(const T *Amat, const T *Hp, bool with_gram, const int *done, bool keep_slabs = false) {
         T *reg = slabs.p + slab_w_off;
+        if (use_bf16x3()) {
+            w_nslab = s_w; w_stride = (int64_t)P * K;
+            launch_bf16x3<1>("gemm_XHt_bf16x3", Hp, K, K, Amat, P, P, N, s_w, false, reg, P, w_stride, done);
+            if (!keep_slabs || w_nslab > 2) { reduce_slabs_from("reduce_XHt", numW_p, reg, w_stride, w_nslab, done); w_in_slabs = false; }
+            else w_in_slabs = true;
+            if (with_gram) {
+                EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
+                gemm<KSTRIDED, KSTRIDED>("gemm_HHt", Hp, K, K, Hp, K, K, N, s_gh, true, eg, done, (double)(K * N) * sizeof(T));
+                reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gh, done);
+            }
+            return;
+        }
         if (with_gram && fuse_gram && K % 128 == 0) {
             w_nslab = s_w; w_stride = (int64_t)P * K;
             const int tiles = (int)((K / 128) * (P / 128));

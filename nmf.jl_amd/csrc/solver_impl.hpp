@@ -186,6 +186,8 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         if (!(o.lambda_h >= 0)) throw StatusError{NMFX_ERR_BAD_ARG, "lambda_h must be non-negative."};
     }
     if (alg < 0 || alg > NMFX_ALG_GREEDYCD) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid algorithm."};
+    if (o.precision != NMFX_PREC_FP32 && o.precision != NMFX_PREC_BF16X3) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for precision."};
+    precision = o.precision;
     HIP_TRY(hipSetDevice(device));
     std::memset(out, 0, sizeof *out);
     if (alg == NMFX_ALG_ALSPGRAD) { run_alspgrad(o, out, trace); return; }

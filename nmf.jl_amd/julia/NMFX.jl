@@ -35,6 +35,8 @@ struct COpts
     l2_w::Float64
     l1_h::Float64
     l2_h::Float64
+    precision::Int32   # 0 = fp32 (default), 1 = bf16x3 (include/nmfx.h)
+    reserved::Int32
 end
 
 # struct nmfx_result
@@ -102,9 +104,9 @@ function run!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, H::Matrix{T})
 end
 
 opts(T; maxiter, tol, update_H, lambda_w=0.0, lambda_h=0.0, maxsubiter=200, tolg=eps(T)^(1/4),
-     l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0) =
+     l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision=0) =
     COpts(maxiter, update_H, 0, maxsubiter, 20, 4, tol, lambda_w, lambda_h, sqrt(eps(T)), tolg, T(0.2), T(0.01),
-          l1_w, l2_w, l1_h, l2_h)
+          l1_w, l2_w, l1_h, l2_h, precision, 0)
 
 # ---- solve! methods: same signatures as src/multupd.jl:45, src/projals.jl:37, src/alspgrad.jl:381, with a
 # ---- leading device Context.  `solve!(alg, X, W, H)` without a Context creates one for the call.

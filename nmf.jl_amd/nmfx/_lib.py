@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("NMFX_LIB", os.path.join(_HERE, "..", "lib", "libnmfx.
 
 F32, F64 = 0, 1
 ALG_MULTMSE, ALG_MULTDIV, ALG_PROJALS, ALG_ALSPGRAD, ALG_CD, ALG_GREEDYCD = 0, 1, 2, 3, 4, 5
+PREC_FP32, PREC_BF16X3 = 0, 1
 OK, ERR_BAD_ARG, ERR_DIM_MISMATCH, ERR_NOT_POSDEF, ERR_ALPHA_NONFINITE, ERR_HIP, ERR_RCCL, ERR_NO_DEVICE, ERR_STATE, ERR_UNSUPPORTED = range(10)
 UNIQUE_ID_BYTES = 128
 
@@ -30,7 +31,8 @@ class Opts(C.Structure):
                 ("maxsubiter", C.c_int32), ("traceiter", C.c_int32), ("check_every", C.c_int32),
                 ("tol", C.c_double), ("lambda_w", C.c_double), ("lambda_h", C.c_double), ("delta", C.c_double),
                 ("tolg", C.c_double), ("beta", C.c_double), ("sigma", C.c_double),
-                ("l1_w", C.c_double), ("l2_w", C.c_double), ("l1_h", C.c_double), ("l2_h", C.c_double)]
+                ("l1_w", C.c_double), ("l2_w", C.c_double), ("l1_h", C.c_double), ("l2_h", C.c_double),
+                ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CResult(C.Structure):

@@ -213,14 +213,15 @@ class Result:
 
 def make_opts(T, maxiter=100, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.0, delta=None, maxsubiter=200,
               traceiter=20, tolg=None, beta=0.2, sigma=0.01, track_objective=False, check_every=4,
-              l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0) -> L.Opts:
+              l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision="fp32") -> L.Opts:
     T = np.dtype(T).type
     return L.Opts(int(maxiter), int(bool(update_H)), int(bool(track_objective)), int(maxsubiter), int(traceiter),
                   int(check_every),
                   float(T(np.cbrt(_eps(T)) if tol is None else tol)), float(lambda_w), float(lambda_h),
                   float(T(math.sqrt(_eps(T))) if delta is None else delta),
                   float(T(_eps(T) ** 0.25) if tolg is None else tolg), float(T(beta)), float(T(sigma)),
-                  float(l1_w), float(l2_w), float(l1_h), float(l2_h))
+                  float(l1_w), float(l2_w), float(l1_h), float(l2_h),
+                  {"fp32": L.PREC_FP32, "bf16x3": L.PREC_BF16X3}[precision], 0)
 
 
 def nmf_checksize(X, W, H):
@@ -405,7 +406,7 @@ def _result(T, W, H, res, trace):
                        final_tolg=res.final_tolg))
 
 
-def solve(alg, X, W, H, ctx: Context | None = None, track_objective=False, check_every=4) -> Result:
+def solve(alg, X, W, H, ctx: Context | None = None, track_objective=False, check_every=4, precision="fp32") -> Result:
     """NMF.solve!(alg, X, W, H): W and H (Fortran-ordered, dtype of X) are updated in place."""
     p, n, k = nmf_checksize(X, W, H)
     T = alg.T
@@ -417,7 +418,7 @@ def solve(alg, X, W, H, ctx: Context | None = None, track_objective=False, check
         ctx.set_X(X)
     track_objective = track_objective or bool(getattr(alg, "verbose", False))   # verbose = true evaluates every iteration
     try:
-        o = make_opts(T, track_objective=track_objective, check_every=check_every, **alg._opts())
+        o = make_opts(T, track_objective=track_objective, check_every=check_every, precision=precision, **alg._opts())
         res, trace = ctx.solve(alg._alg(), o, W, H)
         out = _result(T, W, H, res, trace)
         if track_objective:

@@ -11,3 +11,4 @@ python bench.py --no-cpu-baseline --alg alspgrad --dtype f64 --p 32768 --n 4096 
 python bench.py --no-cpu-baseline --dtype f64 --p 8192 --n 8192 --k 256 --steps 30 --warmup 10            # f64 multmse
 python bench.py --no-cpu-baseline --alg cd --steps 30 --warmup 10                                         # CoordinateDescent at the C3 shape
 python bench.py --no-cpu-baseline --alg greedycd --steps 20 --warmup 10                                   # GreedyCD (nnmf's default algorithm) at the C3 shape
+python bench.py --no-cpu-baseline --precision bf16x3                                                        # OPT-IN mixed-precision big GEMMs (not the headline)

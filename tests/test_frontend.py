@@ -249,9 +249,13 @@ def test_rsvd_contract(built, T, shape):
             # one power iteration on a matrix with a spectral gap recovers the optimal rank-k error
             assert err <= slack * best + 50 * eps * sv[0]
             np.testing.assert_allclose(s, sv[:k], rtol=1e-3 if T == np.float32 else 1e-6)
-    # same seed -> same result
-    U2, s2, _ = nmfx.rsvd(X, k, seed=99, power_iters=1)
-    assert np.array_equal(U, U2) and np.array_equal(s, s2)
+    # same seed -> same sketch: the device half is bit-reproducible, the host LAPACK step in the middle need not be (its
+    # eigenvectors of the nearly degenerate noise-level eigenvalues move with the last bit), so compare what is well defined
+    U2, s2, V2 = nmfx.rsvd(X, k, seed=99, power_iters=1)
+    np.testing.assert_allclose(s2, s, rtol=1e-4 if T == np.float32 else 1e-9)
+    A1 = (U.astype(np.float64) * s) @ V.T.astype(np.float64)
+    A2 = (U2.astype(np.float64) * s2) @ V2.T.astype(np.float64)
+    assert np.linalg.norm(A1 - A2) <= (1e-4 if T == np.float32 else 1e-9) * sv[0]
 
 
 @pytest.mark.gpu

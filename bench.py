@@ -181,7 +181,8 @@ def main():
                 except Exception:
                     traffic = None
             # bf16x3: three dense-bf16 MFMA products (2.5 PFLOP/s peak) per fp32-equivalent product
-            peak = (2500.0 / 3.0) if (a.precision == "bf16x3" and "bf16x3" in dom["name"]) else (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6)
+            on_bf16 = a.precision == "bf16x3" and a.dtype == "f32" and ("bf16x3" in dom["name"] or dom["name"].startswith("gemm_WH_"))
+            peak = (2500.0 / 3.0) if on_bf16 else (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6)
             roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2),
                     "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4),

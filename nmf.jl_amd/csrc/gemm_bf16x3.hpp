@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gemm_mfma.hpp"
+
 namespace nmfx {
 namespace bf16x3 {
 
@@ -82,22 +84,44 @@ __device__ __forceinline__ bf16x8 frag(const char *plane, int rt, int ks, int la
     return *reinterpret_cast<const bf16x8 *>(plane + lds_off(r, c));
 }
 
-// KS = 0: both operands KCONTIG (A(r,k) at A[r*lda + k]);  KS = 1: both KSTRIDED (A(r,k) at A[k*lda + r])
-template <int KS>
-__global__ __launch_bounds__(NT) void gemm_bf16x3_kernel(const float *A, const float *B, float *D, int64_t lda, int64_t ldb, int64_t ldd,
-                                                         int tiles_r, int tiles_c, int tiles, int kchunk, int64_t slab_stride,
-                                                         int c_fastest, const int *done) {
-    if (done != nullptr && *reinterpret_cast<const volatile int *>(done) != 0) return;
+// Operand layouts per side (LA / LB): 0 = KCONTIG (A(r,k) at A[r*lda + k]), 1 = KSTRIDED (A(r,k) at A[k*lda + r]).
+// Epi is one of the epilogue functors of gemm_mfma.hpp (same accumulator layout as the fp32 32x32 MFMA: 16 registers per
+// tile, col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), so the fused ratio / objective / store epilogues are shared.
+struct Args {
+    const float *A, *B;
+    int64_t lda, ldb;
+    int tiles_r, tiles_c, splits, kchunk, c_fastest, group;
+    const int *done;
+};
+
+template <int LA, int LB, typename Epi>
+__global__ __launch_bounds__(NT) void gemm_bf16x3_kernel(Args g, Epi epi) {
+    if (g.done != nullptr && *reinterpret_cast<const volatile int *>(g.done) != 0) return;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    const int split = bid / tiles, trem = bid % tiles;
-    const int tc = c_fastest ? trem % tiles_c : trem / tiles_r, tr = c_fastest ? trem / tiles_c : trem % tiles_r;
-    const int64_t r0 = (int64_t)tr * BR, c0 = (int64_t)tc * BC, kbeg = (int64_t)split * kchunk;
-    const int nk = kchunk / BK;
+    const int tiles = g.tiles_r * g.tiles_c;
+    int split = bid / tiles;
+    const int trem = bid % tiles;
+    int tr, tc;
+    if (g.group > 1) {   // 2-D super-tiles (see gemm_mfma_kernel)
+        const int G = g.group, per = G * G;
+        const int st = trem / per, in = trem % per;
+        const int sr = st / (g.tiles_c / G), sc = st % (g.tiles_c / G);
+        tr = sr * G + in / G;
+        tc = sc * G + in % G;
+    } else if (g.c_fastest) { tc = trem % g.tiles_c; tr = trem / g.tiles_c; }
+    else { tr = trem % g.tiles_r; tc = trem / g.tiles_r; }
+    tr = __builtin_amdgcn_readfirstlane(tr);
+    tc = __builtin_amdgcn_readfirstlane(tc);
+    split = __builtin_amdgcn_readfirstlane(split);
+    const int64_t r0 = (int64_t)tr * BR, c0 = (int64_t)tc * BC, kbeg = (int64_t)split * g.kchunk;
+    const int nk = g.kchunk / BK;
+    TileCtx tctx{tr, tc, wr, wc, lane, tid, NT, (int)blockIdx.x, r0, c0, 4 * (lane >> 5), lane & 31, r0 + wr * 64, c0 + wc * 64};
+    epi.setup(split, tctx);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -106,26 +130,19 @@ __global__ __launch_bounds__(NT) void gemm_bf16x3_kernel(const float *A, const f
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     f32x4 ra[4], rb[4];
-    auto ld = [&](f32x4 (&r)[4], const float *base, int64_t l, int64_t row0, int64_t k0) {
-        if constexpr (KS) load_tile_ks(r, base, l, row0, k0, tid); else load_tile(r, base, l, row0, k0, tid);
-    };
-    auto st = [&](const f32x4 (&r)[4], char *oper) {
-        if constexpr (KS) store_tile_ks(r, oper, tid); else store_tile(r, oper, tid);
-    };
-    ld(ra, A, lda, r0, kbeg);
-    ld(rb, B, ldb, c0, kbeg);
-    st(ra, smem);
-    st(rb, smem + OPER);
-    if (nk > 1) { ld(ra, A, lda, r0, kbeg + BK); ld(rb, B, ldb, c0, kbeg + BK); }
+    auto lda_ = [&](int64_t k0) { if constexpr (LA) load_tile_ks(ra, g.A, g.lda, r0, k0, tid); else load_tile(ra, g.A, g.lda, r0, k0, tid); };
+    auto ldb_ = [&](int64_t k0) { if constexpr (LB) load_tile_ks(rb, g.B, g.ldb, c0, k0, tid); else load_tile(rb, g.B, g.ldb, c0, k0, tid); };
+    auto sta_ = [&](char *oper) { if constexpr (LA) store_tile_ks(ra, oper, tid); else store_tile(ra, oper, tid); };
+    auto stb_ = [&](char *oper) { if constexpr (LB) store_tile_ks(rb, oper, tid); else store_tile(rb, oper, tid); };
+    lda_(kbeg); ldb_(kbeg);
+    sta_(smem); stb_(smem + OPER);
+    if (nk > 1) { lda_(kbeg + BK); ldb_(kbeg + BK); }
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const char *a_s = smem + (t & 1) * STAGE, *b_s = a_s + OPER;
         char *a_n = smem + ((t & 1) ^ 1) * STAGE, *b_n = a_n + OPER;
-        if (t + 1 < nk) { st(ra, a_n); st(rb, b_n); }
-        if (t + 2 < nk) {
-            ld(ra, A, lda, r0, kbeg + (int64_t)(t + 2) * BK);
-            ld(rb, B, ldb, c0, kbeg + (int64_t)(t + 2) * BK);
-        }
+        if (t + 1 < nk) { sta_(a_n); stb_(b_n); }
+        if (t + 2 < nk) { lda_(kbeg + (int64_t)(t + 2) * BK); ldb_(kbeg + (int64_t)(t + 2) * BK); }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
@@ -144,17 +161,22 @@ __global__ __launch_bounds__(NT) void gemm_bf16x3_kernel(const float *A, const f
         }
         __syncthreads();
     }
-    float *dst = D + (int64_t)split * slab_stride;
+    // epilogue: per row of MFMA tiles, request the inputs, then compute and store (gemm_mfma.hpp conventions)
+    epi.begin();
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        typename Epi::Pre pre[2][16];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int64_t r = r0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                const int64_t c = c0 + wc * 64 + j * 32 + (lane & 31);
-                dst[c + r * ldd] = acc[i][j][reg];
-            }
+            for (int reg = 0; reg < 16; ++reg) pre[j][reg] = epi.prefetch(i * 32 + (reg & 3) + 8 * (reg >> 2), j * 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) epi.apply(i * 32 + (reg & 3) + 8 * (reg >> 2), j * 32, acc[i][j][reg], j, pre[j][reg]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    epi.template finish<32, 2, 2, 2>(reinterpret_cast<double *>(smem), tctx);
 }
 
 }  // namespace bf16x3

@@ -476,25 +476,39 @@ template <typename T> class Solver : public SolverBase {
     // nmfx_opts.precision = NMFX_PREC_BF16X3: the two p*n*k products run on the bf16 matrix cores (gemm_bf16x3.hpp)
     int precision = 0;
     bool use_bf16x3() const { return precision == 1 && sizeof(T) == 4 && K % 128 == 0; }
-    template <int KS>
+    template <int LA, int LB, typename Epi>
     void launch_bf16x3(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim, int splits,
-                       bool c_fastest, T *D, int64_t ldd, int64_t slab_stride, const int *done) {
+                       bool c_fastest, const Epi &epi, const int *done, double bytes) {
         if constexpr (sizeof(T) == 4) {
-            const int tiles_r = (int)(R / 128), tiles_c = (int)(C / 128), tiles = tiles_r * tiles_c;
-            timed(name, 2.0 * (double)R * (double)C * (double)Kdim, (double)(R + C) * Kdim * sizeof(T), [&] {
-                hipLaunchKernelGGL((bf16x3::gemm_bf16x3_kernel<KS>), dim3((unsigned)(tiles * splits)), dim3(256), 0, stream,
-                                   reinterpret_cast<const float *>(A), reinterpret_cast<const float *>(B), reinterpret_cast<float *>(D), lda, ldb,
-                                   ldd, tiles_r, tiles_c, tiles, (int)(Kdim / splits), slab_stride, c_fastest ? 1 : 0, done);
+            bf16x3::Args g;
+            g.A = reinterpret_cast<const float *>(A); g.B = reinterpret_cast<const float *>(B);
+            g.lda = lda; g.ldb = ldb;
+            g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 128); g.splits = splits; g.kchunk = (int)(Kdim / splits);
+            g.c_fastest = c_fastest ? 1 : 0;
+            g.group = (splits == 1 && g.tiles_r >= 16 && g.tiles_c >= 16 && g.tiles_r % 8 == 0 && g.tiles_c % 8 == 0) ? 8 : 1;
+            g.done = done;
+            const int blocks = g.tiles_r * g.tiles_c * splits;
+            timed(name, 2.0 * (double)R * (double)C * (double)Kdim, bytes, [&] {
+                hipLaunchKernelGGL((bf16x3::gemm_bf16x3_kernel<LA, LB, Epi>), dim3((unsigned)blocks), dim3(256), 0, stream, g, epi);
                 HIP_TRY(hipGetLastError());
             });
-            last_tiles_r = tiles_r; last_blocks = tiles * splits;
+            last_tiles_r = g.tiles_r; last_blocks = blocks;
         }
+    }
+    // the W*H products with a fused epilogue (ratio pass, objective): fp32 kernel, or the bf16x3 one when opted in
+    template <typename Epi>
+    void gemm_wh(const char *name, const T *Hp, const T *Wp, const Epi &epi, const int *done, double bytes) {
+        if (use_bf16x3() && P % 128 == 0 && N % 128 == 0) launch_bf16x3<0, 1>(name, Hp, K, N, Wp, P, P, K, 1, true, epi, done, bytes);
+        else gemm<KCONTIG, KSTRIDED>(name, Hp, K, N, Wp, P, P, K, 1, true, epi, done, bytes);
     }
     void wt_times(const T *Wp, const T *Bmat, bool with_gram, const int *done, bool keep_slabs = false) {
         T *reg = slabs.p;
         if (use_bf16x3()) {
             h_nslab = s_h; h_stride = (int64_t)K * N;
-            launch_bf16x3<0>("gemm_WtX_bf16x3", Bmat, P, N, Wp, P, K, P, s_h, true, reg, K, h_stride, done);
+            {
+                EpiStore<T> e{reg, K, h_stride, nullptr};
+                launch_bf16x3<0, 0>("gemm_WtX_bf16x3", Bmat, P, N, Wp, P, K, P, s_h, true, e, done, (double)(P * N + P * K) * sizeof(T));
+            }
             if (!keep_slabs || h_nslab > 2) { reduce_slabs_from("reduce_WtX", numH_p, reg, h_stride, h_nslab, done); h_in_slabs = false; }
             else h_in_slabs = true;
             if (with_gram) {   // the k x k Gram stays on the fp32 path
@@ -555,7 +569,10 @@ template <typename T> class Solver : public SolverBase {
         T *reg = slabs.p + slab_w_off;
         if (use_bf16x3()) {
             w_nslab = s_w; w_stride = (int64_t)P * K;
-            launch_bf16x3<1>("gemm_XHt_bf16x3", Hp, K, K, Amat, P, P, N, s_w, false, reg, P, w_stride, done);
+            {
+                EpiStore<T> e{reg, P, w_stride, nullptr};
+                launch_bf16x3<1, 1>("gemm_XHt_bf16x3", Hp, K, K, Amat, P, P, N, s_w, false, e, done, (double)(P * N + K * N) * sizeof(T));
+            }
             if (!keep_slabs || w_nslab > 2) { reduce_slabs_from("reduce_XHt", numW_p, reg, w_stride, w_nslab, done); w_in_slabs = false; }
             else w_in_slabs = true;
             if (with_gram) {

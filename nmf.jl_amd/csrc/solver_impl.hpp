@@ -15,10 +15,10 @@ void Solver<T>::enqueue_objective(int alg, const nmfx_opts &o, double *dst, cons
     const double bytes = (double)(P * N) * sizeof(T);
     if (alg == NMFX_ALG_MULTDIV) {
         EpiObjective<T, 1> e{X.p, P, obj_part.p, 0.0};
-        gemm<KCONTIG, KSTRIDED>("gemm_WH_kldiv", Hp, K, N, Wp, P, P, K, 1, true, e, done, bytes);
+        gemm_wh("gemm_WH_kldiv", Hp, Wp, e, done, bytes);
     } else {
         EpiObjective<T, 0> e{X.p, P, obj_part.p, 0.0};
-        gemm<KCONTIG, KSTRIDED>("gemm_WH_sqdist", Hp, K, N, Wp, P, P, K, 1, true, e, done, bytes);
+        gemm_wh("gemm_WH_sqdist", Hp, Wp, e, done, bytes);
     }
     const int nblk = last_blocks;   // one Float64 partial per block of the launch above
     int nextra = 0;
@@ -133,7 +133,7 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
         const T *Ho = H[hcur].p;
         T *Hn = H[hcur ^ 1].p;
         EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                           // :172-174
-        gemm<KCONTIG, KSTRIDED>("gemm_WH_ratio", Ho, K, N, Wp, P, P, K, 1, true, er, done, qbytes);
+        gemm_wh("gemm_WH_ratio", Ho, Wp, er, done, qbytes);
         wt_times(Wp, Q.p, false, done);                                    // :175
         timed("colsum_W", 0.0, (double)P * K * sizeof(T), [&] {            // :176
             hipLaunchKernelGGL(col_sum_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wp, P, P, (int)K,
@@ -152,7 +152,7 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
     EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                               // :184-186
-    gemm<KCONTIG, KSTRIDED>("gemm_WH_ratio", Hp, K, N, Wo, P, P, K, 1, true, er, done, qbytes);
+    gemm_wh("gemm_WH_ratio", Hp, Wo, er, done, qbytes);
     times_ht(Q.p, Hp, false, done);                                        // :187
     T *sH = sH_p;                                                          // tail of the packed buffer
     timed("rowsum_H", 0.0, (double)K * N * sizeof(T), [&] {                // :188

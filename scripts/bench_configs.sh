@@ -12,3 +12,4 @@ python bench.py --no-cpu-baseline --dtype f64 --p 8192 --n 8192 --k 256 --steps 
 python bench.py --no-cpu-baseline --alg cd --steps 30 --warmup 10                                         # CoordinateDescent at the C3 shape
 python bench.py --no-cpu-baseline --alg greedycd --steps 20 --warmup 10                                   # GreedyCD (nnmf's default algorithm) at the C3 shape
 python bench.py --no-cpu-baseline --precision bf16x3                                                        # OPT-IN mixed-precision big GEMMs (not the headline)
+python bench.py --no-cpu-baseline --precision bf16x3 --alg multdiv --steps 30 --warmup 10                  # OPT-IN, multdiv

@@ -91,6 +91,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "NMFX_BENCH_DEVICE" in os.environ:      # development aid: several ranks on one device (plumbing check on a 1-GPU box)
+        local_rank = int(os.environ["NMFX_BENCH_DEVICE"])
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")

@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--alg", default="multmse", choices=["multmse", "multdiv", "projals", "alspgrad", "cd", "greedycd"])
-    ap.add_argument("--maxsubiter", type=int, default=10, help="alspgrad: inner iteration cap per sub-solve (reference default 200)")
+    ap.add_argument("--maxsubiter", type=int, default=200, help="alspgrad: inner iteration cap per sub-solve (ALSPGrad.maxsubiter, reference default 200)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="bf16x3: OPT-IN mixed-precision form of the two p*n*k products (three bf16 MFMA products per term, fp32 "
@@ -54,7 +54,7 @@ def parse():
     return ap.parse_args()
 
 
-def synth(p, n, k, c0, c1, tdtype, device, normalize_w0=True):
+def synth(p, n, k, c0, c1, tdtype, device, normalize_w0=True, warm=0.0):
     """Planted-rank dense X >= 0: X = Wg Hg + 0.01 U, generated on the device.
     Returns X^T shard as an (n_local, p) row-major tensor == column-major p x n_local, plus host W0, H0 shard."""
     g = torch.Generator(device="cpu")
@@ -62,6 +62,8 @@ def synth(p, n, k, c0, c1, tdtype, device, normalize_w0=True):
     Wg = torch.rand((p, k), generator=g, dtype=torch.float32)
     Hg = torch.rand((k, n), generator=g, dtype=torch.float32)
     W0 = torch.rand((p, k), generator=g, dtype=torch.float64)
+    if warm > 0:
+        W0 = Wg.to(torch.float64) + warm * W0                  # warm start near the planted factor (see main())
     if normalize_w0:
         W0 = W0 / W0.sum(dim=0, keepdim=True)                  # randinit(...; normalize=true), src/interf.jl:43
     H0 = torch.rand((k, n), generator=g, dtype=torch.float64)
@@ -107,10 +109,11 @@ def main():
     p, n, k = a.p, a.n, a.k
     c0, c1 = nmfx.dist.shard_range(n, rank, world)
     nl = c1 - c0
-    # projals: with column-normalised W0 the first H = (W'W + lambda I)^-1 W'X has nearly parallel rows and H H' is not
-    # numerically positive definite in fp32 (the reference's potrf! throws PosDefException on the same input): the
-    # projals workload starts from the un-normalised U[0,1) W0 instead
-    Xt, W0, H0 = synth(p, n, k, c0, c1, tdtype, device, normalize_w0=(a.alg != "projals"))
+    # projals: with a cold column-normalised W0 the first H = (W'W + lambda I)^-1 W'X has nearly parallel rows and H H' is not
+    # numerically positive definite in fp32 (the reference's potrf! throws PosDefException on the same input), and a cold
+    # un-normalised U[0,1) start leaves cond(HH' + lambda I) ~ 1e8 (tests/test_gpu_c4_c5.py): the projals workload is a warm
+    # start W0 = Wg + 0.05 U, where both Grams stay at cond ~ 1e3 and the fp32 iterates are meaningful
+    Xt, W0, H0 = synth(p, n, k, c0, c1, tdtype, device, normalize_w0=(a.alg != "projals"), warm=(0.05 if a.alg == "projals" else 0.0))
     torch.cuda.synchronize()
 
     algid = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3, "cd": 4, "greedycd": 5}[a.alg]

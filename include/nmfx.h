@@ -188,15 +188,34 @@ int nmfx_nndsvd(nmfx_ctx *ctx, const void *U_host, const void *s_host, const voi
 int nmfx_rsvd_begin(nmfx_ctx *ctx, uint64_t seed, int64_t h_col_offset, int power_iters, void *C_host);
 int nmfx_rsvd_finish(nmfx_ctx *ctx, const void *Ub_host, const void *s_host, void *U_out, void *Vt_out);
 
-/* ---- multi-GPU (column sharding, one process per GPU) -----------------------
- * The reference has no distributed path; this is the build's data-parallel extension.
- * Rank r owns columns [c0, c0+n_local) of X and H; W is replicated.  Per outer iteration
- * ONE sum all-reduce (RCCL over xGMI) of the packed buffer [X_g H_g' | H_g H_g' | H row statistics].
- * Usage: rank 0 calls nmfx_comm_get_unique_id, the host broadcasts the 128 bytes by any means,
- * every rank calls nmfx_comm_init.  nranks == 1 is valid (exercises the RCCL path on one GPU). */
+/* ---- multi-GPU (column-sharded X and H) -------------------------------------------------------------------
+ * The reference has no distributed path; this is the build's data-parallel extension (SURVEY.md section 8e).
+ * Rank r owns columns [c0, c0+n_local) of X and H; W is replicated between iterations.  Per outer iteration ONE exchange
+ * step on the W side:
+ *   NMFX_COMM_ROW_SHARDED (default): reduce-scatter of X_g H_g' by row blocks (+ a small all-reduce of H_g H_g', rowsum(H_g)
+ *       and the H statistics) -- rank r then updates only ITS p/nranks rows of W (the update rules, projals' W = XH'(HH')^-1
+ *       and alspgrad's W sub-problem are all row-separable) -- and an all-gather re-assembles W.  Same bytes on the wire as
+ *       the all-reduce, but no replicated W-side work.
+ *   NMFX_COMM_REPLICATED_W: one packed sum all-reduce of [X_g H_g' | H_g H_g' | rowsum(H_g)]; every rank applies the
+ *       identical full W update (round-1 formulation; the fallback when p/nranks is not a whole number of 128-row tiles;
+ *       CoordinateDescent / GreedyCD always use it).
+ * Two transports behind the same code path:
+ *   one process per GPU (production, bench.py): RCCL over xGMI.  Rank 0 calls nmfx_comm_get_unique_id, the host
+ *       broadcasts the 128 bytes by any means, every rank calls nmfx_comm_init.  nranks == 1 is valid.
+ *   several contexts in ONE process, one host thread per context (contexts on different GPUs, or -- for testing the
+ *       sharded path on a 1-GPU box -- on the same GPU): nmfx_local_group_create(nranks) once, then every context calls
+ *       nmfx_comm_init_local(ctx, group, rank) from its own thread (the call is collective).  The collectives are
+ *       hand-written kernels reading the peers' buffers, ordered by hipEvents; reductions add in rank order.
+ * nmfx_comm_init* must precede nmfx_set_X when p is not a multiple of lcm(256, 128*nranks) (the row padding changes). */
 #define NMFX_UNIQUE_ID_BYTES 128
+enum { NMFX_COMM_ROW_SHARDED = 0, NMFX_COMM_REPLICATED_W = 1 };
+typedef struct nmfx_local_group nmfx_local_group;
 int nmfx_comm_get_unique_id(void *out_bytes /* NMFX_UNIQUE_ID_BYTES */);
 int nmfx_comm_init(nmfx_ctx *ctx, const void *unique_id_bytes, int rank, int nranks);
+int nmfx_local_group_create(nmfx_local_group **out, int nranks);   /* nranks <= 16 */
+void nmfx_local_group_destroy(nmfx_local_group *group);            /* after every attached context is destroyed */
+int nmfx_comm_init_local(nmfx_ctx *ctx, nmfx_local_group *group, int rank);
+int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode);
 
 /* ---- standalone passes of the hot path (measurement + parity of the HBM-bound pieces) ----
  * Operate on the resident X, W, H; results are returned by value.

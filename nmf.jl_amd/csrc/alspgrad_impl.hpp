@@ -11,10 +11,14 @@ namespace nmfx {
 template <typename T>
 long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int maxiter, int traceiter, T tolg, T beta,
                                  T sigma, long long *inner_total) {
-    const int64_t rows = left ? K : P, cols = left ? N : K;
-    const int64_t count = rows * cols;
+    // left: Z = H (K x N, this rank's columns).  right: Z = W -- all P rows, or, when the W side is row-sharded, the
+    // rank's row block [row0, row0 + Pc): the caller passes Z and B already offset by row0 (ld stays P), every rank solves
+    // its rows with the SAME global step size (the scalars of the line search are all-reduced, exactly like on the H side).
+    const bool wrows = !left && row_sharded();
+    const int64_t Rw = wrows ? Pc : P;                                     // rows of the W block this call works on
+    const int64_t rows = left ? K : Rw, cols = left ? N : K, ldz = left ? K : P;
     work[3].ensure((size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K));
-    T *G = work[3].p;
+    T *G = work[3].p + (wrows ? row0 : 0);
     pg_part.ensure((size_t)3 * 65536);
     if (!pg_state) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pg_state), sizeof(PgState)));
@@ -25,14 +29,14 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     init.alpha = 1.0;                                                      // :119 alpha = 1 at entry
     init.idle = 1;
     HIP_TRY(hipMemcpyAsync(pg_state, &init, sizeof init, hipMemcpyHostToDevice, stream));
-    const bool sharded = left && nranks > 1;                               // H is column-sharded, W is replicated
+    const bool sharded = (left && nranks > 1) || wrows;                    // H is column-sharded; W row-sharded or replicated
     const T epsT = std::numeric_limits<T>::epsilon();
     const int *idle = &pg_state->idle;
     // G = Gram*Z - B  (+ projgradnorm^2 partials)            :124-130 / :280-286
     auto grad = [&]() {
         EpiGradNorm<T> e{B, Z, G, left ? K : P, pg_part.p, 0.0};
         if (left) gemm<KCONTIG, KCONTIG>("gemm_pg_grad", Z, K, N, Gram, K, K, K, 1, true, e, nullptr, 4.0 * K * N * sizeof(T));
-        else gemm<KSTRIDED, KSTRIDED>("gemm_pg_grad", Gram, K, K, Z, P, P, K, 1, false, e, nullptr, 4.0 * P * K * sizeof(T));
+        else gemm<KSTRIDED, KSTRIDED>("gemm_pg_grad", Gram, K, K, Z, P, Rw, K, 1, false, e, nullptr, 4.0 * Rw * K * sizeof(T));
         return last_blocks;
     };
     // one back-tracking step: Gram * D(alpha) with D formed in the operand loader, scalars reduced in the epilogue
@@ -46,12 +50,12 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
             gemm<KCONTIG, KCONTIG, 1>("gemm_pg_step", Z, K, N, Gram, K, K, K, 1, true, e, idle, 4.0 * K * N * sizeof(T), sg);
         } else {
             sg.b_aux = G;
-            gemm<KSTRIDED, KSTRIDED, 2>("gemm_pg_step", Gram, K, K, Z, P, P, K, 1, false, e, idle, 4.0 * P * K * sizeof(T), sg);
+            gemm<KSTRIDED, KSTRIDED, 2>("gemm_pg_step", Gram, K, K, Z, P, Rw, K, 1, false, e, idle, 4.0 * Rw * K * sizeof(T), sg);
         }
         nblk = last_blocks;
         if (sharded) {
             hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 3, 0, 1);
-            RCCL_TRY(ncclAllReduce(pg_state->red, pg_state->red, 3, ncclDouble, ncclSum, comm, stream));
+            comm->all_reduce(pg_state->red, 3, CT_F64, false, stream);
             hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, beta, sigma, epsT, traceiter);
         } else {
             hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, beta, sigma, epsT, traceiter);
@@ -68,7 +72,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
         const int nblk = grad();
         if (sharded) {
             hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 1, 3, 0);
-            RCCL_TRY(ncclAllReduce(pg_state->red + 3, pg_state->red + 3, 1, ncclDouble, ncclSum, comm, stream));
+            comm->all_reduce(pg_state->red + 3, 1, CT_F64, false, stream);
             hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, tolg);
         } else {
             hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, tolg);
@@ -78,7 +82,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
             for (int s = 0; s < nsteps; ++s) step();
             enq += nsteps;
             // H <- Hn / H <- Hp of the step that broke the loop (no-op while the loop is still running or unchanged)
-            hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(512), dim3(256), 0, stream, Z, G, count, pg_state, (int *)nullptr);
+            hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(512), dim3(256), 0, stream, Z, G, rows, cols, ldz, pg_state);
             hipLaunchKernelGGL(pg_clear_apply_kernel, dim3(1), dim3(1), 0, stream, pg_state);
             HIP_TRY(hipGetLastError());
             fetch();
@@ -93,8 +97,28 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     return t;
 }
 
+// set_h! (src/alspgrad.jl:218-222) + _alspgrad_updatew! (:242-347).  Multi-GPU: the numerator X_g H_g' and H_g H_g' are
+// sums over the column shards; the sub-problem itself is row-separable (G = W*HHt - XHt row by row, one GLOBAL step size),
+// so with the row-sharded W side every rank solves its Pc rows (2 Pc k^2 per product instead of 2 p k^2 on every rank --
+// SURVEY.md section 8e "alspgrad specifics") and the rows are all-gathered afterwards.
+template <typename T> long long Solver<T>::w_subsolve(T *Wc, const T *Hc, const nmfx_opts &o, T tolg, long long *inner) {
+    const bool rs = row_sharded();
+    w_blocked = rs;
+    times_ht(X.p, Hc, true, nullptr);
+    w_blocked = false;
+    if (!rs) {
+        allreduce_w_side(false, nullptr);
+        return pg_subsolve(false, Wc, gramH_p, numW_p, o.maxsubiter, o.traceiter, tolg, (T)o.beta, (T)o.sigma, inner);
+    }
+    scatter_w_numerator(false, nullptr);
+    const long long it = pg_subsolve(false, Wc + row0, gramH_p, numW_p + row0, o.maxsubiter, o.traceiter, tolg, (T)o.beta, (T)o.sigma, inner);
+    gather_w_rows(Wc, false, nullptr);
+    return it;
+}
+
 template <typename T> void Solver<T>::subsolve(int which, const nmfx_opts &o, nmfx_result *out) {
     precision = o.precision;
+    rsvd_ready = 0;
     require_ready();
     HIP_TRY(hipSetDevice(device));
     std::memset(out, 0, sizeof *out);
@@ -104,9 +128,7 @@ template <typename T> void Solver<T>::subsolve(int which, const nmfx_opts &o, nm
         wt_times(W[wcur].p, X.p, true, nullptr);                           // set_w! (:63-67)
         out->niters = pg_subsolve(true, H[hcur].p, gramW_p, numH_p, o.maxsubiter, o.traceiter, (T)o.tolg, (T)o.beta, (T)o.sigma, &inner);
     } else {                                                               // alspgrad_updatew! (:225-240)
-        times_ht(X.p, H[hcur].p, true, nullptr);                           // set_h! (:218-222)
-        allreduce_w_side(false, nullptr);
-        out->niters = pg_subsolve(false, W[wcur].p, gramH_p, numW_p, o.maxsubiter, o.traceiter, (T)o.tolg, (T)o.beta, (T)o.sigma, &inner);
+        out->niters = w_subsolve(W[wcur].p, H[hcur].p, o, (T)o.tolg, &inner);
     }
     HIP_TRY(hipStreamSynchronize(stream));
     out->inner_iters = inner;
@@ -144,13 +166,11 @@ template <typename T> void Solver<T>::run_alspgrad(const nmfx_opts &o, nmfx_resu
             const long long itH = pg_subsolve(true, Hc, gramW_p, numH_p, o.maxsubiter, o.traceiter, tolg, (T)o.beta, (T)o.sigma, &inner);
             if (itH == 1) tolg = (T)((double)tolg * 0.1);                  // :409-411
         }
-        times_ht(X.p, Hc, true, nullptr);                                  // set_h! (:415)
-        allreduce_w_side(false, nullptr);
-        const long long itW = pg_subsolve(false, Wc, gramH_p, numW_p, o.maxsubiter, o.traceiter, tolg, (T)o.beta, (T)o.sigma, &inner);
+        const long long itW = w_subsolve(Wc, Hc, o, tolg, &inner);         // set_h! (:415) + _alspgrad_updatew! (:416-417)
         if (itW == 1) tolg = (T)((double)tolg * 0.1);                      // :419-421
         if (o.update_H) {
             stats_h(Hc, preH, nullptr);
-            if (nranks > 1) RCCL_TRY(ncclAllReduce(hstat.p, hstat.p, (size_t)2 * K, ncclDouble, ncclSum, comm, stream));
+            if (nranks > 1) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
         }
         stats_w(Wc, preW, nullptr);
         enqueue_check(o, t);

@@ -221,10 +221,10 @@ void Solver<T>::nndsvd_core(const T *Ud, int64_t ucs, int64_t uss, const T *Vd, 
     HIP_TRY(hipMemsetAsync(xsum, 0, nsum * sizeof(double), stream));
     if (variant != 0) hipLaunchKernelGGL(sum_block_kernel<T>, dim3(nsum), dim3(256), 0, stream, X.p, p, n, P, xsum);
     if (nranks > 1) {   // V rows (= columns of X, H) are sharded: the norms of V's columns and sum(X) are global quantities
-        RCCL_TRY(ncclGroupStart());
-        RCCL_TRY(ncclAllReduce(vnorm, vnorm, (size_t)2 * k, ncclDouble, ncclSum, comm, stream));
-        RCCL_TRY(ncclAllReduce(xsum, xsum, (size_t)nsum, ncclDouble, ncclSum, comm, stream));
-        RCCL_TRY(ncclGroupEnd());
+        comm->group_start();
+        comm->all_reduce(vnorm, (size_t)2 * k, CT_F64, false, stream);
+        comm->all_reduce(xsum, (size_t)nsum, CT_F64, false, stream);
+        comm->group_end();
     }
     hipLaunchKernelGGL(nndsvd_coef_kernel<T>, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, stream, unorm, vnorm, sd, xsum, nsum,
                        (double)p * (double)n_total, variant, seed, (int)k, coef);

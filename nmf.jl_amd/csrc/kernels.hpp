@@ -248,19 +248,22 @@ __global__ void row_sum_kernel(const T *H, int64_t cols, int64_t ld, int K, doub
     }
 }
 
-// multdiv scalings (src/multupd.jl:177-179, 189-191):
-//   along_contig = 1 (H, K x N): out[i + j*ld] = in * num / (s[i] + lambda)   (s indexed by the contiguous index)
-//   along_contig = 0 (W, P x K): out[i + j*ld] = in * num / (s[j] + lambda)
+// multdiv scalings (src/multupd.jl:177-179, 189-191) over the LOGICAL rows x cols extent (padding is never touched:
+// with lambda == 0 a padded component would give 0 * (0/0) = NaN there):
+//   along_contig = 1 (H, k x n): out[i + j*ld] = in * num / (s[i] + lambda)   (s indexed by the contiguous index)
+//   along_contig = 0 (W, p x k): out[i + j*ld] = in * num / (s[j] + lambda)
+// flat 1-D grid-stride index: no gridDim.y limit on the number of columns of a shard.
 template <typename T>
 __global__ void div_update_kernel(T *out, const T *in, const T *num, const T *s, int64_t rows, int64_t cols,
                                   int64_t ld, T lambda, int along_contig, const int *done) {
     NMFX_DONE_GUARD(done);
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t j = blockIdx.y;
-    if (i >= rows || j >= cols) return;
-    const int64_t o = i + j * ld;
-    const T d = (along_contig ? s[i] : s[j]) + lambda;
-    out[o] = in[o] * (num[o] / d);
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e % rows, j = e / rows;
+        const int64_t o = i + j * ld;
+        const T d = (along_contig ? s[i] : s[j]) + lambda;
+        out[o] = in[o] * (num[o] / d);
+    }
 }
 
 // sum of squares in Float64 -> partial per block (projals objective ||W||^2, ||H||^2: src/projals.jl:67-72)
@@ -292,6 +295,60 @@ __global__ void finish_sumsq_kernel(const double *partial, int n, T half_lambda,
     for (int i = 0; i < n; ++i) s += partial[i];
     const T nrm = sqrt((T)s);           // abs2(norm(W)) with norm in T
     extra[slot] = (double)(T)(half_lambda * (nrm * nrm));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-sharded W side of the multi-GPU path: rank g owns rows [g*Pc, (g+1)*Pc) of the W update.
+// A "blocked" P x K matrix is G consecutive Pc x K column-major pieces (piece g = rows of rank g, ld Pc): the layout in
+// which a reduce-scatter / all-gather chunk is contiguous.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// split-K combine of the X*H' slabs written STRAIGHT into the blocked reduce-scatter send buffer:
+//   dst[(g*K + a)*Pc + il] = sum_s src[s*stride + i + a*P],  i = g*Pc + il   (s ascending, like reduce_slabs_kernel)
+template <typename T>
+__global__ void reduce_slabs_blocked_kernel(T *dst, const T *src, int64_t P, int64_t K, int64_t Pc, int nslab, int64_t stride,
+                                            const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P * K) return;
+    const int64_t i = e % P, a = e / P, g = i / Pc, il = i % Pc;
+    T s = src[e];
+    for (int k = 1; k < nslab; ++k) s += src[(int64_t)k * stride + e];
+    dst[(g * K + a) * Pc + il] = s;
+}
+
+// rows [row0, row0 + Pc) of a column-major P x K matrix (ld P)  <->  a contiguous Pc x K piece (ld Pc)
+template <typename T>
+__global__ void rows_to_piece_kernel(T *piece, const T *full, int64_t P, int64_t K, int64_t Pc, int64_t row0, const int *done) {
+    NMFX_DONE_GUARD(done);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < Pc * K; e += (int64_t)gridDim.x * blockDim.x)
+        piece[e] = full[row0 + e % Pc + (e / Pc) * P];
+}
+template <typename T>
+__global__ void piece_to_rows_kernel(T *full, const T *piece, int64_t P, int64_t K, int64_t Pc, int64_t row0, const int *done) {
+    NMFX_DONE_GUARD(done);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < Pc * K; e += (int64_t)gridDim.x * blockDim.x)
+        full[row0 + e % Pc + (e / Pc) * P] = piece[e];
+}
+// all-gather receive buffer (G chunks of `chunk_bytes`: [Pc x K piece | ntail doubles]) -> full matrix (ld P); the ranks'
+// tail vectors (per-column partial sums of the stop statistics, src/common.jl:95-99) are added in rank order -> tail_sum
+template <typename T>
+__global__ void gathered_to_full_kernel(T *full, const unsigned char *recv, int G, size_t chunk_bytes, int64_t P, int64_t K,
+                                        int64_t Pc, int ntail, double *tail_sum, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int64_t total = (int64_t)G * Pc * K;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = e / (Pc * K), r = e % (Pc * K);
+        const T *piece = reinterpret_cast<const T *>(recv + (size_t)g * chunk_bytes);
+        full[g * Pc + r % Pc + (r / Pc) * P] = piece[r];
+    }
+    if (blockIdx.x == 0 && tail_sum != nullptr)
+        for (int j = threadIdx.x; j < ntail; j += blockDim.x) {
+            double s = 0.0;
+            for (int g = 0; g < G; ++g)
+                s += reinterpret_cast<const double *>(recv + (size_t)g * chunk_bytes + (size_t)Pc * K * sizeof(T))[j];
+            tail_sum[j] = s;
+        }
 }
 
 }  // namespace nmfx

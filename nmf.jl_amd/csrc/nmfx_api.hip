@@ -37,6 +37,12 @@ template <typename F> static int guarded(nmfx_ctx *ctx, F &&f) {
     } catch (const RcclError &e) {
         *err = std::string("RCCL error: ") + ncclGetErrorString(e.e) + " at " + e.what;
         return NMFX_ERR_RCCL;
+    } catch (const RcclFailure &e) {
+        *err = std::string("RCCL error: ") + ncclGetErrorString(e.e) + " at " + e.what;
+        return NMFX_ERR_RCCL;
+    } catch (const CommError &e) {
+        *err = std::string("communicator error: ") + e.msg;
+        return NMFX_ERR_RCCL;
     } catch (const std::exception &e) {
         *err = e.what();
         return NMFX_ERR_STATE;
@@ -135,6 +141,25 @@ int nmfx_comm_get_unique_id(void *out_bytes) {
 int nmfx_comm_init(nmfx_ctx *ctx, const void *unique_id_bytes, int rank, int nranks) {
     if (!ctx || !unique_id_bytes || nranks < 1 || rank < 0 || rank >= nranks) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { ctx->impl->comm_init(unique_id_bytes, rank, nranks); });
+}
+
+int nmfx_local_group_create(nmfx_local_group **out, int nranks) {
+    if (!out || nranks < 1 || nranks > LOCAL_MAX_RANKS) return NMFX_ERR_BAD_ARG;
+    *out = reinterpret_cast<nmfx_local_group *>(new LocalGroup(nranks));
+    return NMFX_OK;
+}
+
+void nmfx_local_group_destroy(nmfx_local_group *group) { delete reinterpret_cast<LocalGroup *>(group); }
+
+int nmfx_comm_init_local(nmfx_ctx *ctx, nmfx_local_group *group, int rank) {
+    LocalGroup *g = reinterpret_cast<LocalGroup *>(group);
+    if (!ctx || !g || rank < 0 || rank >= g->n) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->comm_init_local(g, rank); });
+}
+
+int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode) {
+    if (!ctx || (mode != NMFX_COMM_ROW_SHARDED && mode != NMFX_COMM_REPLICATED_W)) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->comm_set_mode(mode); });
 }
 
 int nmfx_objective(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, double *out) {

@@ -195,13 +195,15 @@ __global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local
     if (brk || st->it >= traceiter) st->idle = 1;                         // loop exhausted: Z unchanged (quirk i)
 }
 
-// Z <- max(Z - alpha_apply*G, 0) if the decision asked for it (H <- Hn / H <- Hp of the reference)
-template <typename T> __global__ void pg_apply_kernel(T *Z, const T *G, int64_t count, PgState *st, int *apply_seen) {
+// Z <- max(Z - alpha_apply*G, 0) if the decision asked for it (H <- Hn / H <- Hp of the reference); Z, G are rows x cols
+// column-major blocks with leading dimension ld (a row block of W when the W side is row-sharded)
+template <typename T> __global__ void pg_apply_kernel(T *Z, const T *G, int64_t rows, int64_t cols, int64_t ld, PgState *st) {
     if (!st->apply) return;
     const T a = (T)st->alpha_apply;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < rows * cols; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e % rows + (e / rows) * ld;
         Z[i] = pg_trial(Z[i], G[i], a);
-    (void)apply_seen;
+    }
 }
 __global__ void pg_clear_apply_kernel(PgState *st) { st->apply = 0; }
 

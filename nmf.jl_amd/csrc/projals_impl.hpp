@@ -61,16 +61,30 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
+    const bool rs = row_sharded();
+    w_blocked = rs;
     times_ht(X.p, Hp, true, done);                                         // :100 HH', :101 XH' (one launch)
-    allreduce_w_side(o.update_H != 0, done);
+    w_blocked = false;
+    if (rs) scatter_w_numerator(o.update_H != 0, done);                    // sharded: numerator rows of this rank + summed HH'
+    else allreduce_w_side(o.update_H != 0, done);
     factor(gramH_p, (T)o.lambda_w, "potrf_HHt", "trtri_HHt");                     // :100 adddiag!, :102 potrf!
     {   // :102 potri! + copytri!: inv = Uinv Uinv' ; then W = max(0, XHt * inv)   (:103 projectnn!)
         EpiStore<T> e1{invA, K, 0, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_potri", Uinv, K, K, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * K * sizeof(T));
-        EpiClampStore<T> e2{Wn, P};
-        gemm<KSTRIDED, KSTRIDED>("gemm_XHtInv_clampW", invA, K, K, numW_p, P, P, K, 1, false, e2, done, 2.0 * P * K * sizeof(T));
+        if (rs) {   // rows of W are independent: this rank forms ITS Pc rows, the all-gather re-assembles W
+            EpiClampStore<T> e2{Wn + row0, P};
+            gemm<KSTRIDED, KSTRIDED>("gemm_XHtInv_clampW", invA, K, K, numW_p + row0, P, Pc, K, 1, false, e2, done, 2.0 * Pc * K * sizeof(T));
+        } else {
+            EpiClampStore<T> e2{Wn, P};
+            gemm<KSTRIDED, KSTRIDED>("gemm_XHtInv_clampW", invA, K, K, numW_p, P, P, K, 1, false, e2, done, 2.0 * P * K * sizeof(T));
+        }
     }
-    stats_w(Wn, Wo, done);
+    if (rs) {
+        stats_w_rows(Wn, Wo, done);
+        gather_w_rows(Wn, true, done);
+    } else {
+        stats_w(Wn, Wo, done);
+    }
     wcur ^= 1;
 }
 

@@ -81,6 +81,7 @@ template <typename T> void Solver<T>::rsvd_begin(uint64_t seed, int64_t h_col_of
     if (power_iters < 0 || power_iters > 8) throw StatusError{NMFX_ERR_BAD_ARG, "power_iters must be in 0..8"};
     if (!have_X) throw StatusError{NMFX_ERR_STATE, "X has not been uploaded (nmfx_set_X)"};
     HIP_TRY(hipSetDevice(device));
+    precision = NMFX_PREC_FP32;  // the sketch / projection products always run in the element type's own arithmetic
     const size_t pk = (size_t)P * K, kn = (size_t)K * N;
     work[4].ensure(pk);          // Q   (P x K, ld P)
     work[5].ensure(std::max(pk, (size_t)n * k));   // U (shared with nndsvd_init's V upload)
@@ -117,7 +118,7 @@ template <typename T> void Solver<T>::rsvd_begin(uint64_t seed, int64_t h_col_of
         EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_BBt", numH_p, K, K, numH_p, K, K, N, s_gh, true, eg, nullptr, (double)(K * N) * sizeof(T));
         reduce_slabs_from("reduce_BBt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gh, nullptr);
-        if (nranks > 1) RCCL_TRY(ncclAllReduce(gramH_p, gramH_p, (size_t)K * K, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, comm, stream));
+        if (nranks > 1) comm->all_reduce(gramH_p, (size_t)K * K, CT, false, stream);
     }
     HIP_TRY(hipMemcpy2DAsync(C_host, k * sizeof(T), gramH_p, K * sizeof(T), k * sizeof(T), k, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));

@@ -6,7 +6,6 @@
 // device-side stop flag; the host polls that flag every `check_every` iterations.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -19,6 +18,7 @@
 #include <vector>
 
 #include "../../include/nmfx.h"
+#include "comm.hpp"
 #include "gemm_mfma.hpp"
 #include "gemm_bf16x3.hpp"
 #include "kernels.hpp"
@@ -66,6 +66,8 @@ struct SolverBase {
     virtual void iterate(int alg, const nmfx_opts &o, nmfx_result *out, double *trace) = 0;
     virtual void subsolve(int which, const nmfx_opts &o, nmfx_result *out) = 0;
     virtual void comm_init(const void *uid, int rank, int nranks) = 0;
+    virtual void comm_init_local(LocalGroup *group, int rank) = 0;
+    virtual void comm_set_mode(int mode) = 0;
     virtual double objective(int alg, const nmfx_opts &o) = 0;
     virtual bool check_nonneg(int which) = 0;
     virtual void randinit(uint64_t seed, bool normalize, bool zeroh, int64_t h_col_offset) = 0;
@@ -112,16 +114,26 @@ template <typename T> class Solver : public SolverBase {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         num_cu = prop.multiProcessorCount;
-        P = round_up(p, 256);
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&ev_beg));
+        HIP_TRY(hipEventCreate(&ev_end));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
+        HIP_TRY(hipMemset(ctrl, 0, sizeof(Ctrl)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctrl_host), sizeof(Ctrl)));
+        layout(256);
+    }
+
+    // Padded extents and every buffer whose size depends on them.  row_mult = the multiple P is rounded up to: 256 for one
+    // GPU; lcm(256, 128 * nranks) once a communicator is attached, so that the row-sharded W side
+    // gets whole 128-row tiles per rank.
+    void layout(int64_t row_mult) {
+        P = round_up(p, row_mult);
         N = round_up(n, 256);
         K = (k <= 64) ? 64 : round_up(k, 128);
         // the fused epilogues address a wave tile with 32-bit byte offsets (gemm_mfma.hpp, "Epilogue addressing"):
         // 256 rows x leading dimension must stay below 4 GiB.  Leading dimensions are P (W, X, Q) and K (H, Gram).
         if ((uint64_t)std::max(P, K) * sizeof(T) * 256 >= (1ull << 32))
             throw StatusError{NMFX_ERR_UNSUPPORTED, "p (or k) too large: 256 * leading dimension * sizeof(T) must be < 2^32"};
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreate(&ev_beg));
-        HIP_TRY(hipEventCreate(&ev_end));
         X.alloc((size_t)P * N);
         for (int i = 0; i < 2; ++i) { W[i].alloc((size_t)P * K); H[i].alloc((size_t)K * N); }
         // H-side numerator and Gram are ONE K x (N+K) matrix: [ W'X | W'W ] is produced by a single GEMM launch
@@ -160,16 +172,17 @@ template <typename T> class Solver : public SolverBase {
         obj_part.alloc((size_t)2 * (P / 128) * (N / 128) + 4096);
         obj_extra.alloc(4);
         obj_final.alloc(1);
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
-        HIP_TRY(hipMemset(ctrl, 0, sizeof(Ctrl)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctrl_host), sizeof(Ctrl)));
+        for (auto &w : work) w.release();
+        Q.release(); Wbest.release(); Hbest.release();
+        have_X = have_F = false;
         HIP_TRY(hipDeviceSynchronize());
     }
 
     ~Solver() override {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(stream);
-        if (comm) (void)ncclCommDestroy(comm);
+        delete comm;
+        comm = nullptr;
         for (auto &e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (pg_state) (void)hipFree(pg_state);
         if (pg_host) (void)hipHostFree(pg_host);
@@ -203,6 +216,7 @@ template <typename T> class Solver : public SolverBase {
         HIP_TRY(hipStreamSynchronize(stream));
         wcur = hcur = 0;
         have_F = true;
+        if (rsvd_ready == 1) rsvd_ready = 0;
     }
 
     void get_factors(void *Wdst, void *Hdst) override {
@@ -214,12 +228,37 @@ template <typename T> class Solver : public SolverBase {
 
     void comm_init(const void *uid, int rank_, int nranks_) override {
         HIP_TRY(hipSetDevice(device));
-        ncclUniqueId id;
         static_assert(sizeof(ncclUniqueId) <= NMFX_UNIQUE_ID_BYTES, "unique id size");
-        std::memcpy(&id, uid, sizeof(id));
-        RCCL_TRY(ncclCommInitRank(&comm, nranks_, id, rank_));
-        rank = rank_;
-        nranks = nranks_;
+        attach(new RcclComm(uid, rank_, nranks_));
+    }
+    void comm_init_local(LocalGroup *group, int rank_) override {
+        HIP_TRY(hipSetDevice(device));
+        attach(new LocalComm(group, rank_, device));
+    }
+    // 0: row-sharded W side (reduce-scatter / all-gather, the default whenever the shapes allow it); 1: the replicated W
+    // update behind one packed all-reduce (round-1 formulation, kept for comparison and as the fallback)
+    void comm_set_mode(int mode) override { comm_mode = mode; }
+    void attach(Comm *c) {
+        delete comm;
+        comm = c;
+        rank = c->rank;
+        nranks = c->nranks;
+        if (nranks > 1) {
+            // whole 128-row tiles per rank for the row-sharded W side
+            int64_t m = 128 * (int64_t)nranks, a = 256, b = m;
+            while (b) { const int64_t t = a % b; a = b; b = t; }
+            const int64_t row_mult = 256 / a * m;
+            if (round_up(p, row_mult) != P) {
+                if (have_X) throw StatusError{NMFX_ERR_STATE, "nmfx_comm_init must be called before nmfx_set_X when p is not a multiple of lcm(256, 128*nranks)"};
+                layout(row_mult);
+            }
+            Pc = P / nranks;
+            row0 = (int64_t)rank * Pc;
+            ag_chunk_bytes = (size_t)Pc * K * sizeof(T) + (size_t)2 * K * sizeof(double);
+            rs_out.alloc((size_t)Pc * K);
+            ag_send.alloc(ag_chunk_bytes);
+            ag_recv.alloc(ag_chunk_bytes * (size_t)nranks);
+        }
     }
 
     // mode 0: off; 1: hipEvent pair around EVERY launch (each pair costs ~10 us of stream time: use for
@@ -280,6 +319,8 @@ template <typename T> class Solver : public SolverBase {
     double objective(int alg, const nmfx_opts &o) override {
         require_ready();
         HIP_TRY(hipSetDevice(device));
+        precision = o.precision;   // the opts of THIS call decide, not those of the last solve
+        if (rsvd_ready == 1) rsvd_ready = 0;   // numH_p (the rsvd's B) is not touched, but keep the contract simple: begin/finish back to back
         enqueue_objective(alg, o, obj_final.p, nullptr);
         double v = 0.0;
         HIP_TRY(hipMemcpyAsync(&v, obj_final.p, sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -318,8 +359,16 @@ template <typename T> class Solver : public SolverBase {
     // (+50 %: 1505 vs 1010 us), so they are dealt out as a short second segment of EVERY block (see the kernel).
     bool fuse_gram = true;    // K % 128 == 0: Gram rides in the big GEMM launch as a balanced tail segment
     size_t slab_w_off = 0;    // W-side slab region
-    ncclComm_t comm = nullptr;
+    Comm *comm = nullptr;
     int rank = 0, nranks = 1;
+    int comm_mode = 0;
+    // row-sharded W side: this rank updates rows [row0, row0 + Pc) of W
+    int64_t Pc = 0, row0 = 0;
+    size_t ag_chunk_bytes = 0;
+    DevBuf<T> rs_out;                       // reduce-scatter output: this rank's rows of the summed numerator (Pc x K, ld Pc)
+    DevBuf<unsigned char> ag_send, ag_recv; // all-gather chunks: [ Pc x K piece of the new W | 2K doubles of column statistics ]
+    bool row_sharded() const { return nranks > 1 && comm_mode == 0 && Pc > 0 && Pc % 128 == 0; }
+    static constexpr int CT = sizeof(T) == 4 ? CT_F32 : CT_F64;
 
     // profiling (hipEvent pair per launch, resolved lazily)
     struct Rec { const char *name; int ev; double flops, bytes; };
@@ -332,6 +381,11 @@ template <typename T> class Solver : public SolverBase {
     void require_ready() {
         if (!have_X) throw StatusError{NMFX_ERR_STATE, "X has not been uploaded (nmfx_set_X)"};
         if (!have_F) throw StatusError{NMFX_ERR_STATE, "W/H have not been uploaded (nmfx_set_factors)"};
+    }
+
+    // grid size of a flat grid-stride elementwise launch (256 threads, >= 4 elements per thread when large)
+    unsigned flat_grid(int64_t count) const {
+        return (unsigned)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, (int64_t)num_cu * 32));
     }
 
     int pick_splits(int tiles, int64_t kdim) const {
@@ -573,8 +627,7 @@ template <typename T> class Solver : public SolverBase {
                 EpiStore<T> e{reg, P, w_stride, nullptr};
                 launch_bf16x3<1, 1>("gemm_XHt_bf16x3", Hp, K, K, Amat, P, P, N, s_w, false, e, done, (double)(P * N + K * N) * sizeof(T));
             }
-            if (!keep_slabs || w_nslab > 2) { reduce_slabs_from("reduce_XHt", numW_p, reg, w_stride, w_nslab, done); w_in_slabs = false; }
-            else w_in_slabs = true;
+            finish_w_slabs(keep_slabs, done);
             if (with_gram) {
                 EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
                 gemm<KSTRIDED, KSTRIDED>("gemm_HHt", Hp, K, K, Hp, K, K, N, s_gh, true, eg, done, (double)(K * N) * sizeof(T));
@@ -595,28 +648,37 @@ template <typename T> class Solver : public SolverBase {
             gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                      (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
             reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
-            if (!keep_slabs || w_nslab > 2) {
-                reduce_slabs_from("reduce_XHt", numW_p, reg, w_stride, w_nslab, done);
-                w_in_slabs = false;
-            } else {
-                w_in_slabs = true;
-            }
+            finish_w_slabs(keep_slabs, done);
             return;
         }
         w_nslab = s_w; w_stride = (int64_t)P * K;
         EpiStore<T> e{reg, P, w_stride, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                  (double)(P * N + K * N) * sizeof(T));
-        if (!keep_slabs || w_nslab > 2) {
-            reduce_slabs_from("reduce_XHt", numW_p, reg, w_stride, w_nslab, done);
-            w_in_slabs = false;
-        } else {
-            w_in_slabs = true;
-        }
+        finish_w_slabs(keep_slabs, done);
         if (with_gram) {
             EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
             gemm<KSTRIDED, KSTRIDED>("gemm_HHt", Hp, K, K, Hp, K, K, N, s_gh, true, eg, done, (double)(K * N) * sizeof(T));
             reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gh, done);
+        }
+    }
+    // where the split-K slabs of X*H' go: left in place for the update GEMM's epilogue (single GPU, <= 2 slabs), summed
+    // into numW (standard layout), or summed into the BLOCKED reduce-scatter send buffer (row-sharded W side)
+    bool w_blocked = false;
+    void finish_w_slabs(bool keep_slabs, const int *done) {
+        const T *reg = slabs.p + slab_w_off;
+        if (w_blocked) {
+            timed("reduce_XHt", 0.0, (double)P * K * (w_nslab + 1) * sizeof(T), [&] {
+                hipLaunchKernelGGL(reduce_slabs_blocked_kernel<T>, dim3((unsigned)((P * K + 255) / 256)), dim3(256), 0, stream, numW_p, reg,
+                                   P, K, Pc, w_nslab, w_stride, done);
+                HIP_TRY(hipGetLastError());
+            });
+            w_in_slabs = false;
+        } else if (!keep_slabs || w_nslab > 2) {
+            reduce_slabs_from("reduce_XHt", numW_p, reg, w_stride, w_nslab, done);
+            w_in_slabs = false;
+        } else {
+            w_in_slabs = true;
         }
     }
     const T *w_num() const { return w_in_slabs ? slabs.p + slab_w_off : numW_p; }
@@ -649,8 +711,13 @@ template <typename T> class Solver : public SolverBase {
         });
     }
 
-    // One all-reduce per outer iteration (multi-GPU): numW, gramH and the H statistics.
+    // One all-reduce per outer iteration (multi-GPU, replicated W update): numW, gramH and the H statistics.
     void allreduce_w_side(bool with_hstat, const int *done);
+    // Row-sharded W side: reduce-scatter of the numerator by row blocks (+ all-reduce of the small k x k / k-vector tail),
+    // and the all-gather that re-assembles W (and sums the ranks' column statistics) afterwards.
+    void scatter_w_numerator(bool with_hstat, const int *done);
+    void gather_w_rows(T *Wfull, bool with_stats, const int *done);
+    void stats_w_rows(const T *Wn, const T *Wo, const int *done);
 
     void enqueue_objective(int alg, const nmfx_opts &o, double *dst, const int *done);
     void enqueue_multmse(const nmfx_opts &o, long long t);
@@ -665,7 +732,7 @@ template <typename T> class Solver : public SolverBase {
                      T lambda, bool sharded_samples, const int *done);
     void allreduce_hstat(const int *done) {   // CD order: H is updated AFTER the packed W-side all-reduce
         (void)done;
-        if (nranks > 1) RCCL_TRY(ncclAllReduce(hstat.p, hstat.p, (size_t)2 * K, ncclDouble, ncclSum, comm, stream));
+        if (nranks > 1) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
     }
     void enqueue_check(const nmfx_opts &o, long long t) {
         const bool track = o.track_objective != 0;
@@ -712,6 +779,7 @@ template <typename T> class Solver : public SolverBase {
     const int *done_flag() const { return &ctrl->done; }
 
     void run_alspgrad(const nmfx_opts &o, nmfx_result *out, double *trace);
+    long long w_subsolve(T *Wc, const T *Hc, const nmfx_opts &o, T tolg, long long *inner);
     long long pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int maxiter, int traceiter, T tolg, T beta, T sigma,
                           long long *inner_total);
     struct PgState *pg_state = nullptr, *pg_host = nullptr;

@@ -57,11 +57,11 @@ void Solver<T>::enqueue_objective(int alg, const nmfx_opts &o, double *dst, cons
         // Reduce the per-block partials to one value first, all-reduce it, then finish.
         hipLaunchKernelGGL(finish_objective_kernel<double>, dim3(1), dim3(256), 0, stream, obj_part.p, nblk, 1,
                            (const double *)nullptr, 0, obj_part.p, done);
-        RCCL_TRY(ncclAllReduce(obj_part.p, obj_part.p, 1, ncclDouble, ncclSum, comm, stream));
+        comm->all_reduce(obj_part.p, 1, CT_F64, false, stream);
         if ((alg == NMFX_ALG_PROJALS || alg == NMFX_ALG_GREEDYCD) && o.lambda_h > 0) {
             // sharded ||H||^2 term: sum the already-scaled shard terms (norm in T per shard; documented deviation)
             const int slot = (o.lambda_w > 0) ? 1 : 0;
-            RCCL_TRY(ncclAllReduce(obj_extra.p + slot, obj_extra.p + slot, 1, ncclDouble, ncclSum, comm, stream));
+            comm->all_reduce(obj_extra.p + slot, 1, CT_F64, false, stream);
         }
         hipLaunchKernelGGL(finish_objective_kernel<T>, dim3(1), dim3(256), 0, stream, obj_part.p, 1,
                            alg == NMFX_ALG_MULTDIV ? 1 : 0, obj_extra.p, nextra, dst, done);
@@ -76,12 +76,53 @@ template <typename T> void Solver<T>::allreduce_w_side(bool with_hstat, const in
     (void)done;
     if (nranks <= 1) return;
     timed("allreduce_pack", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
-        RCCL_TRY(ncclGroupStart());
-        RCCL_TRY(ncclAllReduce(pack.p, pack.p, pack.count,
-                               sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, comm, stream));
-        if (with_hstat) RCCL_TRY(ncclAllReduce(hstat.p, hstat.p, (size_t)2 * K, ncclDouble, ncclSum, comm, stream));
-        RCCL_TRY(ncclGroupEnd());
+        comm->group_start();
+        comm->all_reduce(pack.p, pack.count, CT, false, stream);
+        if (with_hstat) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
+        comm->group_end();
     });
+}
+
+// Row-sharded W side, step 1: the blocked numerator partial sums (times_ht with w_blocked) are reduce-scattered by row
+// blocks; the small tail of the packed buffer [ H_g H_g' | rowsum(H_g) ] and the H statistics are all-reduced in the same
+// group.  The rank's rows of the summed numerator land back in numW (standard layout, ld P) at [row0, row0 + Pc).
+template <typename T> void Solver<T>::scatter_w_numerator(bool with_hstat, const int *done) {
+    timed("reduce_scatter_numW", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
+        comm->group_start();
+        comm->reduce_scatter(numW_p, rs_out.p, (size_t)Pc * K, CT, stream);
+        comm->all_reduce(gramH_p, (size_t)K * K + (size_t)K, CT, false, stream);
+        if (with_hstat) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
+        comm->group_end();
+    });
+    hipLaunchKernelGGL(piece_to_rows_kernel<T>, dim3(flat_grid(Pc * K)), dim3(256), 0, stream, numW_p, rs_out.p, P, K, Pc, row0, done);
+    HIP_TRY(hipGetLastError());
+}
+
+// stop_condition statistics of this rank's rows of W (src/common.jl:95-99): per-column partial sums over [row0, row0 + Pc),
+// written into the tail of the all-gather chunk; gather_w_rows adds the ranks' partials in rank order.
+template <typename T> void Solver<T>::stats_w_rows(const T *Wn, const T *Wo, const int *done) {
+    const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, Pc / 1024));
+    timed("stats_W", 0.0, 2.0 * Pc * K * sizeof(T), [&] {
+        hipLaunchKernelGGL(col_stats_kernel<T>, dim3(chunks, (unsigned)K), dim3(256), 0, stream, Wn + row0, Wo + row0, Pc, P,
+                           (int)K, stat_part.p, done);
+        hipLaunchKernelGGL(finalize_partials_kernel<double>, dim3((unsigned)((2 * K + 3) / 4)), dim3(256), 0, stream,
+                           stat_part.p, chunks, (int)(2 * K), (int)(2 * K),
+                           reinterpret_cast<double *>(ag_send.p + (size_t)Pc * K * sizeof(T)), done);
+        HIP_TRY(hipGetLastError());
+    });
+}
+
+// Row-sharded W side, step 2: every rank contributes its Pc updated rows (+ its column statistics partials), the
+// all-gather re-assembles the full W on every rank (identical bits everywhere) and wstat = sum of the partials.
+template <typename T> void Solver<T>::gather_w_rows(T *Wfull, bool with_stats, const int *done) {
+    hipLaunchKernelGGL(rows_to_piece_kernel<T>, dim3(flat_grid(Pc * K)), dim3(256), 0, stream, reinterpret_cast<T *>(ag_send.p), Wfull,
+                       P, K, Pc, row0, done);
+    timed("all_gather_W", 0.0, (double)(P * K) * sizeof(T), [&] {
+        comm->all_gather(ag_send.p, ag_recv.p, ag_chunk_bytes, CT_BYTE, stream);
+    });
+    hipLaunchKernelGGL(gathered_to_full_kernel<T>, dim3(flat_grid(P * K)), dim3(256), 0, stream, Wfull, ag_recv.p, nranks, ag_chunk_bytes,
+                       P, K, Pc, with_stats ? (int)(2 * K) : 0, with_stats ? wstat.p : (double *)nullptr, done);
+    HIP_TRY(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------
@@ -108,7 +149,20 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
-    // :109 XH': single GPU -> slabs are consumed by the update GEMM's epilogue; sharded -> reduce into the packed
+    if (row_sharded()) {
+        // sharded: X_g H_g' partial sums -> reduce-scatter by row blocks -> this rank updates ITS Pc rows -> all-gather
+        w_blocked = true;
+        times_ht(X.p, Hp, true, done);
+        w_blocked = false;
+        scatter_w_numerator(o.update_H != 0, done);
+        EpiMultUpdate<T, 0> e{numW_p + row0, 1, 0, Wo + row0, Wn + row0, P, (T)o.lambda_w, (T)o.delta, nullptr, 0};   // :110-114
+        gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo + row0, P, Pc, K, 1, false, e, done, 3.0 * Pc * K * sizeof(T));
+        stats_w_rows(Wn, Wo, done);
+        gather_w_rows(Wn, true, done);
+        wcur ^= 1;
+        return;
+    }
+    // :109 XH': single GPU -> slabs are consumed by the update GEMM's epilogue; replicated-W mode -> reduce into the packed
     // buffer first, because the all-reduce needs the rank-local sum
     const bool w_slabs = (nranks == 1);
     times_ht(X.p, Hp, true, done, /*keep_slabs=*/w_slabs);
@@ -128,6 +182,10 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
     const int *done = done_flag();
     Q.ensure((size_t)P * N);
     const double qbytes = 2.0 * P * N * sizeof(T);
+    // MultUpdate's constructor floors both lambdas at sqrt(eps(T)) for obj = :div (src/multupd.jl:37-40); a raw C-ABI caller
+    // gets the same floor here, so a zero column sum can never divide by zero
+    const T lam_floor = std::sqrt(std::numeric_limits<T>::epsilon());
+    const T lambda_h = std::max((T)o.lambda_h, lam_floor), lambda_w = std::max((T)o.lambda_w, lam_floor);
     if (o.update_H) {
         const T *Wp = W[wcur].p;
         const T *Ho = H[hcur].p;
@@ -142,8 +200,8 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
                                stat_chunks_w, (int)K, (int)K, svec.p, done);
         });
         timed("div_update_H", 0.0, 3.0 * K * N * sizeof(T), [&] {           // :177-179
-            hipLaunchKernelGGL(div_update_kernel<T>, dim3((unsigned)((K + 255) / 256), (unsigned)N), dim3(256), 0, stream, Hn,
-                               Ho, numH_p, svec.p, K, N, K, (T)o.lambda_h, 1, done);
+            hipLaunchKernelGGL(div_update_kernel<T>, dim3(flat_grid(k * n)), dim3(256), 0, stream, Hn,
+                               Ho, numH_p, svec.p, k, n, K, lambda_h, 1, done);
         });
         stats_h(Hn, Ho, done);
         hcur ^= 1;
@@ -153,17 +211,34 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
     T *Wn = W[wcur ^ 1].p;
     EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                               // :184-186
     gemm_wh("gemm_WH_ratio", Hp, Wo, er, done, qbytes);
+    const bool rs = row_sharded();
+    w_blocked = rs;
     times_ht(Q.p, Hp, false, done);                                        // :187
+    w_blocked = false;
     T *sH = sH_p;                                                          // tail of the packed buffer
     timed("rowsum_H", 0.0, (double)K * N * sizeof(T), [&] {                // :188
         hipLaunchKernelGGL(row_sum_kernel<T>, dim3(stat_chunks_h), dim3(256), 0, stream, Hp, N, K, (int)K, stat_part.p, done);
         hipLaunchKernelGGL(finalize_partials_kernel<T>, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, stream, stat_part.p,
                            stat_chunks_h, (int)K, (int)K, sH, done);
     });
+    if (rs) {   // row-sharded W side: this rank scales its own rows only
+        scatter_w_numerator(o.update_H != 0, done);
+        const int64_t rows = std::max<int64_t>(0, std::min<int64_t>(Pc, p - row0));
+        timed("div_update_W", 0.0, 3.0 * Pc * K * sizeof(T), [&] {           // :189-191
+            if (rows > 0)
+                hipLaunchKernelGGL(div_update_kernel<T>, dim3(flat_grid(rows * k)), dim3(256), 0, stream, Wn + row0, Wo + row0,
+                                   numW_p + row0, sH, rows, k, P, lambda_w, 0, done);
+        });
+        HIP_TRY(hipGetLastError());
+        stats_w_rows(Wn, Wo, done);
+        gather_w_rows(Wn, true, done);
+        wcur ^= 1;
+        return;
+    }
     allreduce_w_side(o.update_H != 0, done);
     timed("div_update_W", 0.0, 3.0 * P * K * sizeof(T), [&] {               // :189-191
-        hipLaunchKernelGGL(div_update_kernel<T>, dim3((unsigned)((P + 255) / 256), (unsigned)K), dim3(256), 0, stream, Wn, Wo,
-                           numW_p, sH, P, K, P, (T)o.lambda_w, 0, done);
+        hipLaunchKernelGGL(div_update_kernel<T>, dim3(flat_grid(p * k)), dim3(256), 0, stream, Wn, Wo,
+                           numW_p, sH, p, k, P, lambda_w, 0, done);
     });
     HIP_TRY(hipGetLastError());
     stats_w(Wn, Wo, done);
@@ -188,6 +263,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     if (alg < 0 || alg > NMFX_ALG_GREEDYCD) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid algorithm."};
     if (o.precision != NMFX_PREC_FP32 && o.precision != NMFX_PREC_BF16X3) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for precision."};
     precision = o.precision;
+    rsvd_ready = 0;   // the iteration overwrites the buffers a pending rsvd keeps its Q / B in
     HIP_TRY(hipSetDevice(device));
     std::memset(out, 0, sizeof *out);
     if (alg == NMFX_ALG_ALSPGRAD) { run_alspgrad(o, out, trace); return; }

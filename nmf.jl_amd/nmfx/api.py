@@ -378,6 +378,15 @@ class Context:
         buf = C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)
         self._ck(self.lib.nmfx_comm_init(self.h, buf, rank, nranks))
 
+    def comm_init_local(self, group: "LocalGroup", rank: int):
+        """Attach this context as `rank` of an in-process group (collective: every rank calls it from its own thread)."""
+        self._ck(self.lib.nmfx_comm_init_local(self.h, group.h, rank))
+
+    def comm_set_mode(self, mode: str):
+        """'row_sharded' (default: reduce-scatter / all-gather, each rank updates its rows of W) or 'replicated_w'
+        (one packed all-reduce, every rank applies the full W update)."""
+        self._ck(self.lib.nmfx_comm_set_mode(self.h, {"row_sharded": L.COMM_ROW_SHARDED, "replicated_w": L.COMM_REPLICATED_W}[mode]))
+
     def profile_enable(self, mode=1):
         """0 off, 1 every launch (slow), 2 dominant GEMMs sampled 1-in-4 (bench roofline)."""
         self._ck(self.lib.nmfx_profile_enable(self.h, int(mode)))
@@ -388,6 +397,23 @@ class Context:
         self._ck(self.lib.nmfx_profile_get(self.h, arr, 64, C.byref(cnt)))
         return [dict(name=arr[i].name.decode(), ms_total=arr[i].ms_total, launches=arr[i].launches,
                      flops=arr[i].flops, bytes=arr[i].bytes) for i in range(cnt.value)]
+
+
+class LocalGroup:
+    """nmfx_local_group: the in-process transport of the sharded path (several contexts, one host thread each)."""
+
+    def __init__(self, nranks: int):
+        self.lib = L.load()
+        h = C.c_void_p()
+        st = self.lib.nmfx_local_group_create(C.byref(h), nranks)
+        if st != L.OK:
+            _raise(st, "nmfx_local_group_create failed")
+        self.h, self.nranks = h, nranks
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nmfx_local_group_destroy(self.h)
+            self.h = None
 
 
 def comm_unique_id() -> bytes:

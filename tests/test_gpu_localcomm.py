@@ -1,0 +1,149 @@
+"""The sharded path of libnmfx ITSELF with nranks > 1 on the 1-GPU box: G contexts in one process (one host thread each,
+all on device 0) attached to an in-process group (include/nmfx.h, nmfx_local_group_create / nmfx_comm_init_local).  The
+per-rank code is the same SPMD sequence the RCCL transport runs with one process per GPU -- column-sharded X and H,
+reduce-scatter of X_g H_g' by row blocks, row-sharded W update, all-gather of W, all-reduced line-search scalars for
+alspgrad -- only the collectives' transport differs (csrc/comm.hpp).  Checked against the UNSHARDED run of the same library
+and against the CPU oracle: the sharded formulation must reproduce the reference trajectory."""
+import threading
+
+import numpy as np
+import pytest
+
+import nmf_oracle as orc
+import nmfx
+from problems import planted, rel_trace_err
+
+pytestmark = pytest.mark.gpu
+L = nmfx._lib
+ALG = {"multmse": L.ALG_MULTMSE, "multdiv": L.ALG_MULTDIV, "projals": L.ALG_PROJALS, "alspgrad": L.ALG_ALSPGRAD,
+       "cd": L.ALG_CD, "greedycd": L.ALG_GREEDYCD}
+
+
+def run_sharded(T, X, W0, H0, alg, opts_kw, G, mode="row_sharded", timeout=300):
+    """Solve with G in-process ranks; returns (W of rank 0, assembled H, per-rank (res, trace), per-rank W)."""
+    p, n = X.shape
+    k = W0.shape[1]
+    group = nmfx.LocalGroup(G)
+    out = [None] * G
+    errs = []
+
+    def worker(r):
+        try:
+            c0, c1 = nmfx.dist.shard_range(n, r, G)
+            with nmfx.Context(T, p, c1 - c0, k) as ctx:
+                ctx.comm_init_local(group, r)                      # before set_X: the row padding may change
+                ctx.comm_set_mode(mode)
+                ctx.set_X(np.asfortranarray(X[:, c0:c1]))
+                W, H = W0.copy(order="F"), np.asfortranarray(H0[:, c0:c1].copy())
+                res, trace = ctx.solve(ALG[alg], nmfx.make_opts(T, **opts_kw), W, H)
+                out[r] = (c0, c1, W, H, res, trace)
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout)
+    assert not errs, errs
+    assert all(o is not None for o in out), "a rank did not finish"
+    group.close()
+    H = np.zeros_like(H0)
+    for c0, c1, _, Hg, _, _ in out:
+        H[:, c0:c1] = Hg
+    return out[0][2], H, [(o[4], o[5]) for o in out], [o[2] for o in out]
+
+
+def lam_for(alg, T):
+    if alg == "projals":
+        return 0.05
+    if alg == "multdiv":
+        return float(np.sqrt(np.finfo(T).eps))
+    return 1e-4 if alg == "multmse" else 0.0
+
+
+@pytest.mark.parametrize("alg", ["multmse", "multdiv", "projals", "alspgrad"])
+@pytest.mark.parametrize("G", [2, 4])
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_row_sharded_matches_unsharded_and_oracle(built, alg, G, T):
+    p, n, k = 300, 530, 6                                           # ragged column shards; p padded to 128*G rows
+    X, W0, H0 = planted(p, n, k, T, seed=17, normalize=(alg != "projals"))
+    lam = lam_for(alg, T)
+    iters = 5 if alg == "alspgrad" else 10
+    kw = dict(maxiter=iters, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True)
+    Ws, Hs, rr, Wall = run_sharded(T, X, W0, H0, alg, kw, G)
+    # every rank holds the same W bits and reports the same trajectory / counters
+    for Wr in Wall[1:]:
+        assert np.array_equal(Wr, Wall[0])
+    for res, tr in rr[1:]:
+        assert np.array_equal(tr, rr[0][1]) and res.niters == rr[0][0].niters and res.inner_iters == rr[0][0].inner_iters
+    # unsharded run of the same library
+    W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        r1, t1 = ctx.solve(ALG[alg], nmfx.make_opts(T, **kw), W1, H1)
+    tol = {np.float64: 1e-9, np.float32: 2e-5}[T]
+    if alg == "projals" and T == np.float32:
+        tol = 2e-3                                                  # conditioning of the fp32 Cholesky solves
+    assert rr[0][0].niters == r1.niters == iters
+    assert rel_trace_err(rr[0][1], t1) < tol
+    assert np.max(np.abs(Ws - W1)) <= 100 * tol * np.max(np.abs(W1))
+    assert np.max(np.abs(Hs - H1)) <= 100 * tol * np.max(np.abs(H1))
+    if T == np.float64:
+        Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+        ro = orc.solve(alg, X, Wc, Hc, orc.Opts(maxiter=iters, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+        assert rel_trace_err(rr[0][1], ro.trace) < 1e-7
+        assert np.max(np.abs(Ws - Wc)) <= 1e-6 * np.max(np.abs(Wc))
+        if alg == "alspgrad":                                       # global step sizes: counters equal the unsharded oracle's
+            assert rr[0][0].inner_iters == ro.counters["inner"] and rr[0][0].backtracks == ro.counters["backtracks"]
+
+
+@pytest.mark.parametrize("alg", ["multmse", "projals", "cd", "greedycd"])
+def test_replicated_w_mode_and_cd(built, alg):
+    """The round-1 formulation (one packed all-reduce, full W update on every rank) stays available; CoordinateDescent and
+    GreedyCD always use it."""
+    T = np.float64
+    p, n, k = 260, 410, 5
+    X, W0, H0 = planted(p, n, k, T, seed=23, normalize=(alg != "projals"))
+    lam = lam_for(alg, T)
+    kw = dict(maxiter=6, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True)
+    Ws, Hs, rr, Wall = run_sharded(T, X, W0, H0, alg, kw, 2, mode="replicated_w")
+    assert np.array_equal(Wall[0], Wall[1])
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve(alg, X, Wc, Hc, orc.Opts(maxiter=6, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+    assert rel_trace_err(rr[0][1], ro.trace) < 1e-7
+    assert np.max(np.abs(Ws - Wc)) <= 1e-6 * np.max(np.abs(Wc))
+    assert np.max(np.abs(Hs - Hc)) <= 1e-6 * np.max(np.abs(Hc))
+
+
+def test_row_sharded_stop_rule_is_global(built):
+    """stop_condition (src/common.jl:92-111) on the sharded path: column statistics of W are summed over the row blocks,
+    row statistics of H over the column shards -- every rank stops at the iteration the unsharded run stops at."""
+    T = np.float64
+    p, n, k = 256, 384, 4
+    X, W0, H0 = planted(p, n, k, T, seed=3)
+    kw = dict(maxiter=400, tol=1e-3, lambda_w=0.0, lambda_h=0.0)
+    Ws, Hs, rr, _ = run_sharded(T, X, W0, H0, "multmse", kw, 2)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("multmse", X, Wc, Hc, orc.Opts(maxiter=400, tol=1e-3))
+    assert ro.converged and all(res.converged for res, _ in rr)
+    assert all(res.niters == ro.niters for res, _ in rr)
+    assert abs(rr[0][0].objvalue - ro.objvalue) <= 1e-9 * abs(ro.objvalue)
+
+
+def test_eight_ranks_bench_shape_fraction(built):
+    """8 ranks at a 1/16-scale C3 aspect (p = n = 1024*... k = 256): the layout the driver's 8-GPU run uses (Pc = p/8 rows
+    per rank, K = 256), fp32, against the unsharded run."""
+    T = np.float32
+    p, n, k = 2048, 2048, 256
+    X, W0, H0 = planted(p, n, k, T, seed=8)
+    kw = dict(maxiter=4, tol=1e-30, track_objective=True)
+    Ws, Hs, rr, Wall = run_sharded(T, X, W0, H0, "multmse", kw, 8)
+    for Wr in Wall[1:]:
+        assert np.array_equal(Wr, Wall[0])
+    W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        r1, t1 = ctx.solve(L.ALG_MULTMSE, nmfx.make_opts(T, **kw), W1, H1)
+    assert rel_trace_err(rr[0][1], t1) < 1e-5
+    assert np.max(np.abs(Ws - W1)) <= 1e-3 * np.max(np.abs(W1))

@@ -110,3 +110,20 @@ def test_argument_errors(built):
     X, W0, H0 = uniform(12, 10, 3, T)
     with pytest.raises(nmfx.DimensionMismatch):
         nmfx.solve(nmfx.MultUpdate(T), X, W0, np.asfortranarray(H0[:, :5]))
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_multdiv_raw_abi_lambda_zero_padded_k(built, T):
+    """A raw C-ABI caller (make_opts defaults lambda_w = lambda_h = 0) on a k that is padded on the device (5 -> 64):
+    the padded components must stay inert (0 * (0/0) would poison W, H and the objective) and the library applies the
+    sqrt(eps(T)) floor MultUpdate's constructor applies for obj = :div (src/multupd.jl:37-40)."""
+    X, W0, H0 = uniform(70, 90, 5, T, seed=5)
+    with nmfx.Context(T, 70, 90, 5) as ctx:
+        ctx.set_X(X)
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        res, trace = ctx.solve(nmfx._lib.ALG_MULTDIV, nmfx.make_opts(T, maxiter=12, tol=1e-30, track_objective=True), W, H)
+    assert res.niters == 12 and np.isfinite(trace[:13]).all() and np.isfinite(W).all() and np.isfinite(H).all()
+    lam = float(T(np.sqrt(np.finfo(T).eps)))
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("multdiv", X, Wc, Hc, orc.Opts(maxiter=12, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+    assert rel_trace_err(trace[:13], ro.trace) < TOL[T][0]

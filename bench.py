@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="do not bracket launches with hipEvents (no roofline object)")
     ap.add_argument("--all-events", action="store_true", help="hipEvent pair around every launch (per-kernel table; slows the loop ~4%%)")
     ap.add_argument("--cpu-sample-cols", type=int, default=2048)
+    ap.add_argument("--sim-ranks", type=int, default=0,
+                    help="measurement aid (1 GPU): time rank 0's COMPUTE of an N-rank run -- X, H are the rank's column shard, the "
+                         "collectives move their bytes device-locally (results are not a factorisation; never a headline number)")
+    ap.add_argument("--comm-mode", default="row_sharded", choices=["row_sharded", "replicated_w"],
+                    help="multi-GPU W side: reduce-scatter / row-sharded update / all-gather (default) or one packed all-reduce + replicated update")
     return ap.parse_args()
 
 
@@ -107,7 +112,8 @@ def main():
     T = np.float32 if a.dtype == "f32" else np.float64
     tdtype = torch.float32 if a.dtype == "f32" else torch.float64
     p, n, k = a.p, a.n, a.k
-    c0, c1 = nmfx.dist.shard_range(n, rank, world)
+    shards = a.sim_ranks if (a.sim_ranks > 1 and world == 1) else world
+    c0, c1 = nmfx.dist.shard_range(n, rank, shards)
     nl = c1 - c0
     # projals: with a cold column-normalised W0 the first H = (W'W + lambda I)^-1 W'X has nearly parallel rows and H H' is not
     # numerically positive definite in fp32 (the reference's potrf! throws PosDefException on the same input), and a cold
@@ -118,9 +124,13 @@ def main():
 
     algid = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3, "cd": 4, "greedycd": 5}[a.alg]
     ctx = nmfx.Context(T, p, nl, k, device=local_rank)
-    ctx.set_X_device(Xt.data_ptr(), p)
-    if world > 1:
+    if world > 1:                       # before set_X: attaching a communicator may change the row padding
         nmfx.dist.init_comm(ctx)
+        ctx.comm_set_mode(a.comm_mode)
+    elif shards > 1:
+        ctx.comm_init_sim(0, shards)
+        ctx.comm_set_mode(a.comm_mode)
+    ctx.set_X_device(Xt.data_ptr(), p)
     ctx.set_factors(W0, H0)
     eps = float(np.finfo(T).eps)
     lam = float(np.sqrt(eps)) if a.alg == "multdiv" else (float(np.cbrt(eps)) if a.alg == "projals" else 0.0)
@@ -192,6 +202,8 @@ def main():
                     "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4),
                     "traffic": traffic,
+                    "traffic_source": ("static: profiles/pmc_traffic.json (rocprofv3 --pmc passes of this kernel on this workload, "
+                                       "taken when the profile was committed; not re-measured in this run)") if traffic is not None else None,
                     "flops_per_launch": dom["flops"] / dom["launches"],
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": dom["launches"]}
         out = {
@@ -203,7 +215,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"X={p}x{n} k={k} {a.dtype} alg=:{a.alg} (planted-rank dense X, seed {SEED}), "
                                    f"column-sharded over {world} GPU(s)", "p": p, "n": n, "k": k,
-                       "parallelism": f"colshard{world}", "precision": a.precision},
+                       "parallelism": f"colshard{world}" + (f"+{a.comm_mode}" if world > 1 else ""), "precision": a.precision},
             "gflops_algorithmic": round(f_alg * a.steps / dt / 1e9, 1),
             "frac_of_mfma_peak": round(f_alg * a.steps / dt / 1e12 / (((2500.0 / 3.0) if a.precision == "bf16x3" else
                                                                         (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6)) * world), 4),
@@ -212,7 +224,10 @@ def main():
             "kernels": [{"name": s["name"], "launches": s["launches"],
                          "avg_us": round(s["ms_total"] / s["launches"] * 1e3, 2)} for s in prof],
         }
-        if world == 1 and not a.no_cpu_baseline and a.alg == "multmse":
+        if shards != world:
+            out["sim_ranks"] = shards
+            out["metric"] += f"_SIMULATED_rank0_of_{shards}_compute_only"
+        if world == 1 and shards == 1 and not a.no_cpu_baseline and a.alg == "multmse":
             out["cpu_baseline"] = cpu_baseline(p, n, k, T, Xt, W0, H0, a.cpu_sample_cols)
         if a.alg == "greedycd":
             out["greedy_steps_per_step"] = res.inner_iters / a.steps
@@ -230,32 +245,65 @@ def main():
 
 def cpu_baseline(p, n, k, T, Xt, W0, H0, ns):
     """NMF.jl's CPU path = the NumPy restatement executing the reference's operation sequence, on the first `ns`
-    columns of the same X (per-iteration cost is linear in n); value is scaled to the full problem."""
+    columns of the same X (per-iteration cost is linear in n); value is scaled to the full problem.
+    PURE iterations are timed: update_wh! + the preW/preH copies + stop_condition of nmf_skeleton! (src/common.jl:66-73),
+    i.e. what one GPU 'step' does -- not prepare_state's W*H product, not the final objective pass."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nmf_oracle as orc
     ns = min(ns, n)
     Xs = np.asfortranarray(Xt[:ns, :].cpu().numpy().T)            # p x ns, column-major
     Ws, Hs = W0.copy(order="F"), np.asfortranarray(H0[:, :ns].copy())
     tiny = float(np.finfo(T).tiny)
-    orc.solve("multmse", Xs, Ws, Hs, orc.Opts(maxiter=1, tol=tiny))      # warm-up (BLAS threads, page faults)
+    o = orc.resolve_opts(orc.ALG_NAMES["multmse"], T, orc.Opts(maxiter=1, tol=tiny))
+    st = orc._MultMSE(T, o, Xs, Ws, Hs)                            # prepare_state (src/multupd.jl:70-78): NOT timed
+    st.update(Xs, Ws, Hs)                                          # warm-up (BLAS threads, page faults)
     iters, t_used = 0, 0.0
-    while iters < 5 and t_used < 15.0:
+    while iters < 6 and t_used < 15.0:
         t0 = time.perf_counter()
-        orc.solve("multmse", Xs, Ws, Hs, orc.Opts(maxiter=1, tol=tiny))
+        preW, preH = Ws.copy(), Hs.copy()                          # common.jl:66-67
+        st.update(Xs, Ws, Hs)                                      # common.jl:70
+        orc.stop_condition(Ws, preW, Hs, preH, T(tiny))            # common.jl:73
         t_used += time.perf_counter() - t0
         iters += 1
-    # each solve() call = WH GEMM (prepare_state) + 1 iteration (6 GEMMs) + objective pass; count it as one iteration
     t_iter_full = t_used / iters * (n / ns)
     try:
         from threadpoolctl import threadpool_info
         blas = [(d.get("internal_api"), d.get("version"), d.get("num_threads")) for d in threadpool_info()]
     except Exception:
         blas = None
-    return {"value": round(1.0 / t_iter_full, 5), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"first {ns} of {n} columns of the same X (p={p}, k={k}), {iters} timed single-iteration solves of "
-                      f"oracle/nmf_oracle.py (reference's 6-GEMM sequence, OpenBLAS threads = all cores), "
-                      f"time scaled by n/{ns}", "seconds_per_iter_full_est": round(t_iter_full, 3),
-            "gflops_reference_equiv": round(12.0 * p * n * k / t_iter_full / 1e9, 1), "blas": blas}
+    out = {"value": round(1.0 / t_iter_full, 5), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"first {ns} of {n} columns of the same X = {ns / n:.4f} of the workload (p={p}, k={k}); {iters} timed pure outer "
+                     f"iterations (update_wh! + preW/preH copies + stop_condition; prepare_state and the final objective are not "
+                     f"timed) of oracle/nmf_oracle.py -- the reference's 6-GEMM sequence, OpenBLAS threads = all cores; time scaled by n/{ns}",
+           "seconds_per_iter_full_est": round(t_iter_full, 3),
+           "gflops_reference_equiv": round(12.0 * p * n * k / t_iter_full / 1e9, 1), "blas": blas}
+    out["julia_reference"] = julia_reference(p, ns, k, T)
+    return out
+
+
+def julia_reference(p, ns, k, T):
+    """if a `julia` with NMF.jl happens to be installed on the box, ALSO time the real reference
+    (NMF.solve! on a rand(p, ns) matrix of the sample's shape) and report it, labelled as such.  Neither this image nor the
+    GPU box ships Julia, so this normally reports found = false."""
+    import shutil
+    import subprocess
+    exe = shutil.which("julia")
+    if exe is None:
+        return {"found": False}
+    jt = "Float32" if T == np.float32 else "Float64"
+    prog = (f"using NMF, Random; Random.seed!(1); X = rand({jt}, {p}, {ns}); W = rand({jt}, {p}, {k}); H = rand({jt}, {k}, {ns}); "
+            f"alg = NMF.MultUpdate{{{jt}}}(obj=:mse, maxiter=2, tol=floatmin({jt})); NMF.solve!(alg, X, copy(W), copy(H)); "
+            f"alg = NMF.MultUpdate{{{jt}}}(obj=:mse, maxiter=4, tol=floatmin({jt})); t = @elapsed NMF.solve!(alg, X, W, H); "
+            f"println(\"NMFJL_SECONDS_PER_ITER=\", t / 4, \" THREADS=\", Threads.nthreads())")
+    try:
+        r = subprocess.run([exe, "-e", prog], capture_output=True, text=True, timeout=300)
+        for line in r.stdout.splitlines():
+            if line.startswith("NMFJL_SECONDS_PER_ITER="):
+                return {"found": True, "kind": "reference", "raw": line.strip(),
+                        "note": f"NMF.solve!(MultUpdate(obj=:mse)) on rand({p},{ns}), 4 iterations incl. prepare_state and the final objective"}
+        return {"found": True, "error": (r.stderr or r.stdout)[-300:]}
+    except Exception as e:  # noqa: BLE001
+        return {"found": True, "error": repr(e)}
 
 
 if __name__ == "__main__":

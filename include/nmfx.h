@@ -216,6 +216,10 @@ int nmfx_local_group_create(nmfx_local_group **out, int nranks);   /* nranks <= 
 void nmfx_local_group_destroy(nmfx_local_group *group);            /* after every attached context is destroyed */
 int nmfx_comm_init_local(nmfx_ctx *ctx, nmfx_local_group *group, int rank);
 int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode);
+/* Measurement aid (no reference counterpart, results are NOT a factorisation): "rank r of n" without peers -- collectives move
+ * the bytes they would receive device-locally -- so the per-rank compute of the sharded path at an n-rank shard shape can be
+ * timed on one GPU (bench.py --sim-ranks). */
+int nmfx_comm_init_sim(nmfx_ctx *ctx, int rank, int nranks);
 
 /* ---- standalone passes of the hot path (measurement + parity of the HBM-bound pieces) ----
  * Operate on the resident X, W, H; results are returned by value.

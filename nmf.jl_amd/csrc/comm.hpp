@@ -84,6 +84,24 @@ struct RcclComm : Comm {
     void group_end() override { NMFX_RCCL(ncclGroupEnd()); }
 };
 
+// ------------------------------------------------------------------------------------------------ timing stand-in
+// "Rank r of n" with NO peers: every collective moves the bytes it would receive device-locally (reduce-scatter: own chunk;
+// all-gather: own chunk into every slot; all-reduce: nothing).  Numerically meaningless -- it exists so that the per-rank
+// COMPUTE of the sharded path at an n-rank shard shape can be timed on a 1-GPU box (bench.py --sim-ranks).
+struct SimComm : Comm {
+    SimComm(int rank_, int nranks_) { rank = rank_; nranks = nranks_; }
+    const char *transport() const override { return "sim"; }
+    void all_reduce(void *, size_t, int, bool, hipStream_t) override {}
+    void reduce_scatter(const void *send, void *recv, size_t recvcount, int ct, hipStream_t s) override {
+        const size_t b = recvcount * ct_size(ct);
+        (void)hipMemcpyAsync(recv, reinterpret_cast<const char *>(send) + (size_t)rank * b, b, hipMemcpyDeviceToDevice, s);
+    }
+    void all_gather(const void *send, void *recv, size_t sendcount, int ct, hipStream_t s) override {
+        const size_t b = sendcount * ct_size(ct);
+        for (int q = 0; q < nranks; ++q) (void)hipMemcpyAsync(reinterpret_cast<char *>(recv) + (size_t)q * b, send, b, hipMemcpyDeviceToDevice, s);
+    }
+};
+
 // --------------------------------------------------------------------------------------------------- in-process group
 constexpr int LOCAL_MAX_RANKS = 16;
 

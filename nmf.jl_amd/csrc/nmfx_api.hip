@@ -157,6 +157,11 @@ int nmfx_comm_init_local(nmfx_ctx *ctx, nmfx_local_group *group, int rank) {
     return guarded(ctx, [&] { ctx->impl->comm_init_local(g, rank); });
 }
 
+int nmfx_comm_init_sim(nmfx_ctx *ctx, int rank, int nranks) {
+    if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->comm_init_sim(rank, nranks); });
+}
+
 int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode) {
     if (!ctx || (mode != NMFX_COMM_ROW_SHARDED && mode != NMFX_COMM_REPLICATED_W)) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { ctx->impl->comm_set_mode(mode); });

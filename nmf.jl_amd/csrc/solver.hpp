@@ -68,6 +68,7 @@ struct SolverBase {
     virtual void comm_init(const void *uid, int rank, int nranks) = 0;
     virtual void comm_init_local(LocalGroup *group, int rank) = 0;
     virtual void comm_set_mode(int mode) = 0;
+    virtual void comm_init_sim(int rank, int nranks) = 0;
     virtual double objective(int alg, const nmfx_opts &o) = 0;
     virtual bool check_nonneg(int which) = 0;
     virtual void randinit(uint64_t seed, bool normalize, bool zeroh, int64_t h_col_offset) = 0;
@@ -234,6 +235,10 @@ template <typename T> class Solver : public SolverBase {
     void comm_init_local(LocalGroup *group, int rank_) override {
         HIP_TRY(hipSetDevice(device));
         attach(new LocalComm(group, rank_, device));
+    }
+    void comm_init_sim(int rank_, int nranks_) override {
+        HIP_TRY(hipSetDevice(device));
+        attach(new SimComm(rank_, nranks_));
     }
     // 0: row-sharded W side (reduce-scatter / all-gather, the default whenever the shapes allow it); 1: the replicated W
     // update behind one packed all-reduce (round-1 formulation, kept for comparison and as the fallback)

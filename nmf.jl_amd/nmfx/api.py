@@ -382,6 +382,10 @@ class Context:
         """Attach this context as `rank` of an in-process group (collective: every rank calls it from its own thread)."""
         self._ck(self.lib.nmfx_comm_init_local(self.h, group.h, rank))
 
+    def comm_init_sim(self, rank: int, nranks: int):
+        """Timing stand-in: rank `rank` of `nranks` without peers (results are not a factorisation; bench.py --sim-ranks)."""
+        self._ck(self.lib.nmfx_comm_init_sim(self.h, rank, nranks))
+
     def comm_set_mode(self, mode: str):
         """'row_sharded' (default: reduce-scatter / all-gather, each rank updates its rows of W) or 'replicated_w'
         (one packed all-reduce, every rank applies the full W update)."""

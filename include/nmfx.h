@@ -227,6 +227,17 @@ int nmfx_comm_init_sim(nmfx_ctx *ctx, int rank, int nranks);
  *              evaluate_objv, src/multupd.jl:81,148; src/projals.jl:65-74; src/alspgrad.jl:398 */
 int nmfx_objective(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, double *out);
 
+/* The SPD utilities ProjectedALS is built from (src/utils.jl:15-24 adddiag!, :34-41 projectnn!, :63-70 pdsolve!, :72-84
+ * pdrsolve!; pinned by test/utils.jl:6-15, 29-34, 48-63), on the SAME device kernels the projals iteration runs (blocked
+ * Cholesky + triangular inverse + MFMA products), for a context created with (p, n_local, k):
+ *   nmfx_pdsolve   X (k x n_local) = inv(A + lambda I) B,   A k x k symmetric positive definite, B k x n_local
+ *   nmfx_pdrsolve  X (p x k)       = A inv(B + lambda I),   A p x k, B k x k symmetric positive definite
+ * lambda = 0 adds nothing (adddiag! skips it); project_nn != 0 clamps negative results to zero (projectnn!).
+ * All matrices host, column-major, type T; A and B are not modified (the reference overwrites its arguments with the factor /
+ * the inverse).  NMFX_ERR_NOT_POSDEF <-> PosDefException.  The resident W, H of the context are used as scratch. */
+int nmfx_pdsolve(nmfx_ctx *ctx, const void *A_host, double lambda, const void *B_host, void *X_host, int project_nn);
+int nmfx_pdrsolve(nmfx_ctx *ctx, const void *A_host, const void *B_host, double lambda, void *X_host, int project_nn);
+
 /* Device/timing introspection used by bench.py (no reference counterpart). */
 typedef struct {
     char name[64];

@@ -167,6 +167,16 @@ int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode) {
     return guarded(ctx, [&] { ctx->impl->comm_set_mode(mode); });
 }
 
+int nmfx_pdsolve(nmfx_ctx *ctx, const void *A_host, double lambda, const void *B_host, void *X_host, int project_nn) {
+    if (!ctx || !A_host || !B_host || !X_host) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->pdsolve_host(0, A_host, B_host, lambda, X_host, project_nn != 0); });
+}
+
+int nmfx_pdrsolve(nmfx_ctx *ctx, const void *A_host, const void *B_host, double lambda, void *X_host, int project_nn) {
+    if (!ctx || !A_host || !B_host || !X_host) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->pdsolve_host(1, A_host, B_host, lambda, X_host, project_nn != 0); });
+}
+
 int nmfx_objective(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, double *out) {
     if (!ctx || !opts || !out) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { *out = ctx->impl->objective(alg, *opts); });

@@ -68,6 +68,7 @@ struct SolverBase {
     virtual void comm_init(const void *uid, int rank, int nranks) = 0;
     virtual void comm_init_local(LocalGroup *group, int rank) = 0;
     virtual void comm_set_mode(int mode) = 0;
+    virtual void pdsolve_host(int right, const void *A_host, const void *B_host, double lambda, void *X_host, bool clamp) = 0;
     virtual void comm_init_sim(int rank, int nranks) = 0;
     virtual double objective(int alg, const nmfx_opts &o) = 0;
     virtual bool check_nonneg(int which) = 0;
@@ -317,6 +318,7 @@ template <typename T> class Solver : public SolverBase {
                      int64_t n_total) override;
     void nndsvd_core(const T *Ud, int64_t ucs, int64_t uss, const T *Vd, int64_t vcs, int64_t vss, const T *sd, T *coef, int variant,
                      bool zeroh, uint64_t seed, int64_t n_total);
+    void pdsolve_host(int right, const void *A_host, const void *B_host, double lambda, void *X_host, bool clamp) override;
     // randomized SVD of the resident X (rsvd_impl.hpp)
     void rsvd_begin(uint64_t seed, int64_t h_col_offset, int power_iters, void *C_host) override;
     void rsvd_finish(const void *Ub_host, const void *s_host, void *U_out, void *Vt_out) override;
@@ -728,6 +730,9 @@ template <typename T> class Solver : public SolverBase {
     void enqueue_multmse(const nmfx_opts &o, long long t);
     void enqueue_multdiv(const nmfx_opts &o, long long t);
     void enqueue_projals(const nmfx_opts &o, long long t);
+    void spd_factor(T *A, T lambda, T *Uinv, const char *tag_potrf, const char *tag_trtri, const int *done);
+    void spd_solve_left(const T *Uinv, const T *B, T *Y, T *out, bool clamp, const int *done);
+    void spd_solve_right(const T *Uinv, T *invA, const T *A, T *out, int64_t rows, bool clamp, const int *done);
     // coordinate-descent updaters (cd_impl.hpp)
     void enqueue_cd(const nmfx_opts &o, long long t);
     void enqueue_greedycd(const nmfx_opts &o, long long t);

@@ -378,6 +378,29 @@ class Context:
         buf = C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)
         self._ck(self.lib.nmfx_comm_init(self.h, buf, rank, nranks))
 
+    def pdsolve(self, A, B, lambda_=0.0, project_nn=False):
+        """inv(A + lambda I) * B on the device kernels of ProjectedALS (adddiag! + pdsolve! [+ projectnn!], src/utils.jl); A is
+        k x k SPD, B is k x n (the context's k, n)."""
+        T = self.T
+        A = np.asfortranarray(A, dtype=T)
+        B = np.asfortranarray(B, dtype=T)
+        if A.shape != (self.k, self.k) or B.shape != (self.k, self.n):
+            raise DimensionMismatch("A must be k x k and B k x n")
+        X = np.empty_like(B, order="F")
+        self._ck(self.lib.nmfx_pdsolve(self.h, A.ctypes.data, float(lambda_), B.ctypes.data, X.ctypes.data, int(project_nn)))
+        return X
+
+    def pdrsolve(self, A, B, lambda_=0.0, project_nn=False):
+        """A * inv(B + lambda I) (adddiag! + pdrsolve! [+ projectnn!]); A is p x k, B is k x k SPD."""
+        T = self.T
+        A = np.asfortranarray(A, dtype=T)
+        B = np.asfortranarray(B, dtype=T)
+        if A.shape != (self.p, self.k) or B.shape != (self.k, self.k):
+            raise DimensionMismatch("A must be p x k and B k x k")
+        X = np.empty_like(A, order="F")
+        self._ck(self.lib.nmfx_pdrsolve(self.h, A.ctypes.data, B.ctypes.data, float(lambda_), X.ctypes.data, int(project_nn)))
+        return X
+
     def comm_init_local(self, group: "LocalGroup", rank: int):
         """Attach this context as `rank` of an in-process group (collective: every rank calls it from its own thread)."""
         self._ck(self.lib.nmfx_comm_init_local(self.h, group.h, rank))

@@ -52,7 +52,9 @@ def test_projals_default_options_and_stop(built, T):
     Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
     ro = orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=200))
     assert r.converged == ro.converged
-    assert abs(r.niters - ro.niters) <= (0 if T == np.float64 else 2)
+    # identical iteration count in BOTH precisions: on this input every iteration of the CPU run keeps a margin of > 1e-2 (f32)
+    # between stop_condition's relchange and tol (tests/test_gpu_track_stop.py explains why that makes the count exact)
+    assert r.niters == ro.niters
     assert abs(r.objvalue - ro.objvalue) <= 20 * TOL[T] * abs(ro.objvalue)
 
 

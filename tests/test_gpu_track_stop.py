@@ -26,7 +26,16 @@ def test_tracked_objective_of_the_converging_iteration(built, alg):
     r = nmfx.solve(_inst(alg, T, maxiter=400, tol=tol), X, W, H, track_objective=True)
     ro = orc.solve(alg, X, W0.copy(order="F"), H0.copy(order="F"), orc.Opts(maxiter=400, tol=tol, track_objective=True))
     assert r.converged and ro.converged and 1 < r.niters < 400
-    assert abs(r.niters - ro.niters) <= 1
+    # Stop-rule fidelity (src/common.jl:92-111).  The reference sums dev / sum sequentially in T; the device sums the same
+    # T-rounded terms in Float64 in a fixed tree order -- the two totals differ by at most ~eps(T)*sqrt(length) relative, so
+    # the DECISION sqrt(dev) > tol*sqrt(sum) can only differ when an iteration's relchange sits that close to tol.  On this
+    # input every iteration keeps a margin of > 1e-4 from the threshold (asserted), the device's relchange column equals the
+    # oracle's to 1e-6, and therefore niters must be IDENTICAL, not just close.
+    rc_o, rc_d = np.array(ro.relchange[1:]), np.array(r.info["relchange"][1:])
+    assert np.min(np.abs(rc_o - tol) / tol) > 1e-4
+    m = min(len(rc_o), len(rc_d))
+    np.testing.assert_allclose(rc_d[:m], rc_o[:m], rtol=1e-6)
+    assert r.niters == ro.niters
     assert len(r.trace) == r.niters + 1 and np.all(np.isfinite(r.trace))
     assert r.objvalue == r.trace[-1]
     m = min(len(r.trace), len(ro.trace))

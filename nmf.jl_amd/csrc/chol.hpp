@@ -34,7 +34,8 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 
 // A: k x k leading block of a column-major matrix with leading dimension ld.  On a non-positive pivot sets
 // ctrl->status = posdef_status and ctrl->done = 1 (PosDefException of potrf!, src/utils.jl:68,78).
-// Dynamic LDS: 32*32 (diagonal block) + 32*kp (row panel, kp = k rounded up to 32) elements of T + 16 bytes.
+// Dynamic LDS: 32*32 (diagonal block) + 32*kps (row panel; kps = max(32, kp - 32), kp = k rounded up to 32: the panel right of
+// the first diagonal block is the widest) elements of T (32 KiB for k = 256 in f32).
 // Per 32-column panel:  (1) wave 0 factors the diagonal block in registers (lane = column, v_readlane
 // broadcasts);  (2) the 32 x m row panel is staged through LDS with coalesced loads and solved one column per
 // thread;  (3) the trailing update A22 -= R'R runs on the matrix cores (MFMA 32x32x2 f32 / 16x16x4 f64) with
@@ -45,10 +46,11 @@ __global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int
     using M = Mfma<T>;
     constexpr int NB = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
-    const int kp = (k + 31) / 32 * 32;
-    T *U11 = reinterpret_cast<T *>(chol_smem);          // U11[i*NB + l] = U(jb+l, jb+i)  (transposed copy)
+    const int kp0 = (k + 31) / 32 * 32;
+    const int kp = (kp0 > 64) ? kp0 - 32 : 32;          // row stride of the panel image (>= the widest panel, m <= k - 32)
+    T *U11 = reinterpret_cast<T *>(chol_smem);          // U11[i*NB + l] = U(jb+l, jb+i)  (transposed copy), l <= i
     T *Rp = U11 + NB * NB;                              // Rp[l*kp + c]  = U(jb+l, jb+nb+c), zero for c >= m
-    int *failp = reinterpret_cast<int *>(chol_smem + (((size_t)(NB * NB + NB * (size_t)kp) * sizeof(T) + 15) / 16) * 16);
+    int *failp = reinterpret_cast<int *>(U11 + 1);      // (i = 0, l = 1) lies in the never-touched half of the transposed block
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
     if (tid == 0) *failp = 0;
     __syncthreads();

@@ -15,8 +15,7 @@ namespace nmfx {
 template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const char *tag_potrf, const char *tag_trtri, const int *done) {
     const size_t kk = (size_t)K * K;
     // potrf: 32 x 32 diagonal block + 32 x kp row panel in LDS (kp = k rounded up to 32)
-    const size_t kp32 = (size_t)(k + 31) / 32 * 32;
-    const size_t lds32 = ((size_t)(32 * 32 + 32 * kp32) * sizeof(T) + 15) / 16 * 16 + 16;
+    const size_t lds32 = potrf_lds_bytes();
     const size_t lds_tri = (size_t)((k + 31) / 32 + 4) * 1024 * sizeof(T);   // finished tiles of a block column + 4 partial tiles
     if (lds_tri > 160 * 1024) throw StatusError{NMFX_ERR_UNSUPPORTED, "projals: k too large for the blocked triangular inverse"};
     if (lds32 > 160 * 1024) throw StatusError{NMFX_ERR_UNSUPPORTED, "projals: k too large for the single-workgroup Cholesky panel (k <= 1248 f32 / 608 f64)"};
@@ -109,6 +108,10 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     work[1].ensure(kk);              // Uinv
     work[2].ensure(kk);              // inv(HH' + lw I)
     T *Y = work[0].p, *Uinv = work[1].p, *invA = work[2].p;
+    // (Running the factorisation on a second stream UNDER the big GEMM was built and measured: it never becomes co-resident --
+    // two 184-register GEMM waves per SIMD are allocated as 2 x 256 and fill the register file, so the Cholesky workgroup only
+    // starts when GEMM blocks drain; 2.76 ms per iteration either way.  DESIGN.md section 3.2.)
+    const bool rs = row_sharded();
     if (o.update_H) {
         const T *Wp = W[wcur].p;
         const T *Ho = H[hcur].p;
@@ -122,7 +125,6 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
-    const bool rs = row_sharded();
     w_blocked = rs;
     times_ht(X.p, Hp, true, done);                                         // :100 HH', :101 XH' (one launch)
     w_blocked = false;

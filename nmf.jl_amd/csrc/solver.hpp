@@ -340,6 +340,10 @@ template <typename T> class Solver : public SolverBase {
     int device, num_cu = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev_beg = nullptr, ev_end = nullptr;
+    size_t potrf_lds_bytes() const {
+        const size_t kp0 = (size_t)(k + 31) / 32 * 32, kps = kp0 > 64 ? kp0 - 32 : 32;
+        return (size_t)(32 * 32 + 32 * kps) * sizeof(T);
+    }
     DevBuf<T> X, Q, W[2], H[2], hside, slabs, svec, pack;
     T *numH_p = nullptr, *gramW_p = nullptr;
     T *numW_p = nullptr, *gramH_p = nullptr, *sH_p = nullptr;
@@ -722,7 +726,7 @@ template <typename T> class Solver : public SolverBase {
     void allreduce_w_side(bool with_hstat, const int *done);
     // Row-sharded W side: reduce-scatter of the numerator by row blocks (+ all-reduce of the small k x k / k-vector tail),
     // and the all-gather that re-assembles W (and sums the ranks' column statistics) afterwards.
-    void scatter_w_numerator(bool with_hstat, const int *done);
+    void scatter_w_numerator(bool with_hstat, const int *done, bool with_tail = true);
     void gather_w_rows(T *Wfull, bool with_stats, const int *done);
     void stats_w_rows(const T *Wn, const T *Wo, const int *done);
 

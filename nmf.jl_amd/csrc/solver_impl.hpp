@@ -86,11 +86,11 @@ template <typename T> void Solver<T>::allreduce_w_side(bool with_hstat, const in
 // Row-sharded W side, step 1: the blocked numerator partial sums (times_ht with w_blocked) are reduce-scattered by row
 // blocks; the small tail of the packed buffer [ H_g H_g' | rowsum(H_g) ] and the H statistics are all-reduced in the same
 // group.  The rank's rows of the summed numerator land back in numW (standard layout, ld P) at [row0, row0 + Pc).
-template <typename T> void Solver<T>::scatter_w_numerator(bool with_hstat, const int *done) {
+template <typename T> void Solver<T>::scatter_w_numerator(bool with_hstat, const int *done, bool with_tail) {
     timed("reduce_scatter_numW", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
         comm->group_start();
         comm->reduce_scatter(numW_p, rs_out.p, (size_t)Pc * K, CT, stream);
-        comm->all_reduce(gramH_p, (size_t)K * K + (size_t)K, CT, false, stream);
+        if (with_tail) comm->all_reduce(gramH_p, (size_t)K * K + (size_t)K, CT, false, stream);
         if (with_hstat) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
         comm->group_end();
     });

@@ -528,7 +528,7 @@ def randinit(X, k, normalize=False, zeroh=False, rng=None):
     return W, H
 
 
-_ALGS = ("multmse", "multdiv", "projals", "alspgrad")
+_ALGS = ("greedycd", "cd", "multmse", "multdiv", "projals", "alspgrad")
 
 
 def truncated_svd(X, k):
@@ -581,18 +581,28 @@ def nndsvd(X, k, zeroh=False, variant="std", initdata=None, seed=0, ctx: Context
     return W, H
 
 
-def nnmf(X, k, init="random", alg="multmse", maxiter=100, tol=None, replicates=1, W0=None, H0=None,
+def nnmf(X, k, init="nndsvdar", alg="greedycd", maxiter=100, tol=None, replicates=1, W0=None, H0=None,
          update_H=True, verbose=False, rng=None, track_objective=False, seed=None, initdata=None):
-    """nnmf(X, k; ...) (src/interf.jl:3-83) for the accelerated algorithms.
+    """nnmf(X, k; init=:nndsvdar, alg=:greedycd, ...) (src/interf.jl:3-83) with the reference's own defaults.
 
-    Scope (SURVEY.md section 8): alg in {multmse, multdiv, projals, alspgrad}, init in {random, custom};
-    the other algorithms / initialisers stay in Julia (the reference's defaults :greedycd / :nndsvdar are
-    outside the accelerated path and raise ArgumentError here).
+    alg in {greedycd, cd, multmse, multdiv, projals, alspgrad} (:spa needs NonNegLeastSquares and raises ArgumentError);
+    init in {nndsvd, nndsvda, nndsvdar, random, custom} (:spa likewise).
 
-    seed=None: random draws come from `rng` (NumPy) on the host.  seed=int: the device front end is used instead --
-    X is uploaded first and checked for negatives there, init=:random and the replicate restarts are drawn by
-    nmfx_randinit (Philox4x32-10) next to the resident X, and only the winning replicate's factors come back."""
+    The NNDSVD initialisers always run on the device front end (randomized SVD + _nndsvd! next to the resident X; the one
+    uniform per component of :nndsvdar comes from Philox keyed by `seed`, default 0 -- Julia's stream cannot be reproduced).
+    For init in {random, custom}: seed=None draws on the host from `rng` (NumPy) and W0 / H0 are updated IN PLACE like
+    the reference does; seed=int uses the device front end -- X is uploaded first and checked for negatives there, the
+    random start and the replicate restarts are drawn by nmfx_randinit (Philox4x32-10), and only the winning replicate's
+    factors come back (custom W0 / H0 are then copied, not aliased)."""
     T = X.dtype.type
+    # host-checkable arguments first (no device needed to reject them)
+    if init not in ("nndsvd", "nndsvda", "nndsvdar", "random", "custom", "spa"):
+        raise ArgumentError("Invalid value for init.")
+    if alg not in _ALGS + ("spa",):
+        raise ArgumentError("Invalid algorithm.")
+    if "spa" in (init, alg):
+        which = f"init=:{init}" if init == "spa" else f"alg=:{alg}"
+        raise ArgumentError(f"{which} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
     if seed is not None or init in ("nndsvd", "nndsvda", "nndsvdar"):
         return _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, verbose,
                             int(0 if seed is None else seed), initdata)
@@ -630,22 +640,7 @@ def nnmf(X, k, init="random", alg="multmse", maxiter=100, tol=None, replicates=1
         raise ArgumentError("Invalid value for init.")
     W = np.asfortranarray(W, dtype=T)
     H = np.asfortranarray(H, dtype=T)
-    if alg == "projals":
-        inst = ProjectedALS(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
-    elif alg == "alspgrad":
-        inst = ALSPGrad(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
-    elif alg == "multmse":
-        inst = MultUpdate(T, obj="mse", maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
-    elif alg == "multdiv":
-        inst = MultUpdate(T, obj="div", maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
-    elif alg == "cd":
-        inst = CoordinateDescent(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
-    elif alg == "greedycd":
-        inst = GreedyCD(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
-    elif alg == "spa":
-        raise ArgumentError(f"alg=:{alg} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
-    else:
-        raise ArgumentError("Invalid algorithm.")
+    inst = _alg_instance(T, alg, maxiter, tol, verbose, update_H)                 # src/interf.jl:61-79
     # solve_replicates! (src/interf.jl:85-101): X is uploaded once and shared by every replicate
     with Context(T, p, n, k) as ctx:
         ctx.set_X(X)

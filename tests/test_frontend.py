@@ -273,3 +273,19 @@ def test_nndsvd_default_svd_is_the_device_rsvd(built):
     We, _ = nmfx.nndsvd(X, 6, initdata=nmfx.truncated_svd(X, 6))
     Wp, _ = nmfx.nndsvd(X, 6, power_iters=3)
     assert np.abs(Wp[:, 0] - We[:, 0]).max() < 0.02 * np.abs(We[:, 0]).max()
+
+
+@pytest.mark.gpu
+def test_nnmf_reference_defaults(built):
+    """nnmf(X, k) with NO keywords = the reference's defaults init = :nndsvdar, alg = :greedycd (src/interf.jl:4-7); the
+    non-negativity check of X (src/interf.jl:15) then runs on the device."""
+    rng = np.random.default_rng(12)
+    X = np.asfortranarray(rng.random((60, 90)))
+    r = nmfx.nnmf(X, 4)
+    assert r.niters >= 1 and np.isfinite(r.objvalue) and np.all(r.W >= 0) and np.all(r.H >= 0)
+    r2 = nmfx.nnmf(X, 4, init="nndsvdar", alg="greedycd")
+    assert r == r2
+    Xneg = X.copy()
+    Xneg[3, 4] = -0.5
+    with pytest.raises(nmfx.ArgumentError, match="non-negative"):
+        nmfx.nnmf(Xneg, 4)

@@ -12,11 +12,11 @@ def test_nnmf_argument_errors():
     Xneg = X.copy()
     Xneg[0, 0] = -1
     with pytest.raises(nmfx.ArgumentError, match="non-negative"):
-        nmfx.nnmf(Xneg, 2)
+        nmfx.nnmf(Xneg, 2, init="random")       # (the default init = :nndsvdar checks X on the device: tests/test_frontend.py)
     with pytest.raises(nmfx.ArgumentError, match="should not exceed"):
-        nmfx.nnmf(X, 7)
+        nmfx.nnmf(X, 7, init="random")
     with pytest.raises(nmfx.ArgumentError, match="replicates"):
-        nmfx.nnmf(X, 2, replicates=0)
+        nmfx.nnmf(X, 2, init="random", replicates=0)
     with pytest.raises(nmfx.ArgumentError, match="set W0 and H0"):
         nmfx.nnmf(X, 2, init="custom")
     W0 = np.ones((6, 2), order="F")

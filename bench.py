@@ -221,9 +221,21 @@ def main():
                                                                         (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6)) * world), 4),
             "objvalue": res.objvalue,
             "roofline": roof,
-            "kernels": [{"name": s["name"], "launches": s["launches"],
-                         "avg_us": round(s["ms_total"] / s["launches"] * 1e3, 2)} for s in prof],
+            # per kernel: average launch time; algorithmic TFLOP/s and algorithmic HBM GB/s where the launch site states them
+            "kernels": [dict({"name": s["name"], "launches": s["launches"], "avg_us": round(s["ms_total"] / s["launches"] * 1e3, 2)},
+                             **({"tflops": round(s["flops"] / s["ms_total"] / 1e9, 1)} if s["flops"] > 0 else {}),
+                             **({"hbm_gbs": round(s["bytes"] / s["ms_total"] / 1e6, 1)} if s["bytes"] > 0 else {})) for s in prof],
         }
+        # the bandwidth-bound passes of the divergence / objective path against the HBM roofline (north_star: "achieved HBM
+        # GB/s for the bandwidth-bound divergence/objective passes"): algorithmic bytes = X read + Q written (ratio pass),
+        # X read (objective pass) -- SURVEY.md section 8d -- over the launch time
+        hb = [s for s in prof if s["bytes"] > 0 and s["name"] in ("gemm_WH_ratio", "gemm_WH_sqdist", "gemm_WH_kldiv")]
+        if hb:
+            out["roofline_hbm"] = [{"bound": "hbm", "kernel": s["name"], "achieved": round(s["bytes"] / s["ms_total"] / 1e6, 1),
+                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(s["bytes"] / s["ms_total"] / 1e6 / PEAK_HBM_GBS, 4),
+                                    "bytes_per_launch": s["bytes"] / s["launches"], "avg_launch_ms": round(s["ms_total"] / s["launches"], 4),
+                                    "note": "fused into the W*H MFMA GEMM (2pnk flop per launch): the launch is MFMA-bound, so the HBM "
+                                            "fraction is what the fusion leaves unused, not a shortfall"} for s in hb]
         if shards != world:
             out["sim_ranks"] = shards
             out["metric"] += f"_SIMULATED_rank0_of_{shards}_compute_only"

@@ -31,12 +31,12 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     HIP_TRY(hipMemcpyAsync(pg_state, &init, sizeof init, hipMemcpyHostToDevice, stream));
     const bool sharded = (left && nranks > 1) || wrows;                    // H is column-sharded; W row-sharded or replicated
     const T epsT = std::numeric_limits<T>::epsilon();
-    const int *idle = &pg_state->idle;
+    const int *idle = &pg_state->idle, *gate = &pg_state->gate;
     // G = Gram*Z - B  (+ projgradnorm^2 partials)            :124-130 / :280-286
     auto grad = [&]() {
         EpiGradNorm<T> e{B, Z, G, left ? K : P, pg_part.p, 0.0};
-        if (left) gemm<KCONTIG, KCONTIG>("gemm_pg_grad", Z, K, N, Gram, K, K, K, 1, true, e, nullptr, 4.0 * K * N * sizeof(T));
-        else gemm<KSTRIDED, KSTRIDED>("gemm_pg_grad", Gram, K, K, Z, P, Rw, K, 1, false, e, nullptr, 4.0 * Rw * K * sizeof(T));
+        if (left) gemm<KCONTIG, KCONTIG>("gemm_pg_grad", Z, K, N, Gram, K, K, K, 1, true, e, gate, 4.0 * K * N * sizeof(T));
+        else gemm<KSTRIDED, KSTRIDED>("gemm_pg_grad", Gram, K, K, Z, P, Rw, K, 1, false, e, gate, 4.0 * Rw * K * sizeof(T));
         return last_blocks;
     };
     // one back-tracking step: Gram * D(alpha) with D formed in the operand loader, scalars reduced in the epilogue
@@ -61,35 +61,55 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
             hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, beta, sigma, epsT, traceiter);
         }
     };
+    // H <- Hn / H <- Hp of the step that broke the loop (no-op while the loop is still running or unchanged)
+    auto apply = [&]() {
+        hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(512), dim3(256), 0, stream, Z, G, rows, cols, ldz, pg_state);
+        hipLaunchKernelGGL(pg_clear_apply_kernel, dim3(1), dim3(1), 0, stream, pg_state);
+        HIP_TRY(hipGetLastError());
+    };
     auto fetch = [&]() {
         HIP_TRY(hipMemcpyAsync(pg_host, pg_state, sizeof(PgState), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     };
+    // The sub-solve is enqueued AHEAD of the host's knowledge, AHEAD inner iterations at a time, each with SPEC back-tracking
+    // steps (the typical search takes 2-3): the state machine on the device turns everything behind a converged iteration
+    // into no-ops, and an iteration whose search needs more than SPEC steps raises `halt`, which freezes the iterations
+    // enqueued behind it until the host has finished that search step by step.  One host round trip per AHEAD inner iterations
+    // instead of one per iteration (it cost ~15 % of the C5 shard's time); the executed sequence, hence every counter and
+    // every bit of Z, is the same.
+    const int SPEC = std::min(4, traceiter), AHEAD = 8;
     long long t = 0;
     bool converged = false;
     while (!converged && t < maxiter) {
-        ++t;
-        const int nblk = grad();
-        if (sharded) {
-            hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 1, 3, 0);
-            comm->all_reduce(pg_state->red + 3, 1, CT_F64, false, stream);
-            hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, tolg);
-        } else {
-            hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, tolg);
+        const int batch = (int)std::min<long long>(AHEAD, (long long)maxiter - t);
+        for (int b = 0; b < batch; ++b) {
+            const int nblk = grad();
+            if (sharded) {
+                hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 1, 3, 2);
+                comm->all_reduce(pg_state->red + 3, 1, CT_F64, false, stream);
+                hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, tolg);
+            } else {
+                hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, tolg);
+            }
+            for (int sidx = 0; sidx < SPEC; ++sidx) step();
+            apply();
+            hipLaunchKernelGGL(pg_endcheck_kernel, dim3(1), dim3(1), 0, stream, pg_state);
         }
-        int enq = 0;
-        auto batch = [&](int nsteps) {
-            for (int s = 0; s < nsteps; ++s) step();
-            enq += nsteps;
-            // H <- Hn / H <- Hp of the step that broke the loop (no-op while the loop is still running or unchanged)
-            hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(512), dim3(256), 0, stream, Z, G, rows, cols, ldz, pg_state);
-            hipLaunchKernelGGL(pg_clear_apply_kernel, dim3(1), dim3(1), 0, stream, pg_state);
-            HIP_TRY(hipGetLastError());
-            fetch();
-        };
-        batch(std::min(3, traceiter));
-        while (!pg_host->idle && enq < traceiter) batch(std::min(4, traceiter - enq));
+        fetch();
+        while (pg_host->halt && !pg_host->nonfinite) {
+            // finish the halted search: the remaining steps, a few at a time
+            while (!pg_host->idle && pg_host->it < traceiter) {
+                const int more = std::min(4, traceiter - pg_host->it);
+                for (int sidx = 0; sidx < more; ++sidx) step();
+                apply();
+                fetch();
+            }
+            hipLaunchKernelGGL(pg_resume_kernel, dim3(1), dim3(1), 0, stream, pg_state);
+            // the iterations that were frozen behind the halt have to be enqueued again: leave the batch loop
+            break;
+        }
         if (pg_host->nonfinite) throw StatusError{NMFX_ERR_ALPHA_NONFINITE, "alpha is not finite"};
+        t = pg_host->t_inner;
         converged = pg_host->converged != 0;
     }
     if (inner_total) *inner_total += t;

@@ -28,8 +28,10 @@ struct PgState {
     int apply;           // 1: Z <- max(Z - alpha_apply*G, 0) pending (pg_apply_kernel clears it)
     int nonfinite;       // alpha became non-finite ("alpha is not finite", alspgrad.jl:140,296)
     int zp_valid;        // a previous trial point exists (false at it == 1 where Hp == H)
-    int pad;
+    int gate;            // != 0: inner iterations enqueued ahead of the host's knowledge are no-ops (= converged | halt)
     long long backtracks;
+    int halt;            // the line search of the current inner iteration needs more steps than were enqueued: the host takes over
+    int t_inner;         // executed inner iterations of this sub-solve (the converged one included, like the reference's t)
 };
 
 template <typename T> __device__ __forceinline__ T pg_trial(T z, T g, T alpha) {
@@ -128,6 +130,7 @@ __device__ __forceinline__ double pg_block_sum(const double *partial, int n, int
 // start of an inner iteration (src/alspgrad.jl:129-137): red[3] = projgradnorm^2 from the gradient GEMM's partials
 // (n_local = 0 when the caller already reduced / all-reduced them into red[3]); converged if < tolg, else arm back-tracking.
 template <typename T> __global__ void pg_begin_kernel(PgState *st, const double *partial, int n_local, T tolg) {
+    if (st->gate) return;
     __shared__ double sm[4];
     if (n_local > 0) {
         const double s = pg_block_sum(partial, n_local, 1, 0, sm);
@@ -142,12 +145,26 @@ template <typename T> __global__ void pg_begin_kernel(PgState *st, const double 
         st->it = 0;
         st->zp_valid = 0;
         st->apply = 0;
+        st->t_inner += 1;
+        if (conv) st->gate = 1;
     }
+}
+
+// end of the steps enqueued for one inner iteration: a line search that is still running hands over to the host
+// (every inner iteration enqueued behind this one becomes a no-op until the host has finished the search)
+__global__ void pg_endcheck_kernel(PgState *st) {
+    if (!st->idle) { st->halt = 1; st->gate = 1; }
+}
+// the host finished a halted line search: speculation may continue
+__global__ void pg_resume_kernel(PgState *st) {
+    st->halt = 0;
+    st->gate = st->converged ? 1 : 0;
 }
 
 // only the reduction part (sharded H: the partial sums are all-reduced before the decision)
 __global__ void pg_reduce_kernel(PgState *st, const double *partial, int n, int nslots, int slot0, int guard_idle) {
-    if (guard_idle && st->idle) return;
+    if (guard_idle == 1 && st->idle) return;
+    if (guard_idle == 2 && st->gate) return;
     __shared__ double sm[4];
     for (int sl = 0; sl < nslots; ++sl) {
         const double s = pg_block_sum(partial, n, nslots, sl, sm);
@@ -170,7 +187,7 @@ __global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local
     }
     if (threadIdx.x != 0) return;
     T alpha = (T)st->alpha;
-    if (!isfinite(alpha)) { st->nonfinite = 1; st->idle = 1; return; }   // :140 (the step's sums are garbage then)
+    if (!isfinite(alpha)) { st->nonfinite = 1; st->idle = 1; st->gate = 1; return; }   // :140 (the step's sums are garbage then)
     const T dv1 = (T)st->red[0], dv2 = (T)st->red[1];
     const bool suff_decr = (((T)1 - sigma) * dv1 + (T)0.5 * dv2) < (T)0;
     st->it += 1;

@@ -22,8 +22,8 @@ template <typename T> int run(int k) {
     T *dA, *dU, *dInv; Ctrl *ctrl;
     CK(hipMalloc(&dA, A.size() * sizeof(T))); CK(hipMalloc(&dU, A.size() * sizeof(T))); CK(hipMalloc(&dInv, A.size() * sizeof(T)));
     CK(hipMalloc(&ctrl, sizeof(Ctrl))); CK(hipMemset(ctrl, 0, sizeof(Ctrl)));
-    const size_t kp = (size_t)(k + 31) / 32 * 32;
-    const size_t lds = ((size_t)(32 * 32 + 32 * kp) * sizeof(T) + 15) / 16 * 16 + 16;
+    const size_t kp0 = (size_t)(k + 31) / 32 * 32, kps = kp0 > 64 ? kp0 - 32 : 32;
+    const size_t lds = (size_t)(32 * 32 + 32 * kps) * sizeof(T);
     const size_t lds_tri = (size_t)((k + 31) / 32 + 4) * 1024 * sizeof(T);
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&trtri_offdiag_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tri));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_upper_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -207,4 +207,25 @@ function solve_replicates!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, 
     NMF.Result{T}(W, H, Int(res[].niters), res[].converged != 0, T(res[].objvalue))
 end
 
+# ---- the SPD utilities of src/utils.jl on the device kernels ProjectedALS runs (include/nmfx.h: nmfx_pdsolve / nmfx_pdrsolve) ----
+# pdsolve!(A, x) : x <- inv(A + lambda I) x   (adddiag! + pdsolve!, src/utils.jl:15-24, 63-70); A is k x k SPD, x is k x n
+function pdsolve!(ctx::Context{T}, A::Matrix{T}, x::Matrix{T}; lambda::Real=0, projectnn::Bool=false) where T
+    check(ccall((:nmfx_pdsolve, libnmfx), Cint, (Ptr{Cvoid}, Ptr{T}, Float64, Ptr{T}, Ptr{T}, Cint), ctx.h, A, lambda, x, x, projectnn), ctx.h)
+    x
+end
+# pdrsolve!(A, B, x) : x <- A inv(B + lambda I)   (adddiag! + pdrsolve!, src/utils.jl:72-84); A, x are p x k, B is k x k SPD
+function pdrsolve!(ctx::Context{T}, A::Matrix{T}, B::Matrix{T}, x::Matrix{T}; lambda::Real=0, projectnn::Bool=false) where T
+    check(ccall((:nmfx_pdrsolve, libnmfx), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Float64, Ptr{T}, Cint), ctx.h, A, B, lambda, x, projectnn), ctx.h)
+    x
+end
+
+# ---- multi-GPU from ONE Julia process: one task (thread) per Context, all attached to a local group (include/nmfx.h) --------
+# g = local_group(nranks); Threads.@spawn per rank: ctx = Context{T}(...) on its device; attach!(ctx, g, rank) BEFORE the X upload
+# changes anything (the row padding depends on nranks); then solve! as usual with the rank's column shard of X and H.
+local_group(nranks::Integer) = (r = Ref{Ptr{Cvoid}}(C_NULL);
+                                check(ccall((:nmfx_local_group_create, libnmfx), Cint, (Ref{Ptr{Cvoid}}, Cint), r, nranks)); r[])
+free_local_group(g::Ptr{Cvoid}) = ccall((:nmfx_local_group_destroy, libnmfx), Cvoid, (Ptr{Cvoid},), g)
+attach!(ctx::Context, g::Ptr{Cvoid}, rank::Integer) =
+    check(ccall((:nmfx_comm_init_local, libnmfx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), ctx.h, g, rank), ctx.h)
+
 end # module

@@ -193,12 +193,11 @@ int nmfx_rsvd_finish(nmfx_ctx *ctx, const void *Ub_host, const void *s_host, voi
  * Rank r owns columns [c0, c0+n_local) of X and H; W is replicated between iterations.  Per outer iteration ONE exchange
  * step on the W side:
  *   NMFX_COMM_ROW_SHARDED (default): reduce-scatter of X_g H_g' by row blocks (+ a small all-reduce of H_g H_g', rowsum(H_g)
- *       and the H statistics) -- rank r then updates only ITS p/nranks rows of W (the update rules, projals' W = XH'(HH')^-1
- *       and alspgrad's W sub-problem are all row-separable) -- and an all-gather re-assembles W.  Same bytes on the wire as
+ *       and the H statistics) -- rank r then updates only ITS p/nranks rows of W (the update rules, projals' W = XH'(HH')^-1,
+ *       alspgrad's W sub-problem and the cd / greedycd row sweeps are all row-separable) -- and an all-gather re-assembles W.  Same bytes on the wire as
  *       the all-reduce, but no replicated W-side work.
  *   NMFX_COMM_REPLICATED_W: one packed sum all-reduce of [X_g H_g' | H_g H_g' | rowsum(H_g)]; every rank applies the
- *       identical full W update (round-1 formulation; the fallback when p/nranks is not a whole number of 128-row tiles;
- *       CoordinateDescent / GreedyCD always use it).
+ *       identical full W update (round-1 formulation; the fallback when p/nranks is not a whole number of 128-row tiles).
  * Two transports behind the same code path:
  *   one process per GPU (production, bench.py): RCCL over xGMI.  Rank 0 calls nmfx_comm_get_unique_id, the host
  *       broadcasts the 128 bytes by any means, every rank calls nmfx_comm_init.  nranks == 1 is valid.

@@ -53,15 +53,29 @@ template <typename T> void Solver<T>::enqueue_cd(const nmfx_opts &o, long long t
         const T *Hp = H[hcur].p;
         const T *Wo = W[wcur].p;
         T *Wn = W[wcur ^ 1].p;
+        // multi-GPU: the rows of W do not interact in the sweep, so with the row-sharded W side this rank
+        // sweeps only ITS rows [row0, row0 + rows): numerator by reduce-scatter, rows re-assembled by the all-gather
+        const bool rs = row_sharded();
+        const int64_t r0 = rs ? row0 : 0, rows = rs ? std::max<int64_t>(0, std::min<int64_t>(Pc, p - row0)) : p;
+        w_blocked = rs;
         times_ht(X.p, Hp, true, done);
-        allreduce_w_side(false, done);
+        w_blocked = false;
+        if (rs) scatter_w_numerator(false, done);
+        else allreduce_w_side(false, done);
         if (o.l2_w > 0)   // :118-120
             hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, gramH_p, K, (int)k, (T)o.l2_w, done);
-        timed("cd_sweep_W", 2.0 * p * k * k, 3.0 * P * K * sizeof(T), [&] {
-            cd_sweep(SampleView<const T>{Wo, 1, P}, SampleView<T>{Wn, 1, P}, SampleView<const T>{numW_p, 1, P}, gramH_p, p, (T)o.l1_w, done);
+        timed("cd_sweep_W", 2.0 * rows * k * k, 3.0 * rows * K * sizeof(T), [&] {
+            if (rows > 0)
+                cd_sweep(SampleView<const T>{Wo + r0, 1, P}, SampleView<T>{Wn + r0, 1, P}, SampleView<const T>{numW_p + r0, 1, P}, gramH_p, rows,
+                         (T)o.l1_w, done);
             HIP_TRY(hipGetLastError());
         });
-        stats_w(Wn, Wo, done);
+        if (rs) {
+            stats_w_rows(Wn, Wo, done);
+            gather_w_rows(Wn, true, done);
+        } else {
+            stats_w(Wn, Wo, done);
+        }
         wcur ^= 1;
     }
     if (o.update_H) {   // ---- H (:169-174) through the transposed views
@@ -88,7 +102,7 @@ template <typename T>
 void Solver<T>::greedy_side(const char *tag, SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> G, const T *Pm, int64_t nsamples,
                             T lambda, bool sharded_samples, const int *done) {
     const T epsT = std::numeric_limits<T>::epsilon();
-    const unsigned blocks = (unsigned)((nsamples + 3) / 4);
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, (nsamples + 3) / 4);   // >= 1: a rank without samples still takes part in the p_init all-reduce
     work[3].ensure((size_t)blocks + 8);
     T *part = work[3].p, *pinit = work[3].p + blocks;
     timed(tag, 0.0, 4.0 * (double)nsamples * K * sizeof(T), [&] {
@@ -113,15 +127,27 @@ template <typename T> void Solver<T>::enqueue_greedycd(const nmfx_opts &o, long 
         const T *Hp = H[hcur].p;
         const T *Wo = W[wcur].p;
         T *Wn = W[wcur ^ 1].p;
+        // multi-GPU, row-sharded W side: this rank forms G and sweeps for ITS rows; p_init is the maximum over ALL rows
+        // (greedycd.jl:127-132) -> one max all-reduce, like on the column-sharded H side
+        const bool rs = row_sharded();
+        const int64_t r0 = rs ? row0 : 0, rows = rs ? std::max<int64_t>(0, std::min<int64_t>(Pc, p - row0)) : p;
+        w_blocked = rs;
         times_ht(X.p, Hp, true, done);
-        allreduce_w_side(false, done);
+        w_blocked = false;
+        if (rs) scatter_w_numerator(false, done);
+        else allreduce_w_side(false, done);
         work[0].ensure((size_t)std::max(P * K, K * N));
         T *G = work[0].p;
-        EpiSubStore<T> e{numW_p, G, P};
-        gemm<KSTRIDED, KSTRIDED>("gemm_WP_subZ", gramH_p, K, K, Wo, P, P, K, 1, false, e, done, 3.0 * P * K * sizeof(T));
-        greedy_side("greedy_W", SampleView<const T>{Wo, 1, P}, SampleView<T>{Wn, 1, P}, SampleView<const T>{G, 1, P}, gramH_p, p,
-                    (T)o.lambda_w, false, done);
-        stats_w(Wn, Wo, done);
+        EpiSubStore<T> e{numW_p + r0, G + r0, P};
+        gemm<KSTRIDED, KSTRIDED>("gemm_WP_subZ", gramH_p, K, K, Wo + r0, P, rs ? Pc : P, K, 1, false, e, done, 3.0 * (rs ? Pc : P) * K * sizeof(T));
+        greedy_side("greedy_W", SampleView<const T>{Wo + r0, 1, P}, SampleView<T>{Wn + r0, 1, P}, SampleView<const T>{G + r0, 1, P}, gramH_p, rows,
+                    (T)o.lambda_w, rs, done);
+        if (rs) {
+            stats_w_rows(Wn, Wo, done);
+            gather_w_rows(Wn, true, done);
+        } else {
+            stats_w(Wn, Wo, done);
+        }
         wcur ^= 1;
     }
     if (o.update_H) {   // ---- H (:171-174)

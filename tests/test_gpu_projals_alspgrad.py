@@ -1,8 +1,12 @@
 """GPU parity: ProjectedALS and ALSPGrad through the C ABI vs the CPU oracle.
 
-Stated tolerances.  projals: objective trajectory 1e-7 (f64) / 2e-3 (f32) relative -- the f32 figure is the
-conditioning of the reference algorithm itself (two CPU implementations of it differ by ~2e-4, see
-tests/golden/make_golden.py); the device H-solve uses Uinv*(Uinv'*B) instead of two substitutions.
+Stated tolerances.  projals: objective trajectory 1e-7 (f64) relative.  In f32 the algorithm itself amplifies rounding by the
+condition number of the Grams (up to 4e4 on these inputs), so ANY fp32 implementation drifts from the exact trajectory: the
+yardstick is the fp64 run of the same algorithm on the same (f32) inputs, and the GPU may be off by at most
+max(2e-4, 2.5 x the error of the worse of the two CPU fp32 restatements against that fp64 run) -- measured (scripts/
+projals_f32_error.py): GPU 1.0e-4 / 6.4e-3 / 1.7e-4 / 0.36 against CPU 3.7e-5 / 5.7e-3 / 1.7e-3 / 0.41 on the four shapes below
+(the last one, k = 100 ~ min(p, n), is ill-conditioned for everybody).  The device H-solve uses Uinv*(Uinv'*B) instead of
+two substitutions (same forward-error class).
 alspgrad: 1e-7 (f64) / 2e-3 (f32); its suff_decr / isapprox branches are discontinuous in the data, so
 trajectories (not branch traces) are compared, as SURVEY.md section 7 prescribes.
 """
@@ -30,11 +34,16 @@ def test_projals_trajectory(built, T, shape):
     Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
     ro = orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=15, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
     assert r.niters == ro.niters == 15
-    # conditioning yardstick: how far the two independent CPU restatements of the SAME algorithm drift apart on
-    # this input (cond(HH'+lambda I) reaches 4e4 for k=70 in f32).  The GPU may not deviate from the reference by
-    # more than 3x that, nor is it asked to beat it.
     rc = co.solve("projals", X, W0.copy(order="F"), H0.copy(order="F"),
                   orc.Opts(maxiter=15, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+    if T == np.float32:
+        # yardstick: the fp64 run of the same algorithm on the same inputs; the GPU's distance from it against the CPU fp32
+        # restatements' distance from it (cond(HH'+lambda I) reaches 4e4 for k = 70)
+        r64 = orc.solve("projals", np.asfortranarray(X.astype(np.float64)), np.asfortranarray(W0.astype(np.float64)),
+                        np.asfortranarray(H0.astype(np.float64)),
+                        orc.Opts(maxiter=15, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+        cpu = max(rel_trace_err(ro.trace, r64.trace), rel_trace_err(rc.trace, r64.trace))
+        assert rel_trace_err(r.trace, r64.trace) <= max(2e-4, 2.5 * cpu)
     tol = max(TOL[T], 3 * rel_trace_err(rc.trace, ro.trace))
     assert rel_trace_err(r.trace, ro.trace) < tol
     assert np.max(np.abs(Wg - Wc)) <= 50 * tol * np.max(np.abs(Wc))
@@ -129,5 +138,5 @@ def test_projals_large_k(built, T, k):
                   orc.Opts(maxiter=6, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
     tol = max(TOL[T], 3 * rel_trace_err(rc.trace, ro.trace))
     assert r.niters == ro.niters
-    assert rel_trace_err(r.trace, ro.trace) < tol
+    assert rel_trace_err(r.trace, ro.trace) < (tol if T == np.float64 else 3e-4)      # well conditioned: 8e-5 measured in f32
     assert np.max(np.abs(Wg - Wc)) <= 50 * tol * np.max(np.abs(Wc))

@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--sim-ranks", type=int, default=0,
                     help="measurement aid (1 GPU): time rank 0's COMPUTE of an N-rank run -- X, H are the rank's column shard, the "
                          "collectives move their bytes device-locally (results are not a factorisation; never a headline number)")
-    ap.add_argument("--comm-mode", default="row_sharded", choices=["row_sharded", "replicated_w"],
+    ap.add_argument("--comm-mode", default="row_sharded", choices=["row_sharded", "replicated_w", "pipelined"],
                     help="multi-GPU W side: reduce-scatter / row-sharded update / all-gather (default) or one packed all-reduce + replicated update")
     return ap.parse_args()
 

@@ -198,6 +198,10 @@ int nmfx_rsvd_finish(nmfx_ctx *ctx, const void *Ub_host, const void *s_host, voi
  *       the all-reduce, but no replicated W-side work.
  *   NMFX_COMM_REPLICATED_W: one packed sum all-reduce of [X_g H_g' | H_g H_g' | rowsum(H_g)]; every rank applies the
  *       identical full W update (round-1 formulation; the fallback when p/nranks is not a whole number of 128-row tiles).
+ *   NMFX_COMM_PIPELINED (opt-in): the row-sharded form with the exchange overlapped: the W side runs per row super-chunk, chunk
+ *       c's reduce-scatter on a second stream under chunk c+1's X_g H_g' launch, its all-gather under the next iteration's
+ *       W'X split-K part of chunk c+1.  MultUpdate-MSE only (other algorithms run as ROW_SHARDED); same results bit for bit
+ *       up to the split-K grouping of the two big products.
  * Two transports behind the same code path:
  *   one process per GPU (production, bench.py): RCCL over xGMI.  Rank 0 calls nmfx_comm_get_unique_id, the host
  *       broadcasts the 128 bytes by any means, every rank calls nmfx_comm_init.  nranks == 1 is valid.
@@ -207,7 +211,7 @@ int nmfx_rsvd_finish(nmfx_ctx *ctx, const void *Ub_host, const void *s_host, voi
  *       hand-written kernels reading the peers' buffers, ordered by hipEvents; reductions add in rank order.
  * nmfx_comm_init* must precede nmfx_set_X when p is not a multiple of lcm(256, 128*nranks) (the row padding changes). */
 #define NMFX_UNIQUE_ID_BYTES 128
-enum { NMFX_COMM_ROW_SHARDED = 0, NMFX_COMM_REPLICATED_W = 1 };
+enum { NMFX_COMM_ROW_SHARDED = 0, NMFX_COMM_REPLICATED_W = 1, NMFX_COMM_PIPELINED = 2 };
 typedef struct nmfx_local_group nmfx_local_group;
 int nmfx_comm_get_unique_id(void *out_bytes /* NMFX_UNIQUE_ID_BYTES */);
 int nmfx_comm_init(nmfx_ctx *ctx, const void *unique_id_bytes, int rank, int nranks);

@@ -303,18 +303,19 @@ __global__ void finish_sumsq_kernel(const double *partial, int n, T half_lambda,
 // which a reduce-scatter / all-gather chunk is contiguous.
 // ---------------------------------------------------------------------------------------------------------------------
 
-// split-K combine of the X*H' slabs written STRAIGHT into the blocked reduce-scatter send buffer:
-//   dst[(g*K + a)*Pc + il] = sum_s src[s*stride + i + a*P],  i = g*Pc + il   (s ascending, like reduce_slabs_kernel)
+// split-K combine of the X*H' slabs written STRAIGHT into the blocked reduce-scatter send buffer, for the rows [i0, i0 + R)
+// (all P rows, or one row super-chunk of the pipelined exchange):
+//   dst[(blk*K + a)*Pc + il] = sum_s src[s*stride + i + a*P],  i = blk*Pc + il   (s ascending, like reduce_slabs_kernel)
 template <typename T>
 __global__ void reduce_slabs_blocked_kernel(T *dst, const T *src, int64_t P, int64_t K, int64_t Pc, int nslab, int64_t stride,
-                                            const int *done) {
+                                            int64_t i0, int64_t R, const int *done) {
     NMFX_DONE_GUARD(done);
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= P * K) return;
-    const int64_t i = e % P, a = e / P, g = i / Pc, il = i % Pc;
-    T s = src[e];
-    for (int k = 1; k < nslab; ++k) s += src[(int64_t)k * stride + e];
-    dst[(g * K + a) * Pc + il] = s;
+    if (e >= R * K) return;
+    const int64_t i = i0 + e % R, a = e / R, blk = i / Pc, il = i % Pc, o = i + a * P;
+    T s = src[o];
+    for (int k = 1; k < nslab; ++k) s += src[(int64_t)k * stride + o];
+    dst[(blk * K + a) * Pc + il] = s;
 }
 
 // rows [row0, row0 + Pc) of a column-major P x K matrix (ld P)  <->  a contiguous Pc x K piece (ld Pc)
@@ -330,21 +331,23 @@ __global__ void piece_to_rows_kernel(T *full, const T *piece, int64_t P, int64_t
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < Pc * K; e += (int64_t)gridDim.x * blockDim.x)
         full[row0 + e % Pc + (e / Pc) * P] = piece[e];
 }
-// all-gather receive buffer (G chunks of `chunk_bytes`: [Pc x K piece | ntail doubles]) -> full matrix (ld P); the ranks'
-// tail vectors (per-column partial sums of the stop statistics, src/common.jl:95-99) are added in rank order -> tail_sum
+// all-gather receive buffer (G chunks of `chunk_bytes`: [Pc x K piece | ntail doubles]) -> rows [rowbase + g*Pc, ... + Pc) of the
+// full matrix (ld P), g = 0..G-1; the ranks' tail vectors (per-column partial sums of the stop statistics,
+// src/common.jl:95-99) are added in rank order -> tail_sum (accumulate != 0: added to what is there -- the later row
+// super-chunks of the pipelined exchange)
 template <typename T>
 __global__ void gathered_to_full_kernel(T *full, const unsigned char *recv, int G, size_t chunk_bytes, int64_t P, int64_t K,
-                                        int64_t Pc, int ntail, double *tail_sum, const int *done) {
+                                        int64_t Pc, int64_t rowbase, int ntail, double *tail_sum, int accumulate, const int *done) {
     NMFX_DONE_GUARD(done);
     const int64_t total = (int64_t)G * Pc * K;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t g = e / (Pc * K), r = e % (Pc * K);
         const T *piece = reinterpret_cast<const T *>(recv + (size_t)g * chunk_bytes);
-        full[g * Pc + r % Pc + (r / Pc) * P] = piece[r];
+        full[rowbase + g * Pc + r % Pc + (r / Pc) * P] = piece[r];
     }
     if (blockIdx.x == 0 && tail_sum != nullptr)
         for (int j = threadIdx.x; j < ntail; j += blockDim.x) {
-            double s = 0.0;
+            double s = accumulate ? tail_sum[j] : 0.0;
             for (int g = 0; g < G; ++g)
                 s += reinterpret_cast<const double *>(recv + (size_t)g * chunk_bytes + (size_t)Pc * K * sizeof(T))[j];
             tail_sum[j] = s;

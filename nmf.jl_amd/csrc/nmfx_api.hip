@@ -11,6 +11,7 @@
 #include "frontend_impl.hpp"
 #include "cd_impl.hpp"
 #include "rsvd_impl.hpp"
+#include "pipeline_impl.hpp"
 
 using namespace nmfx;
 
@@ -163,7 +164,7 @@ int nmfx_comm_init_sim(nmfx_ctx *ctx, int rank, int nranks) {
 }
 
 int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode) {
-    if (!ctx || (mode != NMFX_COMM_ROW_SHARDED && mode != NMFX_COMM_REPLICATED_W)) return NMFX_ERR_BAD_ARG;
+    if (!ctx || (mode != NMFX_COMM_ROW_SHARDED && mode != NMFX_COMM_REPLICATED_W && mode != NMFX_COMM_PIPELINED)) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { ctx->impl->comm_set_mode(mode); });
 }
 

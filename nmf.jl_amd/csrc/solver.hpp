@@ -155,15 +155,16 @@ template <typename T> class Solver : public SolverBase {
         s_gh = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), N);
         // slab buffer = [ big-GEMM slabs | Gram slabs ]: the two live side by side so the update GEMM can consume
         // the un-reduced numerator slabs directly in its epilogue
-        const size_t h_region = (size_t)s_h * K * N;
-        const size_t w_region = (size_t)s_w * P * K;
+        // (x PIPE_C: the pipelined exchange launches the big products per row super-chunk, each with its own split-K slabs)
+        const size_t h_region = (size_t)s_h * K * N * PIPE_C;
+        const size_t w_region = (size_t)std::max(s_w, pick_splits((int)(P / PIPE_C / 128) * (int)((K + 127) / 128), N)) * P * K;
         slab_w_off = h_region;
         gram_slab_off = h_region + w_region;
         // Gram slabs: split-K slabs of the stand-alone Gram launch, or tail pieces of the fused launch
         // (pieces <= blocks / tail tiles, see tail_piece)
         const size_t tail_tiles_total = std::max<size_t>(1, ((K + 127) / 128) * ((K + 127) / 128));
         const size_t max_pieces = (size_t)(2 * num_cu * 4) / tail_tiles_total + 2;
-        max_gram_slabs = (int)std::max<size_t>((size_t)std::max(s_gw, s_gh), max_pieces);
+        max_gram_slabs = (int)std::max<size_t>((size_t)std::max(s_gw, s_gh), max_pieces) * PIPE_C;
         slabs.alloc(gram_slab_off + (size_t)max_gram_slabs * K * K);
         stat_chunks_w = (int)std::max<int64_t>(1, std::min<int64_t>(64, P / 1024));
         stat_chunks_h = (int)std::max<int64_t>(1, std::min<int64_t>(256, N / 64));
@@ -185,6 +186,12 @@ template <typename T> class Solver : public SolverBase {
         (void)hipStreamSynchronize(stream);
         delete comm;
         comm = nullptr;
+        if (cstream) {
+            (void)hipStreamSynchronize(cstream);
+            for (int c = 0; c < PIPE_C; ++c) { (void)hipEventDestroy(ev_red[c]); (void)hipEventDestroy(ev_rs[c]); (void)hipEventDestroy(ev_pack[c]); (void)hipEventDestroy(ev_ag[c]); }
+            (void)hipEventDestroy(ev_tail);
+            (void)hipStreamDestroy(cstream);
+        }
         for (auto &e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (pg_state) (void)hipFree(pg_state);
         if (pg_host) (void)hipHostFree(pg_host);
@@ -242,7 +249,8 @@ template <typename T> class Solver : public SolverBase {
         attach(new SimComm(rank_, nranks_));
     }
     // 0: row-sharded W side (reduce-scatter / all-gather, the default whenever the shapes allow it); 1: the replicated W
-    // update behind one packed all-reduce (round-1 formulation, kept for comparison and as the fallback)
+    // update behind one packed all-reduce (round-1 formulation, kept for comparison and as the fallback); 2: row-sharded with
+    // the exchange pipelined against the big products (MultUpdate-MSE; the other algorithms run as in mode 0)
     void comm_set_mode(int mode) override { comm_mode = mode; }
     void attach(Comm *c) {
         delete comm;
@@ -251,7 +259,7 @@ template <typename T> class Solver : public SolverBase {
         nranks = c->nranks;
         if (nranks > 1) {
             // whole 128-row tiles per rank for the row-sharded W side
-            int64_t m = 128 * (int64_t)nranks, a = 256, b = m;
+            int64_t m = 128 * (int64_t)nranks * PIPE_C, a = 256, b = m;   // x PIPE_C: whole tiles per rank and row super-chunk
             while (b) { const int64_t t = a % b; a = b; b = t; }
             const int64_t row_mult = 256 / a * m;
             if (round_up(p, row_mult) != P) {
@@ -260,10 +268,23 @@ template <typename T> class Solver : public SolverBase {
             }
             Pc = P / nranks;
             row0 = (int64_t)rank * Pc;
+            Rc = P / PIPE_C;
+            Pcc = Pc / PIPE_C;
             ag_chunk_bytes = (size_t)Pc * K * sizeof(T) + (size_t)2 * K * sizeof(double);
+            agc_bytes = (size_t)Pcc * K * sizeof(T) + (size_t)2 * K * sizeof(double);
             rs_out.alloc((size_t)Pc * K);
-            ag_send.alloc(ag_chunk_bytes);
-            ag_recv.alloc(ag_chunk_bytes * (size_t)nranks);
+            ag_send.alloc(std::max(ag_chunk_bytes, agc_bytes * PIPE_C));
+            ag_recv.alloc(std::max(ag_chunk_bytes, agc_bytes * PIPE_C) * (size_t)nranks);
+            if (!cstream) {
+                HIP_TRY(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+                for (int c = 0; c < PIPE_C; ++c) {
+                    HIP_TRY(hipEventCreateWithFlags(&ev_red[c], hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&ev_rs[c], hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&ev_pack[c], hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&ev_ag[c], hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventCreateWithFlags(&ev_tail, hipEventDisableTiming));
+            }
         }
     }
 
@@ -378,7 +399,23 @@ template <typename T> class Solver : public SolverBase {
     size_t ag_chunk_bytes = 0;
     DevBuf<T> rs_out;                       // reduce-scatter output: this rank's rows of the summed numerator (Pc x K, ld Pc)
     DevBuf<unsigned char> ag_send, ag_recv; // all-gather chunks: [ Pc x K piece of the new W | 2K doubles of column statistics ]
-    bool row_sharded() const { return nranks > 1 && comm_mode == 0 && Pc > 0 && Pc % 128 == 0; }
+    bool row_sharded() const { return nranks > 1 && comm_mode != NMFX_COMM_REPLICATED_W && Pc > 0 && Pc % 128 == 0; }
+    // Pipelined exchange (pipeline_impl.hpp; NMFX_COMM_PIPELINED, MultUpdate-MSE): the W side runs per row super-chunk, chunk
+    // c's reduce-scatter on a second stream under chunk c+1's X*H' launch, its all-gather under the next iteration's W'X part.
+    static constexpr int PIPE_C = 2;
+    int64_t Rc = 0, Pcc = 0;              // rows per super-chunk, rows per (super-chunk, rank)
+    size_t agc_bytes = 0;
+    hipStream_t cstream = nullptr;        // the collectives of the pipelined mode
+    hipEvent_t ev_red[PIPE_C] = {}, ev_rs[PIPE_C] = {}, ev_pack[PIPE_C] = {}, ev_ag[PIPE_C] = {}, ev_tail = nullptr;
+    bool pipe_pending = false;            // an iteration's W is still in flight (all-gather not consumed, stop check not run)
+    long long pipe_t = 0;                 // ... that iteration's number
+    int pipe_gram_pieces = 1;             // Gram tail pieces per chunk launch
+    bool pipelined() const { return row_sharded() && comm_mode == NMFX_COMM_PIPELINED && Pcc > 0 && Pcc % 128 == 0 && fuse_gram && K % 128 == 0 && !use_bf16x3(); }
+    void enqueue_multmse_pipelined(const nmfx_opts &o, long long t);
+    void pipe_consume_w(const nmfx_opts &o, bool launch_wtx);
+    void pipe_flush(const nmfx_opts &o);
+    void wt_times_chunk(const T *Wp, const T *Bmat, int c, const int *done);
+    void times_ht_chunk(const T *Amat, const T *Hp, int c, const int *done);
     static constexpr int CT = sizeof(T) == 4 ? CT_F32 : CT_F64;
 
     // profiling (hipEvent pair per launch, resolved lazily)
@@ -528,7 +565,7 @@ template <typename T> class Solver : public SolverBase {
     // the Gram slab buffer.  One piece per block => every block does kchunk/BK + tail_per k-tiles.
     int tail_piece(int blocks, int tail_tiles_total, int nkt) const {
         int per = std::max(1, (int)(((int64_t)tail_tiles_total * nkt + blocks - 1) / blocks));
-        while ((int64_t)tail_tiles_total * ((nkt + per - 1) / per) > blocks || (nkt + per - 1) / per > max_gram_slabs) ++per;
+        while ((int64_t)tail_tiles_total * ((nkt + per - 1) / per) > blocks || (nkt + per - 1) / per > max_gram_slabs / PIPE_C) ++per;
         return per;
     }
 
@@ -681,7 +718,7 @@ template <typename T> class Solver : public SolverBase {
         if (w_blocked) {
             timed("reduce_XHt", 0.0, (double)P * K * (w_nslab + 1) * sizeof(T), [&] {
                 hipLaunchKernelGGL(reduce_slabs_blocked_kernel<T>, dim3((unsigned)((P * K + 255) / 256)), dim3(256), 0, stream, numW_p, reg,
-                                   P, K, Pc, w_nslab, w_stride, done);
+                                   P, K, Pc, w_nslab, w_stride, (int64_t)0, P, done);
                 HIP_TRY(hipGetLastError());
             });
             w_in_slabs = false;

@@ -121,7 +121,7 @@ template <typename T> void Solver<T>::gather_w_rows(T *Wfull, bool with_stats, c
         comm->all_gather(ag_send.p, ag_recv.p, ag_chunk_bytes, CT_BYTE, stream);
     });
     hipLaunchKernelGGL(gathered_to_full_kernel<T>, dim3(flat_grid(P * K)), dim3(256), 0, stream, Wfull, ag_recv.p, nranks, ag_chunk_bytes,
-                       P, K, Pc, with_stats ? (int)(2 * K) : 0, with_stats ? wstat.p : (double *)nullptr, done);
+                       P, K, Pc, (int64_t)0, with_stats ? (int)(2 * K) : 0, with_stats ? wstat.p : (double *)nullptr, 0, done);
     HIP_TRY(hipGetLastError());
 }
 
@@ -263,6 +263,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     if (alg < 0 || alg > NMFX_ALG_GREEDYCD) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid algorithm."};
     if (o.precision != NMFX_PREC_FP32 && o.precision != NMFX_PREC_BF16X3) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for precision."};
     precision = o.precision;
+    pipe_pending = false;
     rsvd_ready = 0;   // the iteration overwrites the buffers a pending rsvd keeps its Q / B in
     HIP_TRY(hipSetDevice(device));
     std::memset(out, 0, sizeof *out);
@@ -288,16 +289,22 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     while (t < o.maxiter) {
         ++t;
         switch (alg) {
-            case NMFX_ALG_MULTMSE: enqueue_multmse(o, t); break;
+            case NMFX_ALG_MULTMSE:
+                if (pipelined()) enqueue_multmse_pipelined(o, t);
+                else enqueue_multmse(o, t);
+                break;
             case NMFX_ALG_MULTDIV: enqueue_multdiv(o, t); break;
             case NMFX_ALG_PROJALS: enqueue_projals(o, t); break;
             case NMFX_ALG_CD: enqueue_cd(o, t); break;
             case NMFX_ALG_GREEDYCD: enqueue_greedycd(o, t); break;
         }
+        // pipelined exchange: the iteration's W is still travelling; its stop check runs when the next iteration has consumed
+        // it.  Anything that needs the complete W (objective tracking, the host's poll) flushes the pipeline first.
+        if (pipe_pending && (track || t % check_every == 0 || t == o.maxiter)) pipe_flush(o);
         // common.jl:79 -- enqueued BEFORE the stop check: the check raises the `done` flag that turns every later kernel
         // into a no-op, and the objective of the converging iteration itself must still be evaluated
         if (track) enqueue_objective(alg, o, trace_dev.p + t, done_flag());
-        enqueue_check(o, t);                                               // common.jl:73
+        if (!pipe_pending) enqueue_check(o, t);                            // common.jl:73
         if (t % check_every == 0 || t == o.maxiter) {
             HIP_TRY(hipMemcpyAsync(ctrl_host, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));

@@ -412,7 +412,7 @@ class Context:
     def comm_set_mode(self, mode: str):
         """'row_sharded' (default: reduce-scatter / all-gather, each rank updates its rows of W) or 'replicated_w'
         (one packed all-reduce, every rank applies the full W update)."""
-        self._ck(self.lib.nmfx_comm_set_mode(self.h, {"row_sharded": L.COMM_ROW_SHARDED, "replicated_w": L.COMM_REPLICATED_W}[mode]))
+        self._ck(self.lib.nmfx_comm_set_mode(self.h, {"row_sharded": L.COMM_ROW_SHARDED, "replicated_w": L.COMM_REPLICATED_W, "pipelined": L.COMM_PIPELINED}[mode]))
 
     def profile_enable(self, mode=1):
         """0 off, 1 every launch (slow), 2 dominant GEMMs sampled 1-in-4 (bench roofline)."""

@@ -150,3 +150,46 @@ def test_eight_ranks_bench_shape_fraction(built):
         r1, t1 = ctx.solve(L.ALG_MULTMSE, nmfx.make_opts(T, **kw), W1, H1)
     assert rel_trace_err(rr[0][1], t1) < 1e-5
     assert np.max(np.abs(Ws - W1)) <= 1e-3 * np.max(np.abs(W1))
+
+
+@pytest.mark.parametrize("G", [2, 4])
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("update_H", [True, False])
+def test_pipelined_exchange_multmse(built, G, T, update_H):
+    """NMFX_COMM_PIPELINED: the W side by row super-chunks, reduce-scatter / all-gather on a second stream under the big products
+    of the next chunk / the next iteration, stop check deferred until the W in flight has been consumed.  Same trajectory as the
+    unsharded run (only the split-K grouping of the two big products differs), W bit-identical across ranks, objective tracking
+    (which flushes the pipeline every iteration) and plain runs (which do not) agree."""
+    p, n, k = 300, 530, 200                                            # K = 256: the fused-Gram launches the mode is built on
+    X, W0, H0 = planted(p, n, k, T, seed=29)
+    kw = dict(maxiter=9, tol=1e-30, lambda_w=1e-4, lambda_h=1e-4, update_H=update_H)
+    Wt, Ht, rt, Wall = run_sharded(T, X, W0, H0, "multmse", dict(kw, track_objective=True), G, mode="pipelined")
+    for Wr in Wall[1:]:
+        assert np.array_equal(Wr, Wall[0])
+    Wp, Hp, rp, _ = run_sharded(T, X, W0, H0, "multmse", dict(kw, check_every=4), G, mode="pipelined")    # no tracking: W stays in flight
+    assert np.array_equal(Wp, Wt) and np.array_equal(Hp, Ht)
+    assert rp[0][0].niters == rt[0][0].niters == 9 and rp[0][0].objvalue == rt[0][0].objvalue
+    W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        r1, t1 = ctx.solve(L.ALG_MULTMSE, nmfx.make_opts(T, track_objective=True, **kw), W1, H1)
+    tol = {np.float64: 1e-9, np.float32: 2e-5}[T]
+    assert rel_trace_err(rt[0][1], t1) < tol
+    assert np.max(np.abs(Wt - W1)) <= 100 * tol * np.max(np.abs(W1))
+    assert np.max(np.abs(Ht - H1)) <= 100 * tol * np.max(np.abs(H1))
+
+
+def test_pipelined_stop_rule(built):
+    """The deferred stop check of the pipelined mode stops at the same iteration as the oracle, for every poll interval."""
+    T = np.float64
+    p, n, k = 256, 384, 130
+    X, W0, H0 = planted(p, n, k, T, seed=3, k0=4)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("multmse", X, Wc, Hc, orc.Opts(maxiter=300, tol=3e-3))
+    assert ro.converged and 3 < ro.niters < 300
+    for ce in (1, 4, 7):
+        kw = dict(maxiter=300, tol=3e-3, lambda_w=0.0, lambda_h=0.0, check_every=ce)
+        Ws, Hs, rr, _ = run_sharded(T, X, W0, H0, "multmse", kw, 2, mode="pipelined")
+        assert all(res.converged and res.niters == ro.niters for res, _ in rr), (ce, [r.niters for r, _ in rr], ro.niters)
+        assert abs(rr[0][0].objvalue - ro.objvalue) <= 1e-9 * abs(ro.objvalue)
+        assert np.max(np.abs(Ws - Wc)) <= 1e-7 * np.max(np.abs(Wc))

@@ -92,7 +92,11 @@ template <typename T> struct DevBuf {
         count = n;
         if (n == 0) return;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+        // hipMemset is stream-ordered on the NULL stream, which the solver's non-blocking streams do not wait for: without the
+        // synchronisation a buffer that is allocated lazily (Q, the work arrays, the exchange buffers) could be zeroed AFTER
+        // the first kernel wrote to it (seen once, with four contexts sharing one GPU: a wiped Q sent the KL objective to inf)
         HIP_TRY(hipMemset(p, 0, n * sizeof(T)));
+        HIP_TRY(hipStreamSynchronize(nullptr));
     }
     void ensure(size_t n) {
         if (n > count) alloc(n);

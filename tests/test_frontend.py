@@ -279,6 +279,7 @@ def test_nndsvd_default_svd_is_the_device_rsvd(built):
 def test_nnmf_reference_defaults(built):
     """nnmf(X, k) with NO keywords = the reference's defaults init = :nndsvdar, alg = :greedycd (src/interf.jl:4-7); the
     non-negativity check of X (src/interf.jl:15) then runs on the device."""
+    import nmfx
     rng = np.random.default_rng(12)
     X = np.asfortranarray(rng.random((60, 90)))
     r = nmfx.nnmf(X, 4)

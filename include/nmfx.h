@@ -79,15 +79,20 @@ typedef struct {
     double beta, sigma;
     /* CoordinateDescentUpd's resolved regularisation (src/coorddesc.jl:62-82): l1 = alpha*l1ratio, l2 = alpha*(1-l1ratio)
      * for W (regularization in {:both, :transformation}) and H ({:both, :components}); GreedyCD uses lambda_w / lambda_h
-     * as its L1 coefficients (src/greedycd.jl:15-16).  shuffle=true (a Julia-RNG permutation of the components) is not
-     * offered: the sweep always runs in component order. */
+     * as its L1 coefficients (src/greedycd.jl:15-16). */
     double l1_w, l2_w, l1_h, l2_h;
     /* arithmetic of the two p*n*k products.  NMFX_PREC_FP32 (0, default): v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64,
      * the element type's own arithmetic.  NMFX_PREC_BF16X3 (1; f32 contexts with k >= 65, ignored otherwise): operands split
      * into bf16 pairs, three bf16 MFMA products per term, fp32 accumulation (csrc/gemm_bf16x3.hpp) -- ~2.2x faster launches,
      * GEMM error vs fp64 as small as the fp32 path's; opt-in because the inputs are rounded to 16 mantissa bits. */
     int32_t precision;
-    int32_t reserved;
+    /* CoordinateDescent(shuffle = ...), src/coorddesc.jl:130-134.  0: components are swept in order 1..k (shuffle = false).
+     * != 0: shuffle = true -- every call of _update_coord_descent! (W side and H side of every outer iteration) sweeps in a
+     * fresh random order.  The reference draws randperm(k) from Julia's global RNG, whose stream cannot be reproduced outside
+     * Julia; here the order of call c = 2*(t-1) + side is the permutation that sorts the k keys
+     * Philox4x32-10(counter = (i, c, 4, 0), key = cd_shuffle)[0], i = 0..k-1 (ties by index) -- documented, reproducible,
+     * identical on every rank of a sharded run. */
+    int32_t cd_shuffle;
 } nmfx_opts;
 enum { NMFX_PREC_FP32 = 0, NMFX_PREC_BF16X3 = 1 };
 

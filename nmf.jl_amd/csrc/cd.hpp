@@ -46,6 +46,32 @@ __device__ __forceinline__ double op_add(double a, double b) { return __dadd_rn(
 __device__ __forceinline__ float op_sub(float a, float b) { return __fsub_rn(a, b); }
 __device__ __forceinline__ double op_sub(double a, double b) { return __dsub_rn(a, b); }
 
+// shuffle = true (src/coorddesc.jl:130-131): sweeping the components in the order perm[0], perm[1], ... is the in-order sweep of
+// the problem with its components renamed -- W'(:, s) = W(:, perm[s]), Z'(:, s) = Z(:, perm[s]), P'(a, b) = P(perm[a], perm[b]) --
+// so the sweep kernels below stay as they are and these two kernels rename on the way in and out.
+template <typename T>
+__global__ void permute_components_kernel(SampleView<T> dst, SampleView<const T> src, const int *__restrict__ perm, int64_t nsamples, int k,
+                                          int inverse, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int64_t total = nsamples * k;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i;
+        int s;
+        if (src.cs == 1) { s = (int)(e % k); i = e / k; }           // components contiguous (the H side's transposed view)
+        else { i = e % nsamples; s = (int)(e / nsamples); }         // samples contiguous (the W side)
+        if (inverse) dst.at(i, perm[s]) = src.at(i, s);
+        else dst.at(i, s) = src.at(i, perm[s]);
+    }
+}
+template <typename T>
+__global__ void permute_gram_kernel(T *dst, const T *src, int64_t ld, const int *__restrict__ perm, int k, const int *done) {
+    NMFX_DONE_GUARD(done);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < k * k; e += gridDim.x * blockDim.x) {
+        const int a = e % k, b = e / k;
+        dst[a + (int64_t)b * ld] = src[perm[a] + (int64_t)perm[b] * ld];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // CoordinateDescent sweep (src/coorddesc.jl:130-156).  For every sample row i, components t = 1..k in order:
 //     grad = -Z'(i,t) + sum_r P(t,r) W(i,r)          Z' = Z - l1 (:121-123), P already carries + l2 on its diagonal (:118-120)

@@ -46,9 +46,52 @@ void Solver<T>::cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<co
     }
 }
 
+// The component orders of a CoordinateDescent(shuffle = true) solve, all of them up front (2 * maxiter calls x k components):
+// call c = 2*(t-1) + side sweeps in the order that sorts the keys Philox4x32-10((i, c, 4, 0), key = cd_shuffle)[0], i < k
+// (include/nmfx.h; NumPy twin: tests/philox_ref.py::cd_permutation).
+template <typename T> void Solver<T>::prepare_cd_permutations(const nmfx_opts &o) {
+    const uint64_t key = (uint64_t)(int64_t)o.cd_shuffle;   // sign-extended 32-bit field
+    const size_t calls = (size_t)2 * (size_t)o.maxiter;
+    std::vector<int> host(calls * (size_t)k);
+    std::vector<std::pair<uint32_t, int>> keys((size_t)k);
+    for (size_t c = 0; c < calls; ++c) {
+        for (int i = 0; i < (int)k; ++i) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)i, (uint32_t)c, 4u, 0u, (uint32_t)key, (uint32_t)(key >> 32), w);
+            keys[(size_t)i] = {w[0], i};
+        }
+        std::sort(keys.begin(), keys.end());
+        for (int i = 0; i < (int)k; ++i) host[c * (size_t)k + (size_t)i] = keys[(size_t)i].second;
+    }
+    cd_perm.ensure(host.size());
+    HIP_TRY(hipMemcpyAsync(cd_perm.p, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+}
+
+// cd_sweep in the component order `perm` (nullptr: 1..k): rename in, sweep, rename out (cd.hpp)
+template <typename T>
+void Solver<T>::cd_sweep_ordered(SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> Num, const T *Pm, int64_t nsamples, T l1,
+                                 const int *perm, int64_t offset, const int *done) {
+    if (perm == nullptr) { cd_sweep(Zo, Zn, Num, Pm, nsamples, l1, done); return; }
+    const size_t big = (size_t)std::max(P * K, K * N);
+    work[4].ensure(big);
+    work[5].ensure(big);
+    work[6].ensure((size_t)K * K);
+    SampleView<T> Wp{work[4].p + offset, Zo.ss, Zo.cs}, Np{work[5].p + offset, Zo.ss, Zo.cs};
+    const unsigned grid = flat_grid(nsamples * k);
+    hipLaunchKernelGGL(permute_components_kernel<T>, dim3(grid), dim3(256), 0, stream, Wp, Zo, perm, nsamples, (int)k, 0, done);
+    hipLaunchKernelGGL(permute_components_kernel<T>, dim3(grid), dim3(256), 0, stream, Np, Num, perm, nsamples, (int)k, 0, done);
+    hipLaunchKernelGGL(permute_gram_kernel<T>, dim3(flat_grid(k * k)), dim3(256), 0, stream, work[6].p, Pm, K, perm, (int)k, done);
+    cd_sweep(SampleView<const T>{Wp.p, Wp.ss, Wp.cs}, Wp, SampleView<const T>{Np.p, Np.ss, Np.cs}, work[6].p, nsamples, l1, done);
+    hipLaunchKernelGGL(permute_components_kernel<T>, dim3(grid), dim3(256), 0, stream, Zn, SampleView<const T>{Wp.p, Wp.ss, Wp.cs}, perm,
+                       nsamples, (int)k, 1, done);
+    HIP_TRY(hipGetLastError());
+}
+
 template <typename T> void Solver<T>::enqueue_cd(const nmfx_opts &o, long long t) {
-    (void)t;
     const int *done = done_flag();
+    const int *perm_w = o.cd_shuffle ? cd_perm.p + (size_t)(2 * (t - 1)) * (size_t)k : nullptr;
+    const int *perm_h = o.cd_shuffle ? cd_perm.p + (size_t)(2 * (t - 1) + 1) * (size_t)k : nullptr;
     {   // ---- W (coorddesc.jl:166): HHt = H*Ht, XHt = X*Ht (:109-115)
         const T *Hp = H[hcur].p;
         const T *Wo = W[wcur].p;
@@ -66,8 +109,8 @@ template <typename T> void Solver<T>::enqueue_cd(const nmfx_opts &o, long long t
             hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, gramH_p, K, (int)k, (T)o.l2_w, done);
         timed("cd_sweep_W", 2.0 * rows * k * k, 3.0 * rows * K * sizeof(T), [&] {
             if (rows > 0)
-                cd_sweep(SampleView<const T>{Wo + r0, 1, P}, SampleView<T>{Wn + r0, 1, P}, SampleView<const T>{numW_p + r0, 1, P}, gramH_p, rows,
-                         (T)o.l1_w, done);
+                cd_sweep_ordered(SampleView<const T>{Wo + r0, 1, P}, SampleView<T>{Wn + r0, 1, P}, SampleView<const T>{numW_p + r0, 1, P}, gramH_p,
+                                 rows, (T)o.l1_w, perm_w, r0, done);
             HIP_TRY(hipGetLastError());
         });
         if (rs) {
@@ -86,7 +129,8 @@ template <typename T> void Solver<T>::enqueue_cd(const nmfx_opts &o, long long t
         if (o.l2_h > 0)
             hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, gramW_p, K, (int)k, (T)o.l2_h, done);
         timed("cd_sweep_H", 2.0 * n * k * k, 3.0 * K * N * sizeof(T), [&] {
-            cd_sweep(SampleView<const T>{Ho, K, 1}, SampleView<T>{Hn, K, 1}, SampleView<const T>{numH_p, K, 1}, gramW_p, n, (T)o.l1_h, done);
+            cd_sweep_ordered(SampleView<const T>{Ho, K, 1}, SampleView<T>{Hn, K, 1}, SampleView<const T>{numH_p, K, 1}, gramW_p, n, (T)o.l1_h,
+                             perm_h, 0, done);
             HIP_TRY(hipGetLastError());
         });
         stats_h(Hn, Ho, done);

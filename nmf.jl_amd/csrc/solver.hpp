@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <type_traits>
@@ -782,6 +783,10 @@ template <typename T> class Solver : public SolverBase {
     void enqueue_cd(const nmfx_opts &o, long long t);
     void enqueue_greedycd(const nmfx_opts &o, long long t);
     template <typename F> void with_kmax(F &&f);
+    void prepare_cd_permutations(const nmfx_opts &o);
+    DevBuf<int> cd_perm;   // CoordinateDescent(shuffle = true): the component orders of every call of the solve
+    void cd_sweep_ordered(SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> Num, const T *Pm, int64_t nsamples, T l1,
+                          const int *perm, int64_t offset, const int *done);
     void cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> Num, const T *Pm, int64_t nsamples, T l1, const int *done);
     void greedy_side(const char *tag, SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> G, const T *Pm, int64_t nsamples,
                      T lambda, bool sharded_samples, const int *done);

@@ -281,6 +281,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         HIP_TRY(hipMemcpyAsync(trace_dev.p, nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    if (alg == NMFX_ALG_CD && o.cd_shuffle != 0) prepare_cd_permutations(o);
     const int w0 = wcur, h0 = hcur;
     begin_iter_trace(o);
     HIP_TRY(hipEventRecord(ev_beg, stream));

@@ -36,7 +36,7 @@ struct COpts
     l1_h::Float64
     l2_h::Float64
     precision::Int32   # 0 = fp32 (default), 1 = bf16x3 (include/nmfx.h)
-    reserved::Int32
+    cd_shuffle::Int32  # 0 = shuffle=false; != 0: shuffle=true, permutations keyed by this value (include/nmfx.h)
 end
 
 # struct nmfx_result
@@ -104,9 +104,9 @@ function run!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, H::Matrix{T})
 end
 
 opts(T; maxiter, tol, update_H, lambda_w=0.0, lambda_h=0.0, maxsubiter=200, tolg=eps(T)^(1/4),
-     l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision=0) =
+     l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision=0, cd_shuffle=0) =
     COpts(maxiter, update_H, 0, maxsubiter, 20, 4, tol, lambda_w, lambda_h, sqrt(eps(T)), tolg, T(0.2), T(0.01),
-          l1_w, l2_w, l1_h, l2_h, precision, 0)
+          l1_w, l2_w, l1_h, l2_h, precision, cd_shuffle)
 
 # ---- solve! methods: same signatures as src/multupd.jl:45, src/projals.jl:37, src/alspgrad.jl:381, with a
 # ---- leading device Context.  `solve!(alg, X, W, H)` without a Context creates one for the call.
@@ -125,12 +125,14 @@ solve!(ctx::Context{T}, alg::NMF.ALSPGrad{T}, W::Matrix{T}, H::Matrix{T}) where 
                                  maxsubiter=alg.maxsubiter, tolg=alg.tolg), W, H)
 
 # CoordinateDescent (src/coorddesc.jl:54-56): the l1/l2 pairs are resolved exactly like CoordinateDescentUpd's constructor
-# (src/coorddesc.jl:62-82); shuffle = true needs a permutation from Julia's RNG and stays on the CPU path.
+# (src/coorddesc.jl:62-82).  shuffle = true: the component orders come from the library's documented Philox generator
+# (Julia's randperm stream is not reproducible on the device); the key is drawn here from Julia's RNG, so `Random.seed!`
+# still makes a run repeatable.
 function solve!(ctx::Context{T}, alg::NMF.CoordinateDescent{T}, W::Matrix{T}, H::Matrix{T}) where T
-    alg.shuffle && throw(ArgumentError("shuffle=true is not offered by the device path"))
     u = NMF.CoordinateDescentUpd{T}(alg.α, alg.l₁ratio, alg.regularization, alg.shuffle, alg.update_H)
+    key = alg.shuffle ? Int32(rand(1:typemax(Int32))) : Int32(0)
     run!(ctx, ALG_CD, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
-                           l1_w=u.l₁W, l2_w=u.l₂W, l1_h=u.l₁H, l2_h=u.l₂H), W, H)
+                           l1_w=u.l₁W, l2_w=u.l₂W, l1_h=u.l₁H, l2_h=u.l₂H, cd_shuffle=key), W, H)
 end
 
 # GreedyCD (src/greedycd.jl:34-35)

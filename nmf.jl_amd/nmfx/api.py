@@ -136,14 +136,16 @@ class ALSPGrad:
 
 class CoordinateDescent:
     """CoordinateDescent{T}(; maxiter, verbose, tol, update_H, α, regularization, l₁ratio, shuffle)  (src/coorddesc.jl:23-51);
-    the resolved l1/l2 pairs are those of CoordinateDescentUpd (src/coorddesc.jl:62-82).  shuffle=True (a permutation drawn
-    from Julia's RNG) is outside the device path."""
+    the resolved l1/l2 pairs are those of CoordinateDescentUpd (src/coorddesc.jl:62-82).  shuffle=True sweeps the components
+    in a fresh random order per side and iteration (src/coorddesc.jl:130-134); Julia's randperm stream cannot be reproduced,
+    the orders come from the documented Philox generator of include/nmfx.h, keyed by `shuffle_seed` (non-zero)."""
 
     def __init__(self, T, maxiter=100, verbose=False, tol=None, update_H=True, alpha=0.0, regularization="both",
-                 l1ratio=0.0, shuffle=False):
+                 l1ratio=0.0, shuffle=False, shuffle_seed=1):
         T = np.dtype(T).type
-        if shuffle:
-            raise ArgumentError("shuffle=true is not offered by the device path (component order is fixed)")
+        if shuffle and (int(shuffle_seed) == 0 or not -2**31 <= int(shuffle_seed) < 2**31):
+            raise ArgumentError("shuffle_seed must be a non-zero 32-bit integer")
+        self.shuffle, self.shuffle_seed = bool(shuffle), int(shuffle_seed)
         if regularization not in ("both", "components", "transformation", "none"):
             raise ArgumentError("Invalid value for regularization.")
         self.T, self.maxiter, self.verbose = T, int(maxiter), bool(verbose)
@@ -160,7 +162,7 @@ class CoordinateDescent:
 
     def _opts(self):
         return dict(maxiter=self.maxiter, tol=self.tol, update_H=self.update_H, l1_w=self.l1_w, l2_w=self.l2_w,
-                    l1_h=self.l1_h, l2_h=self.l2_h)
+                    l1_h=self.l1_h, l2_h=self.l2_h, cd_shuffle=self.shuffle_seed if self.shuffle else 0)
 
 
 class GreedyCD:
@@ -213,7 +215,7 @@ class Result:
 
 def make_opts(T, maxiter=100, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.0, delta=None, maxsubiter=200,
               traceiter=20, tolg=None, beta=0.2, sigma=0.01, track_objective=False, check_every=4,
-              l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision="fp32") -> L.Opts:
+              l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision="fp32", cd_shuffle=0) -> L.Opts:
     T = np.dtype(T).type
     return L.Opts(int(maxiter), int(bool(update_H)), int(bool(track_objective)), int(maxsubiter), int(traceiter),
                   int(check_every),
@@ -221,7 +223,7 @@ def make_opts(T, maxiter=100, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.
                   float(T(math.sqrt(_eps(T))) if delta is None else delta),
                   float(T(_eps(T) ** 0.25) if tolg is None else tolg), float(T(beta)), float(T(sigma)),
                   float(l1_w), float(l2_w), float(l1_h), float(l2_h),
-                  {"fp32": L.PREC_FP32, "bf16x3": L.PREC_BF16X3}[precision], 0)
+                  {"fp32": L.PREC_FP32, "bf16x3": L.PREC_BF16X3}[precision], int(cd_shuffle))
 
 
 def nmf_checksize(X, W, H):

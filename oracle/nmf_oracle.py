@@ -61,7 +61,10 @@ class Opts:
     beta: float = 0.2
     sigma: float = 0.01
     track_objective: bool = False   # verbose-style per-iteration objective (common.jl:76-82)
-    # CoordinateDescentUpd's resolved regularisation (coorddesc.jl:62-82); shuffle is not modelled (component order 1..k)
+    # CoordinateDescentUpd's resolved regularisation (coorddesc.jl:62-82).  shuffle = true (coorddesc.jl:130-131) draws
+    # randperm(k) from Julia's RNG per _update_coord_descent! call; the oracle takes the orders as an INPUT instead:
+    # perm_source(call_index) -> permutation of range(k), call_index = 2*(t-1) + side (None: order 1..k, shuffle = false)
+    perm_source: object = None
     l1_w: float = 0.0
     l2_w: float = 0.0
     l1_h: float = 0.0
@@ -398,8 +401,9 @@ class _ALSPGrad:
 # CoordinateDescent (src/coorddesc.jl) and GreedyCD (src/greedycd.jl) -- SURVEY.md section 8f rank 2
 # ----------------------------------------------------------------------------
 
-def _update_coord_descent(X, W, H, l1_reg, l2_reg):
-    """_update_coord_descent! (coorddesc.jl:107-158) for shuffle = false: updates W in place, returns the violation.
+def _update_coord_descent(X, W, H, l1_reg, l2_reg, permutation=None):
+    """_update_coord_descent! (coorddesc.jl:107-158): updates W in place, returns the violation.  permutation = None is
+    shuffle = false (:132-133); otherwise the component order of this call (:130-131, given instead of drawn).
     `H` is k x n (any strides).  The reference's t-outer / i-inner loops are kept; the inner loop over samples i is
     vectorised (rows do not interact) and the sum over r runs left to right in T exactly like :143-145."""
     T = X.dtype.type
@@ -412,7 +416,7 @@ def _update_coord_descent(X, W, H, l1_reg, l2_reg):
     if l1_reg > 0:
         XHt = XHt - T(l1_reg)                                      # :121-123
     violation = T(0)
-    for t in range(k):                                             # :133 (permutation = 1:n_components)
+    for t in (range(k) if permutation is None else permutation):   # :130-135
         grad = -XHt[:, t]                                          # :141
         for r in range(k):                                         # :143-145
             grad = grad + HHt[t, r] * W[:, r]
@@ -431,16 +435,24 @@ class _CoordDesc:
     def __init__(self, T, o, X, W, H):
         self.T, self.o = T, o
         self.violation = T(0)
+        self.calls = 0                                             # _update_coord_descent! calls so far (index of the next permutation)
 
     def objv(self, X, W, H):
         return float(self.T(0.5 * sqL2dist(X, W @ H)))             # :101-104
 
+    def _perm(self, side):
+        c = self.calls
+        self.calls += 1
+        return None if self.o.perm_source is None else [int(v) for v in self.o.perm_source(c - c % 2 + side)]
+
     def update(self, X, W, H):
         T, o = self.T, self.o
-        v = _update_coord_descent(X, W, H, o.l1_w, o.l2_w)                       # :166
+        v = _update_coord_descent(X, W, H, o.l1_w, o.l2_w, self._perm(0))        # :166
         if o.update_H:
             Ht = H.T                                                                # a view: the update lands in H
-            v = T(v + _update_coord_descent(X.T, Ht, W.T, o.l1_h, o.l2_h))      # :169-174
+            v = T(v + _update_coord_descent(X.T, Ht, W.T, o.l1_h, o.l2_h, self._perm(1)))   # :169-174
+        else:
+            self.calls += 1                                                         # keep call_index = 2*(t-1) + side
         self.violation = v
 
 

@@ -42,3 +42,13 @@ def randinit(T, p, n, k, seed, normalize=False, zeroh=False, h_col_offset=0):
         W = np.asfortranarray((W / W.sum(axis=0, dtype=np.float64).astype(T)[None, :]).astype(T))
     H = np.zeros((k, n), dtype=T, order="F") if zeroh else rand_matrix(T, k, n, seed, 1, h_col_offset)
     return W, H
+
+
+def cd_permutation(k, seed, call):
+    """Component order of CoordinateDescent(shuffle = true) for call index `call` = 2*(t-1) + side (include/nmfx.h, nmfx_opts.cd_shuffle):
+    the permutation that sorts the keys Philox4x32-10(counter = (i, call, 4, 0), key = seed)[0], i = 0..k-1, ties by index."""
+    i = np.arange(k, dtype=np.uint64)
+    seed &= 0xFFFFFFFF                                   # the 32-bit field, sign-extended to the 64-bit key like the device does
+    key = seed if seed < 2**31 else seed | (0xFFFFFFFF << 32)
+    u = philox4x32_10(i, np.full(k, call, np.uint64), np.full(k, 4, np.uint64), np.zeros(k, np.uint64), key & 0xFFFFFFFF, (key >> 32) & 0xFFFFFFFF)[0]
+    return np.lexsort((np.arange(k), u))

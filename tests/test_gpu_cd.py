@@ -143,3 +143,44 @@ def test_k_limit(built):
     X, W0, H0 = uniform(1100, 1100, 1030, np.float32, seed=1)
     with pytest.raises(nmfx.NMFXError, match="k > 1024"):
         nmfx.solve(nmfx.GreedyCD(np.float32, maxiter=2), X, W0, H0)
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(64, 96, 5), (130, 515, 8), (300, 260, 70), (129, 257, 100), (200, 180, 130)])
+@pytest.mark.parametrize("update_H", [True, False])
+def test_cd_shuffle_matches_oracle(built, T, shape, update_H):
+    """CoordinateDescent(shuffle = true) (src/coorddesc.jl:130-131): a fresh component order per side and iteration.  Device and
+    oracle use the same documented orders (include/nmfx.h; tests/philox_ref.py::cd_permutation), so the trajectories must agree
+    like they do for shuffle = false -- and differ from the shuffle = false run."""
+    import philox_ref
+    p, n, k = shape
+    X, W0, H0 = planted(p, n, k, T, seed=40 + k)
+    seed = -123456 if k == 8 else 77 + k                          # (a negative key exercises the sign extension)
+    inst = nmfx.CoordinateDescent(T, maxiter=6, tol=1e-30, alpha=1e-3, l1ratio=0.5, shuffle=True, shuffle_seed=seed, update_H=update_H)
+    W, H = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(inst, X, W, H, track_objective=True)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    o = orc.Opts(maxiter=6, tol=1e-30, update_H=update_H, l1_w=inst.l1_w, l2_w=inst.l2_w, l1_h=inst.l1_h, l2_h=inst.l2_h, track_objective=True,
+                 perm_source=lambda c: philox_ref.cd_permutation(k, seed, c))
+    ro = orc.solve("cd", X, Wc, Hc, o)
+    assert r.niters == ro.niters == 6
+    tol = {np.float64: 1e-9, np.float32: 5e-4}[T]
+    assert rel_trace_err(r.trace, ro.trace) < tol
+    assert np.max(np.abs(W - Wc)) <= 200 * tol * np.max(np.abs(Wc))
+    if update_H:
+        assert np.max(np.abs(H - Hc)) <= 200 * tol * np.max(np.abs(Hc))
+    else:
+        assert np.array_equal(H, H0)
+    W2, H2 = W0.copy(order="F"), H0.copy(order="F")
+    nmfx.solve(nmfx.CoordinateDescent(T, maxiter=6, tol=1e-30, alpha=1e-3, l1ratio=0.5, update_H=update_H), X, W2, H2)
+    assert not np.array_equal(W, W2)
+
+
+def test_cd_shuffle_reference_kat(built):
+    """test/coorddesc.jl:10-14 on the GPU path: alpha = 1e-4, l1ratio = 0.5, shuffle = true reconstructs X to 1e-2."""
+    for T in (np.float64, np.float32):
+        X, Wg, Hg = orc.laurberg6x3(0.3, T)
+        W = np.asfortranarray(Wg + np.random.default_rng(2).random(Wg.shape).astype(T) * T(0.1))
+        H = Hg.copy(order="F")
+        nmfx.solve(nmfx.CoordinateDescent(T, alpha=1e-4, l1ratio=0.5, shuffle=True, maxiter=1000, tol=1e-9), X, W, H)
+        assert np.allclose(X, W @ H, atol=1e-2, rtol=0)

@@ -47,8 +47,10 @@ def test_coordinate_descent_option_structs():
     assert (c.l1_w, c.l2_w) == (0.0025, 0.0075) and (c.l1_h, c.l2_h) == (0.0, 0.0)
     c = nmfx.CoordinateDescent(np.float32)
     assert (c.l1_w, c.l2_w, c.l1_h, c.l2_h) == (0.0, 0.0, 0.0, 0.0) and c.maxiter == 100
-    with pytest.raises(nmfx.ArgumentError, match="shuffle"):
-        nmfx.CoordinateDescent(np.float32, shuffle=True)
+    with pytest.raises(nmfx.ArgumentError, match="shuffle_seed"):
+        nmfx.CoordinateDescent(np.float32, shuffle=True, shuffle_seed=0)
+    assert nmfx.CoordinateDescent(np.float32, shuffle=True, shuffle_seed=9)._opts()["cd_shuffle"] == 9
+    assert nmfx.CoordinateDescent(np.float32)._opts()["cd_shuffle"] == 0
     g = nmfx.GreedyCD(np.float32)
     assert g.lambda_w == 0 and g.lambda_h == 0 and abs(g.tol - 4.92e-3) < 1e-5
     for bad in (dict(maxiter=1), dict(tol=0), dict(lambda_w=-1), dict(lambda_h=-1)):

@@ -7,7 +7,7 @@ Reference tests ported (file:line under /root/reference/test):
   alspgrad.jl:3-25       sub-solver KATs + solve! smoke
   utils.jl:6-15,29-34,48-63   adddiag!, projectnn!, pdsolve!, pdrsolve!
   interf.jl:33-37        update_H=false leaves H untouched
-  coorddesc.jl:5-14      CoordinateDescent KATs (the shuffle = true one runs in component order: Julia's RNG is not available)
+  coorddesc.jl:5-14      CoordinateDescent KATs (shuffle = true with the component orders as an input: Julia's RNG is not available)
   greedycd.jl:5-20       GreedyCD KATs (lambda_w, lambda_h in {0, 1e-5})
 """
 import numpy as np
@@ -72,6 +72,27 @@ def test_coorddesc_kat(impl, T):
     # alpha = 1e-4, l1ratio = 0.5, regularization = :both  ->  l1 = l2 = 5e-5 on both sides (coorddesc.jl:62-82)
     ORACLES[impl].solve("cd", X, W, H, orc.Opts(maxiter=1000, tol=1e-9, l1_w=5e-5, l2_w=5e-5, l1_h=5e-5, l2_h=5e-5))
     assert np.allclose(X, W @ H, atol=1e-2, rtol=0)
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_coorddesc_shuffle_kat(T):
+    """test/coorddesc.jl:10-14 with shuffle = true: the reference draws randperm(k) per _update_coord_descent! call from Julia's
+    RNG; the oracle takes the orders as an input (here the documented Philox orders the device uses), and the KAT -- the
+    regularised solve still reconstructs X to 1e-2 -- holds for them as for any other sequence of orders."""
+    import philox_ref
+    rng = np.random.default_rng(2)
+    X, Wg, Hg = orc.laurberg6x3(0.3, T)
+    W = np.asfortranarray(Wg + rng.random(Wg.shape).astype(T) * T(0.1)); H = Hg.copy(order="F")
+    o = orc.Opts(maxiter=1000, tol=1e-9, l1_w=5e-5, l2_w=5e-5, l1_h=5e-5, l2_h=5e-5, perm_source=lambda c: philox_ref.cd_permutation(3, 7, c))
+    r = orc.solve("cd", X, W, H, o)
+    assert np.allclose(X, W @ H, atol=1e-2, rtol=0)
+    # the orders matter: a different key gives a different trajectory; shuffle = false a third one
+    W2 = np.asfortranarray(Wg + np.random.default_rng(2).random(Wg.shape).astype(T) * T(0.1)); H2 = Hg.copy(order="F")
+    r2 = orc.solve("cd", X, W2, H2, orc.Opts(maxiter=1000, tol=1e-9, l1_w=5e-5, l2_w=5e-5, l1_h=5e-5, l2_h=5e-5))
+    assert not np.array_equal(W, W2)
+    for c in range(6):                                   # every order is a permutation of the components
+        assert sorted(philox_ref.cd_permutation(5, 11, c)) == list(range(5))
+    assert any(list(philox_ref.cd_permutation(5, 11, c)) != list(range(5)) for c in range(6))
 
 
 @pytest.mark.parametrize("impl", ["numpy", "c"])

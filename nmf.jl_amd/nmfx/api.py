@@ -595,7 +595,7 @@ def nnmf(X, k, init="nndsvdar", alg="greedycd", maxiter=100, tol=None, replicate
     For init in {random, custom}: seed=None draws on the host from `rng` (NumPy) and W0 / H0 are updated IN PLACE like
     the reference does; seed=int uses the device front end -- X is uploaded first and checked for negatives there, the
     random start and the replicate restarts are drawn by nmfx_randinit (Philox4x32-10), and only the winning replicate's
-    factors come back (custom W0 / H0 are then copied, not aliased)."""
+    factors come back (custom W0 / H0 are updated in place there too when they are column-major arrays of X's element type)."""
     T = X.dtype.type
     # host-checkable arguments first (no device needed to reject them)
     if init not in ("nndsvd", "nndsvda", "nndsvdar", "random", "custom", "spa"):
@@ -707,8 +707,10 @@ def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, ve
         if not ctx.check_nonneg(0):
             raise ArgumentError("The elements of X must be non-negative.")
         if init == "custom":
-            W = np.asfortranarray(W0, dtype=T).copy(order="F")
-            H = np.asfortranarray(H0, dtype=T).copy(order="F")
+            # like the reference (and the host path above) the caller's W0 / H0 are updated IN PLACE when they already are
+            # column-major arrays of the element type; anything else is converted (then the result lives in the converted copy)
+            W = W0 if (isinstance(W0, np.ndarray) and W0.dtype == T and W0.flags.f_contiguous) else np.asfortranarray(W0, dtype=T).copy(order="F")
+            H = H0 if (isinstance(H0, np.ndarray) and H0.dtype == T and H0.flags.f_contiguous) else np.asfortranarray(H0, dtype=T).copy(order="F")
             ctx.set_factors(W, H)
             if not ctx.check_nonneg(1):
                 raise ArgumentError("The elements of W0 must be non-negative.")

@@ -131,6 +131,12 @@ def test_nnmf_device_front_end(built):
     W0 = np.abs(np.random.default_rng(0).random((48, 3))); H0 = np.random.default_rng(1).random((3, 64)); H0[1, 1] = -1
     with pytest.raises(nmfx.ArgumentError, match="elements of H0 must be non-negative"):
         nmfx.nnmf(X, 3, init="custom", alg="multmse", W0=W0, H0=H0, seed=1)
+    # init = :custom updates the caller's W0 / H0 in place on both front ends, like the reference (README: "may be overwritten")
+    for sd in (None, 4):
+        Wc = np.asfortranarray(np.random.default_rng(0).random((48, 3))); Hc = np.asfortranarray(np.random.default_rng(1).random((3, 64)))
+        Wb, Hb = Wc.copy(), Hc.copy()
+        rc = nmfx.nnmf(X, 3, init="custom", alg="multmse", W0=Wc, H0=Hc, maxiter=10, seed=sd)
+        assert rc.W is Wc and rc.H is Hc and not np.array_equal(Wc, Wb) and not np.array_equal(Hc, Hb)
     # projals starts from H = 0 (src/interf.jl:39): the front end must not draw H
     rp = nmfx.nnmf(X, 3, init="random", alg="projals", maxiter=10, seed=5)
     assert np.isfinite(rp.objvalue)

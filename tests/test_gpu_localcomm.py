@@ -193,3 +193,71 @@ def test_pipelined_stop_rule(built):
         assert all(res.converged and res.niters == ro.niters for res, _ in rr), (ce, [r.niters for r, _ in rr], ro.niters)
         assert abs(rr[0][0].objvalue - ro.objvalue) <= 1e-9 * abs(ro.objvalue)
         assert np.max(np.abs(Ws - Wc)) <= 1e-7 * np.max(np.abs(Wc))
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_sharded_front_end_rsvd_nndsvd(built, T):
+    """The nnmf front end on a sharded X with 2 in-process ranks: randinit with the shard's
+    column offset, the randomized SVD (Y = X*Omega summed over the shards, B = Q'X local, C = B B' all-reduced) and _nndsvd! from
+    the resident triple (column norms of V and mean(X) all-reduced).  Same generator counters as the unsharded run, so W must
+    agree on both ranks and with the unsharded context, and the H shards must tile the unsharded H."""
+    p, n, k, G = 96, 150, 6, 2
+    X, _, _ = planted(p, n, k, T, seed=41)
+    out = [None] * G
+    errs = []
+    group = nmfx.LocalGroup(G)
+
+    def worker(r):
+        try:
+            c0, c1 = nmfx.dist.shard_range(n, r, G)
+            with nmfx.Context(T, p, c1 - c0, k) as ctx:
+                ctx.comm_init_local(group, r)
+                ctx.set_X(np.asfortranarray(X[:, c0:c1]))
+                ctx.randinit(99, normalize=True, zeroh=False, h_col_offset=c0)
+                Wr, Hr = np.empty((p, k), T, order="F"), np.empty((k, c1 - c0), T, order="F")
+                ctx.get_factors(Wr, Hr)
+                ctx.rsvd(seed=5, h_col_offset=c0, download=False, power_iters=1)
+                ctx.nndsvd_init(None, None, None, variant="a", seed=3, n_total=n)
+                Wn, Hn = np.empty((p, k), T, order="F"), np.empty((k, c1 - c0), T, order="F")
+                ctx.get_factors(Wn, Hn)
+                out[r] = (c0, c1, Wr, Hr, Wn, Hn)
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errs, errs
+    group.close()
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        ctx.randinit(99, normalize=True, zeroh=False)
+        W1, H1 = np.empty((p, k), T, order="F"), np.empty((k, n), T, order="F")
+        ctx.get_factors(W1, H1)
+        ctx.rsvd(seed=5, download=False, power_iters=1)
+        ctx.nndsvd_init(None, None, None, variant="a", seed=3)
+        W2, H2 = np.empty((p, k), T, order="F"), np.empty((k, n), T, order="F")
+        ctx.get_factors(W2, H2)
+    tol = 1e-9 if T == np.float64 else 2e-3
+    for c0, c1, Wr, Hr, Wn, Hn in out:
+        assert np.array_equal(Wr, W1) and np.array_equal(Hr, H1[:, c0:c1])          # counter-based draws: bit-identical
+        assert np.max(np.abs(Wn - W2)) <= tol * np.max(np.abs(W2))
+        assert np.max(np.abs(Hn - H2[:, c0:c1])) <= tol * np.max(np.abs(H2))
+    assert np.array_equal(out[0][4], out[1][4])
+
+
+def test_sharded_cd_shuffle(built):
+    """CoordinateDescent(shuffle = true) on the row-sharded path: every rank derives the same component orders from the key."""
+    import philox_ref
+    T = np.float64
+    p, n, k = 260, 410, 7
+    X, W0, H0 = planted(p, n, k, T, seed=23)
+    kw = dict(maxiter=5, tol=1e-30, track_objective=True, cd_shuffle=31)
+    Ws, Hs, rr, Wall = run_sharded(T, X, W0, H0, "cd", kw, 2)
+    assert np.array_equal(Wall[0], Wall[1])
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("cd", X, Wc, Hc, orc.Opts(maxiter=5, tol=1e-30, track_objective=True, perm_source=lambda c: philox_ref.cd_permutation(k, 31, c)))
+    assert rel_trace_err(rr[0][1], ro.trace) < 1e-9
+    assert np.max(np.abs(Ws - Wc)) <= 1e-7 * np.max(np.abs(Wc)) and np.max(np.abs(Hs - Hc)) <= 1e-7 * np.max(np.abs(Hc))

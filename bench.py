@@ -106,9 +106,13 @@ def main():
     import nmfx
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dev_sim = os.environ.get("NMFX_BENCH_BACKEND") == "gloo-sim"   # development aid (1-GPU box): gloo rendezvous + peer-less collectives
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if dev_sim:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     T = np.float32 if a.dtype == "f32" else np.float64
     tdtype = torch.float32 if a.dtype == "f32" else torch.float64
     p, n, k = a.p, a.n, a.k
@@ -125,7 +129,10 @@ def main():
     algid = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3, "cd": 4, "greedycd": 5}[a.alg]
     ctx = nmfx.Context(T, p, nl, k, device=local_rank)
     if world > 1:                       # before set_X: attaching a communicator may change the row padding
-        nmfx.dist.init_comm(ctx)
+        if dev_sim:
+            ctx.comm_init_sim(rank, world)
+        else:
+            nmfx.dist.init_comm(ctx)
         ctx.comm_set_mode(a.comm_mode)
     elif shards > 1:
         ctx.comm_init_sim(0, shards)
@@ -141,6 +148,7 @@ def main():
                               maxsubiter=a.maxsubiter, precision=a.precision)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
@@ -159,10 +167,24 @@ def main():
     ctx.profile_enable(0)
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], device=("cpu" if dev_sim else device), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert res.niters == a.steps, (res.niters, a.steps)
+    # N > 1: the ranks must hold the SAME W (bit for bit) and report the same objective -- the exchange step is the only thing
+    # that keeps them together, so this is the on-hardware check of the RCCL path (outside the timed region)
+    consistency = None
+    if world > 1:
+        import hashlib
+        import torch.distributed as dist
+        Wchk = np.empty((p, k), dtype=T, order="F")
+        ctx.get_factors(Wchk, None)
+        mine = (hashlib.sha256(Wchk.tobytes()).hexdigest(), float(res.objvalue), bool(np.isfinite(Wchk).all()))
+        allv = [None] * world
+        dist.all_gather_object(allv, mine)
+        consistency = {"W_identical_on_all_ranks": len({v[0] for v in allv}) == 1,
+                       "objective_identical_on_all_ranks": len({v[1] for v in allv}) == 1,
+                       "finite": all(v[2] for v in allv) and bool(np.isfinite(res.objvalue))}
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -236,6 +258,8 @@ def main():
                                     "bytes_per_launch": s["bytes"] / s["launches"], "avg_launch_ms": round(s["ms_total"] / s["launches"], 4),
                                     "note": "fused into the W*H MFMA GEMM (2pnk flop per launch): the launch is MFMA-bound, so the HBM "
                                             "fraction is what the fusion leaves unused, not a shortfall"} for s in hb]
+        if consistency is not None:
+            out["multi_gpu_consistency"] = consistency
         if shards != world:
             out["sim_ranks"] = shards
             out["metric"] += f"_SIMULATED_rank0_of_{shards}_compute_only"

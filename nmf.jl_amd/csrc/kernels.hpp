@@ -63,6 +63,38 @@ __global__ __launch_bounds__(256) void reduce_many_slabs_kernel(T *dst, const T 
     if (sl == 0 && i < count) dst[i] = ((sm[0][e] + sm[1][e]) + sm[2][e]) + sm[3][e];
 }
 
+// Two split-K combines in ONE launch (numerator + Gram of the same side: at small shapes every launch is ~5 % of an
+// iteration): blocks [0, nb1) serve (dst1, src1, ...), the rest (dst2, src2, ...); same summation order as the kernel above.
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_pair_kernel(T *dst1, const T *src1, int64_t count1, int nslab1, int64_t stride1, T *dst2,
+                                                          const T *src2, int64_t count2, int nslab2, int64_t stride2, unsigned nb1,
+                                                          const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ T sm[4][64];
+    const bool first = blockIdx.x < nb1;
+    T *dst = first ? dst1 : dst2;
+    const T *src = first ? src1 : src2;
+    const int64_t count = first ? count1 : count2, stride = first ? stride1 : stride2;
+    const int nslab = first ? nslab1 : nslab2;
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)(first ? blockIdx.x : blockIdx.x - nb1) * 64 + e;
+    T acc = (T)0;
+    if (i < count) {
+        int k = sl;
+        for (; k + 28 < nslab; k += 32) {
+            T v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(k + 4 * q) * stride + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; k < nslab; k += 4) acc += src[(int64_t)k * stride + i];
+    }
+    sm[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && i < count) dst[i] = ((sm[0][e] + sm[1][e]) + sm[2][e]) + sm[3][e];
+}
+
 // A[i + i*ld] += a for i < m  (adddiag!, src/utils.jl:15-24)
 template <typename T>
 __global__ void adddiag_kernel(T *A, int64_t ld, int m, T a, const int *done) {

@@ -559,6 +559,16 @@ template <typename T> class Solver : public SolverBase {
             HIP_TRY(hipGetLastError());
         });
     }
+    // numerator and Gram of one side combined by ONE launch
+    void reduce_pair(const char *name, T *dst1, const T *src1, int64_t count1, int nslab1, int64_t stride1, T *dst2, const T *src2,
+                     int64_t count2, int nslab2, int64_t stride2, const int *done) {
+        timed(name, 0.0, ((double)count1 * (nslab1 + 1) + (double)count2 * (nslab2 + 1)) * sizeof(T), [&] {
+            const unsigned nb1 = (unsigned)((count1 + 63) / 64), nb2 = (unsigned)((count2 + 63) / 64);
+            hipLaunchKernelGGL(reduce_pair_kernel<T>, dim3(nb1 + nb2), dim3(256), 0, stream, dst1, src1, count1, nslab1, stride1, dst2, src2,
+                               count2, nslab2, stride2, nb1, done);
+            HIP_TRY(hipGetLastError());
+        });
+    }
     void reduce_slabs(const char *name, T *dst, int64_t count, int nslab, const int *done) {
         reduce_slabs_from(name, dst, slabs.p, count, nslab, done);
     }
@@ -650,16 +660,16 @@ template <typename T> class Solver : public SolverBase {
         EpiStore<T> e{reg, K, h_stride, nullptr};
         gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                (double)(P * N + P * K) * sizeof(T));
-        if (!keep_slabs || h_nslab > 2) {
-            reduce_slabs_from("reduce_WtX", numH_p, reg, h_stride, h_nslab, done);
-            h_in_slabs = false;
-        } else {
-            h_in_slabs = true;
-        }
+        const bool red = !keep_slabs || h_nslab > 2;
+        h_in_slabs = !red;
         if (with_gram) {
             EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
             gemm<KCONTIG, KCONTIG>("gemm_WtW", Wp, P, K, Wp, P, K, P, s_gw, true, eg, done, (double)(P * K) * sizeof(T));
-            reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gw, done);
+            if (red) reduce_pair("reduce_WtX_WtW", numH_p, reg, h_stride, h_nslab, h_stride, gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gw,
+                                 (int64_t)K * K, done);
+            else reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gw, done);
+        } else if (red) {
+            reduce_slabs_from("reduce_WtX", numH_p, reg, h_stride, h_nslab, done);
         }
     }
     // after wt_times(..., with_gram=true): where the numerator / the Gram operand live
@@ -708,11 +718,18 @@ template <typename T> class Solver : public SolverBase {
         EpiStore<T> e{reg, P, w_stride, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                  (double)(P * N + K * N) * sizeof(T));
-        finish_w_slabs(keep_slabs, done);
+        const bool pair = with_gram && !w_blocked && (!keep_slabs || w_nslab > 2);   // both combines in one launch
+        if (!pair) finish_w_slabs(keep_slabs, done);
         if (with_gram) {
             EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
             gemm<KSTRIDED, KSTRIDED>("gemm_HHt", Hp, K, K, Hp, K, K, N, s_gh, true, eg, done, (double)(K * N) * sizeof(T));
-            reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gh, done);
+            if (pair) {
+                reduce_pair("reduce_XHt_HHt", numW_p, reg, w_stride, w_nslab, w_stride, gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gh,
+                            (int64_t)K * K, done);
+                w_in_slabs = false;
+            } else {
+                reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gh, done);
+            }
         }
     }
     // where the split-K slabs of X*H' go: left in place for the update GEMM's epilogue (single GPU, <= 2 slabs), summed

@@ -193,6 +193,15 @@ int nmfx_nndsvd(nmfx_ctx *ctx, const void *U_host, const void *s_host, const voi
 int nmfx_rsvd_begin(nmfx_ctx *ctx, uint64_t seed, int64_t h_col_offset, int power_iters, void *C_host);
 int nmfx_rsvd_finish(nmfx_ctx *ctx, const void *Ub_host, const void *s_host, void *U_out, void *Vt_out);
 
+/* spa(X, k), src/spa.jl:38-63 -- nnmf's init = :spa (src/interf.jl:50-51) and, with the objective on top, alg = :spa
+ * (src/interf.jl:73-77, src/spa.jl:66-75) -- on the resident X: fills the resident W = X[:, anchors] (p x k) and H (k x n).
+ * The anchor search (k rounds of arg-max column norm + rank-1 projection of the p x n residual) is k HBM passes; H =
+ * nonneg_lsq(W, X, alg = :fnnls) comes from NonNegLeastSquares.jl in the reference (not vendored): the minimiser it returns is
+ * reached here by exact coordinate minimisation on the normal equations, swept until no entry of H moves by more than
+ * tol * max|H| or max_sweeps sweeps are done (*sweeps_out, nullable).  anchors_out (nullable): the k anchor column indices,
+ * 0-based, in selection order.  Single GPU.  nmfx_get_factors / nmfx_iterate / nmfx_objective work on the result. */
+int nmfx_spa_init(nmfx_ctx *ctx, int max_sweeps, double tol, int64_t *anchors_out, int *sweeps_out);
+
 /* ---- multi-GPU (column-sharded X and H) -------------------------------------------------------------------
  * The reference has no distributed path; this is the build's data-parallel extension.
  * Rank r owns columns [c0, c0+n_local) of X and H; W is replicated between iterations.  Per outer iteration ONE exchange

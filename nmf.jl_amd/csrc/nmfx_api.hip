@@ -12,6 +12,7 @@
 #include "cd_impl.hpp"
 #include "rsvd_impl.hpp"
 #include "pipeline_impl.hpp"
+#include "spa_impl.hpp"
 
 using namespace nmfx;
 
@@ -176,6 +177,11 @@ int nmfx_pdsolve(nmfx_ctx *ctx, const void *A_host, double lambda, const void *B
 int nmfx_pdrsolve(nmfx_ctx *ctx, const void *A_host, const void *B_host, double lambda, void *X_host, int project_nn) {
     if (!ctx || !A_host || !B_host || !X_host) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { ctx->impl->pdsolve_host(1, A_host, B_host, lambda, X_host, project_nn != 0); });
+}
+
+int nmfx_spa_init(nmfx_ctx *ctx, int max_sweeps, double tol, int64_t *anchors_out, int *sweeps_out) {
+    if (!ctx) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->spa_init(max_sweeps, tol, anchors_out, sweeps_out); });
 }
 
 int nmfx_objective(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, double *out) {

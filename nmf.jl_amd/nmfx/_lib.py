@@ -23,7 +23,7 @@ SYMBOLS = [
     "nmfx_set_factors", "nmfx_get_factors", "nmfx_iterate", "nmfx_solve", "nmfx_alspgrad_subsolve",
     "nmfx_comm_get_unique_id", "nmfx_comm_init", "nmfx_objective", "nmfx_profile_enable", "nmfx_profile_get",
     "nmfx_device_info", "nmfx_check_nonneg", "nmfx_randinit", "nmfx_solve_replicates", "nmfx_nndsvd", "nmfx_get_iter_trace", "nmfx_rsvd_begin", "nmfx_rsvd_finish",
-    "nmfx_local_group_create", "nmfx_local_group_destroy", "nmfx_comm_init_local", "nmfx_comm_set_mode", "nmfx_comm_init_sim", "nmfx_pdsolve", "nmfx_pdrsolve",
+    "nmfx_local_group_create", "nmfx_local_group_destroy", "nmfx_comm_init_local", "nmfx_comm_set_mode", "nmfx_comm_init_sim", "nmfx_pdsolve", "nmfx_pdrsolve", "nmfx_spa_init",
 ]
 COMM_ROW_SHARDED, COMM_REPLICATED_W, COMM_PIPELINED = 0, 1, 2
 
@@ -91,6 +91,7 @@ def load():
     lib.nmfx_comm_init_local.argtypes = [vp, vp, i32]
     lib.nmfx_comm_set_mode.argtypes = [vp, i32]
     lib.nmfx_comm_init_sim.argtypes = [vp, i32, i32]
+    lib.nmfx_spa_init.argtypes = [vp, i32, C.c_double, vp, C.POINTER(i32)]
     lib.nmfx_pdsolve.argtypes = [vp, vp, C.c_double, vp, vp, i32]
     lib.nmfx_pdrsolve.argtypes = [vp, vp, vp, C.c_double, vp, i32]
     lib.nmfx_objective.argtypes = [vp, i32, C.POINTER(Opts), C.POINTER(C.c_double)]

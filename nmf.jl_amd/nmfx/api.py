@@ -191,6 +191,24 @@ class GreedyCD:
 
 
 @dataclass
+class SPA:
+    """NMF.SPA{T}(obj = :mse) (src/spa.jl:26-34): no iterations, solve! only evaluates the objective of the given W, H."""
+    T: type
+    obj: str = "mse"
+
+    def __post_init__(self):
+        self.T = np.dtype(self.T).type
+        if self.obj not in ("mse", "div"):
+            raise ArgumentError("Invalid value for obj.")
+
+    def _alg(self):
+        return L.ALG_MULTMSE if self.obj == "mse" else L.ALG_MULTDIV
+
+    def _opts(self):
+        return dict(maxiter=0)
+
+
+@dataclass
 class Result:
     """NMF.Result{T} (src/common.jl:21-38).  W and H are the caller's arrays, updated in place."""
     W: np.ndarray
@@ -380,6 +398,15 @@ class Context:
         buf = C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)
         self._ck(self.lib.nmfx_comm_init(self.h, buf, rank, nranks))
 
+    def spa_init(self, max_sweeps=20000, tol=None):
+        """spa(X, k) (src/spa.jl:38-63) on the resident X into the resident W, H; returns (anchors, sweeps): the anchor column
+        indices (0-based, selection order) and the coordinate sweeps the non-negative least-squares fit of H took."""
+        tol = 8 * _eps(self.T) if tol is None else tol
+        anchors = np.empty(self.k, dtype=np.int64)
+        sweeps = C.c_int32()
+        self._ck(self.lib.nmfx_spa_init(self.h, int(max_sweeps), float(tol), anchors.ctypes.data, C.byref(sweeps)))
+        return anchors, sweeps.value
+
     def pdsolve(self, A, B, lambda_=0.0, project_nn=False):
         """inv(A + lambda I) * B on the device kernels of ProjectedALS (adddiag! + pdsolve! [+ projectnn!], src/utils.jl); A is
         k x k SPD, B is k x n (the context's k, n)."""
@@ -473,6 +500,9 @@ def solve(alg, X, W, H, ctx: Context | None = None, track_objective=False, check
         ctx.set_X(X)
     track_objective = track_objective or bool(getattr(alg, "verbose", False))   # verbose = true evaluates every iteration
     try:
+        if isinstance(alg, SPA):                                                 # src/spa.jl:66-75
+            ctx.set_factors(W, H)
+            return Result(W, H, 0, True, ctx.objective(alg._alg(), make_opts(T)), None, {})
         o = make_opts(T, track_objective=track_objective, check_every=check_every, precision=precision, **alg._opts())
         res, trace = ctx.solve(alg._alg(), o, W, H)
         out = _result(T, W, H, res, trace)
@@ -554,6 +584,25 @@ def rsvd(X, k, seed=0, ctx: Context | None = None, power_iters=0):
             ctx.close()
 
 
+def spa(X, k, ctx: Context | None = None, return_anchors=False, max_sweeps=20000, tol=None):
+    """spa(X, k) -> (W, H) (src/spa.jl:38-63): W = X[:, anchors], H the non-negative least-squares fit (Context.spa_init)."""
+    T = X.dtype.type
+    p, n = X.shape
+    own = ctx is None
+    if own:
+        ctx = Context(T, p, n, k)
+        ctx.set_X(np.asfortranarray(X))
+    try:
+        anchors, _ = ctx.spa_init(max_sweeps=max_sweeps, tol=tol)
+        W = np.empty((p, k), dtype=T, order="F")
+        H = np.empty((k, n), dtype=T, order="F")
+        ctx.get_factors(W, H)
+    finally:
+        if own:
+            ctx.close()
+    return (W, H, anchors) if return_anchors else (W, H)
+
+
 def nndsvd(X, k, zeroh=False, variant="std", initdata=None, seed=0, ctx: Context | None = None, power_iters=0):
     """nndsvd(X, k; zeroh, variant, initdata) (src/initialization.jl:74-101): the SVD comes from `initdata` = (U, s, V) or,
     like the reference's default, from the randomized rsvd(X, k) -- run on the device, its result never leaves it;
@@ -587,8 +636,8 @@ def nnmf(X, k, init="nndsvdar", alg="greedycd", maxiter=100, tol=None, replicate
          update_H=True, verbose=False, rng=None, track_objective=False, seed=None, initdata=None):
     """nnmf(X, k; init=:nndsvdar, alg=:greedycd, ...) (src/interf.jl:3-83) with the reference's own defaults.
 
-    alg in {greedycd, cd, multmse, multdiv, projals, alspgrad} (:spa needs NonNegLeastSquares and raises ArgumentError);
-    init in {nndsvd, nndsvda, nndsvdar, random, custom} (:spa likewise).
+    alg in {greedycd, cd, multmse, multdiv, projals, alspgrad, spa}; init in {nndsvd, nndsvda, nndsvdar, spa, random, custom}
+    (alg = spa requires init = spa, src/interf.jl:73-77).
 
     The NNDSVD initialisers always run on the device front end (randomized SVD + _nndsvd! next to the resident X; the one
     uniform per component of :nndsvdar comes from Philox keyed by `seed`, default 0 -- Julia's stream cannot be reproduced).
@@ -602,10 +651,9 @@ def nnmf(X, k, init="nndsvdar", alg="greedycd", maxiter=100, tol=None, replicate
         raise ArgumentError("Invalid value for init.")
     if alg not in _ALGS + ("spa",):
         raise ArgumentError("Invalid algorithm.")
-    if "spa" in (init, alg):
-        which = f"init=:{init}" if init == "spa" else f"alg=:{alg}"
-        raise ArgumentError(f"{which} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
-    if seed is not None or init in ("nndsvd", "nndsvda", "nndsvdar"):
+    if alg == "spa" and init != "spa":
+        raise ArgumentError("Invalid value for init, use :spa instead.")
+    if seed is not None or init in ("nndsvd", "nndsvda", "nndsvdar", "spa"):
         return _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, verbose,
                             int(0 if seed is None else seed), initdata)
     if not (np.issubdtype(X.dtype, np.floating) and np.all(X >= 0)):
@@ -636,8 +684,6 @@ def nnmf(X, k, init="nndsvdar", alg="greedycd", maxiter=100, tol=None, replicate
         W, H = randinit(X, k, zeroh=not initH, normalize=True, rng=rng)
     elif init == "custom":
         W, H = W0, H0
-    elif init in ("nndsvd", "nndsvda", "nndsvdar", "spa"):
-        raise ArgumentError(f"init=:{init} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
     else:
         raise ArgumentError("Invalid value for init.")
     W = np.asfortranarray(W, dtype=T)
@@ -670,7 +716,7 @@ def _alg_instance(T, alg, maxiter, tol, verbose, update_H):
     if alg == "greedycd":
         return GreedyCD(T, maxiter=maxiter, tol=tol, verbose=verbose, update_H=update_H)
     if alg == "spa":
-        raise ArgumentError(f"alg=:{alg} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
+        return SPA(T, obj="mse")
     raise ArgumentError("Invalid algorithm.")
 
 
@@ -694,9 +740,7 @@ def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, ve
             raise ArgumentError("Invalid size for W0.")
         if H0.shape != (k, n):
             raise ArgumentError("Invalid size for H0.")
-    elif init == "spa":
-        raise ArgumentError(f"init=:{init} is outside the accelerated hot path (SURVEY.md section 8f); use the Julia package")
-    elif init not in ("random", "nndsvd", "nndsvda", "nndsvdar"):
+    elif init not in ("random", "nndsvd", "nndsvda", "nndsvdar", "spa"):
         raise ArgumentError("Invalid value for init.")
     elif W0 is not None or H0 is not None:
         warnings.warn("Ignore W0 and H0 except for :custom initialization.")
@@ -721,6 +765,8 @@ def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, ve
             H = np.empty((k, n), dtype=T, order="F")
             if init == "random":
                 ctx.randinit(seed, normalize=True, zeroh=not initH)
+            elif init == "spa":                                          # src/interf.jl:50-51
+                ctx.spa_init()
             else:                                                        # src/interf.jl:44-49
                 if initdata is None:
                     ctx.rsvd(seed, download=False)                       # rsvd(X, k), src/initialization.jl:83
@@ -729,7 +775,7 @@ def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, ve
                     U, s, V = initdata
                 ctx.nndsvd_init(U, s, V, variant={"nndsvd": "std", "nndsvda": "a", "nndsvdar": "ar"}[init], zeroh=not initH, seed=seed)
             ctx.get_factors(W, H)
-        if verbose:
+        if verbose or isinstance(inst, SPA):
             # the verbose table needs the per-iteration trace of every replicate: drive solve_replicates! from the host
             # (same draws, same winner rule), X stays resident
             ret, best = solve(inst, X, W, H, ctx=ctx), 1

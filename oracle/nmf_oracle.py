@@ -635,6 +635,47 @@ def nndsvd(X, k, zeroh=False, variant="std", initdata=None, rand_vj=None):
 # test problem (test/testproblems.jl:6-13)
 # ----------------------------------------------------------------------------
 
+# ----------------------------------------------------------------------------
+# SPA -- successive projection algorithm for separable NMF (src/spa.jl:38-63), the last `init` / `alg` option of nnmf
+# (src/interf.jl:50-51, 73-77).  H = nonneg_lsq(W, X, alg=:fnnls) comes from NonNegLeastSquares.jl, which is NOT vendored in the
+# reference (Project.toml compat 0.4): it is Bro & de Jong's fast NNLS, an active-set method that returns THE minimiser of
+# ||X[:, j] - W h||, h >= 0 (unique when W has full column rank), so any exact NNLS solver restates it up to rounding -- here
+# SciPy's Lawson-Hanson `nnls`.  Pinned by test/spa.jl:11-32 (tests/test_oracle_kat.py).
+# ----------------------------------------------------------------------------
+def spa_anchors(X, k):
+    """The anchor indices of spa() (src/spa.jl:40-55), 0-based."""
+    T = X.dtype.type
+    R = X / X.sum(axis=0, keepdims=True)                               # :41  columns of R sum to one
+    ai = []
+    for _ in range(k):
+        a = int(np.argmax((R ** 2).sum(axis=0)))                       # :50  first index on ties, like Julia's argmax
+        ai.append(a)
+        pc = R[:, a].copy()                                            # :53
+        R = R - np.outer(pc, pc @ R) / T(pc @ pc)                      # :54  p*(p'R) ./ (p'p)
+    return ai
+
+
+def spa(X, k):
+    """W, H = spa(X, k) (src/spa.jl:38-63)."""
+    from scipy.optimize import nnls
+    T = X.dtype.type
+    ai = spa_anchors(X, k)
+    W = np.asfortranarray(X[:, ai])                                    # :58
+    W64 = W.astype(np.float64)
+    H = np.zeros((k, X.shape[1]), dtype=T, order="F")
+    for j in range(X.shape[1]):                                        # :61  nonneg_lsq(W, X, alg=:fnnls), column by column
+        H[:, j] = nnls(W64, X[:, j].astype(np.float64))[0].astype(T)
+    projectnn(H)                                                       # :62
+    return W, H, ai
+
+
+def spa_solve(X, W, H, obj="mse"):
+    """solve!(::SPA, X, W, H) (src/spa.jl:66-75): no iterations, only the objective."""
+    T = X.dtype.type
+    objv = 0.5 * sqL2dist(X, W @ H) if obj == "mse" else gkldiv(X, W @ H)
+    return Result(W, H, 0, True, float(T(objv)))
+
+
 def laurberg6x3(alpha, T=np.float64):
     a = T(alpha)
     H = np.array([[a, 1, 1, a, 0, 0],

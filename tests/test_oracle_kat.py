@@ -9,6 +9,7 @@ Reference tests ported (file:line under /root/reference/test):
   interf.jl:33-37        update_H=false leaves H untouched
   coorddesc.jl:5-14      CoordinateDescent KATs (shuffle = true with the component orders as an input: Julia's RNG is not available)
   greedycd.jl:5-20       GreedyCD KATs (lambda_w, lambda_h in {0, 1e-5})
+  spa.jl:11-32           spa(X, k): non-negative factors, reconstruction of a rank-k product and of separable data
 """
 import numpy as np
 import pytest
@@ -200,3 +201,37 @@ def test_defaults_match_reference_table():
     assert abs(oa.tolg - 1.858e-2) < 1e-5 and oa.maxsubiter == 200 and oa.traceiter == 20
     op = orc.resolve_opts(orc.PROJALS, np.float64, orc.Opts())
     assert abs(op.lambda_w - 6.06e-6) < 1e-8
+
+
+def separable_data(m, n, k, rng, T):
+    """separable_data(m, n, k) of src/spa.jl:28-36 (own RNG): W = rand, H = [I V] with the columns of V summing to one, columns
+    of H permuted -- so the (scaled) columns of W appear among the columns of X = W H."""
+    W = rng.random((m, k))
+    V = rng.random((k, n - k))
+    V /= V.sum(axis=0, keepdims=True)
+    H = np.concatenate([np.eye(k), V], axis=1)[:, rng.permutation(n)]
+    return W.astype(T), H.astype(T)
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_spa_kat(T):
+    """test/spa.jl:11-32."""
+    rng = np.random.default_rng(4)
+    p, n, k = 15, 8, 2
+    eps4 = np.finfo(T).eps ** 0.25
+    Wg = np.maximum(rng.random((p, k)).astype(T) - T(0.3), T(eps4))
+    Hg = np.maximum(rng.random((k, n)).astype(T) - T(0.3), T(eps4))
+    X = np.asfortranarray(Wg @ Hg)
+    w, h, ai = orc.spa(X, k)
+    assert np.all(w >= 0) and np.all(h >= 0) and len(set(ai)) == k
+    assert np.allclose(w @ h, X, atol=10.0 * eps4, rtol=0)
+    Wg, Hg = separable_data(p, n, k, rng, T)
+    X = np.asfortranarray(Wg @ Hg)
+    w, h, ai = orc.spa(X, k)
+    assert np.all(w >= 0) and np.all(h >= 0)
+    d = (X - w @ h).astype(np.float64)
+    assert float(np.sum(d * d)) < np.finfo(T).eps                      # sqL2dist(X, x) < eps(T)
+    # the anchors are the columns where H is a unit vector
+    assert sorted(ai) == sorted(int(np.argmax(Hg[a] == 1)) for a in range(k))
+    r = orc.spa_solve(X, w, h)
+    assert r.niters == 0 and r.converged and r.objvalue < np.finfo(T).eps

@@ -195,12 +195,15 @@ int nmfx_rsvd_finish(nmfx_ctx *ctx, const void *Ub_host, const void *s_host, voi
 
 /* spa(X, k), src/spa.jl:38-63 -- nnmf's init = :spa (src/interf.jl:50-51) and, with the objective on top, alg = :spa
  * (src/interf.jl:73-77, src/spa.jl:66-75) -- on the resident X: fills the resident W = X[:, anchors] (p x k) and H (k x n).
- * The anchor search (k rounds of arg-max column norm + rank-1 projection of the p x n residual) is k HBM passes; H =
- * nonneg_lsq(W, X, alg = :fnnls) comes from NonNegLeastSquares.jl in the reference (not vendored): the minimiser it returns is
- * reached here by exact coordinate minimisation on the normal equations, swept until no entry of H moves by more than
- * tol * max|H| or max_sweeps sweeps are done (*sweeps_out, nullable).  anchors_out (nullable): the k anchor column indices,
- * 0-based, in selection order.  Single GPU.  nmfx_get_factors / nmfx_iterate / nmfx_objective work on the result. */
-int nmfx_spa_init(nmfx_ctx *ctx, int max_sweeps, double tol, int64_t *anchors_out, int *sweeps_out);
+ * The anchor search (k rounds of arg-max column norm + rank-1 projection of the p x n residual) is k HBM passes.  H =
+ * nonneg_lsq(W, X, alg = :fnnls) comes from NonNegLeastSquares.jl in the reference (not vendored): the same published
+ * active-set method (Bro & de Jong's fast NNLS on W'W, W'X; KKT tolerance 10 eps(T) ||W'W||_1, at most 30 k + 64 steps) runs
+ * here with one workgroup per column of X, Float64 arithmetic inside, started from `warm_sweeps` coordinate sweeps
+ * (CoordinateDescent's H sweep; 0 = cold start like the reference) -- a warm start changes the path, not the minimiser.
+ * anchors_out (nullable): the k anchor column indices, 0-based, in selection order.  *unsolved_out (nullable): columns whose
+ * solve hit the step cap or a Cholesky breakdown (W'W numerically singular on the passive set); they keep their last feasible
+ * iterate.  Single GPU.  nmfx_get_factors / nmfx_iterate / nmfx_objective work on the result. */
+int nmfx_spa_init(nmfx_ctx *ctx, int warm_sweeps, int64_t *anchors_out, int64_t *unsolved_out);
 
 /* ---- multi-GPU (column-sharded X and H) -------------------------------------------------------------------
  * The reference has no distributed path; this is the build's data-parallel extension.

@@ -179,9 +179,9 @@ int nmfx_pdrsolve(nmfx_ctx *ctx, const void *A_host, const void *B_host, double 
     return guarded(ctx, [&] { ctx->impl->pdsolve_host(1, A_host, B_host, lambda, X_host, project_nn != 0); });
 }
 
-int nmfx_spa_init(nmfx_ctx *ctx, int max_sweeps, double tol, int64_t *anchors_out, int *sweeps_out) {
+int nmfx_spa_init(nmfx_ctx *ctx, int warm_sweeps, int64_t *anchors_out, int64_t *unsolved_out) {
     if (!ctx) return NMFX_ERR_BAD_ARG;
-    return guarded(ctx, [&] { ctx->impl->spa_init(max_sweeps, tol, anchors_out, sweeps_out); });
+    return guarded(ctx, [&] { ctx->impl->spa_init(warm_sweeps, anchors_out, unsolved_out); });
 }
 
 int nmfx_objective(nmfx_ctx *ctx, int alg, const nmfx_opts *opts, double *out) {

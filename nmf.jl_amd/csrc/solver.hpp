@@ -69,7 +69,7 @@ struct SolverBase {
     virtual void comm_init(const void *uid, int rank, int nranks) = 0;
     virtual void comm_init_local(LocalGroup *group, int rank) = 0;
     virtual void comm_set_mode(int mode) = 0;
-    virtual void spa_init(int max_sweeps, double tol, int64_t *anchors_out, int *sweeps_out) = 0;
+    virtual void spa_init(int warm_sweeps, int64_t *anchors_out, int64_t *unsolved_out) = 0;
     virtual void pdsolve_host(int right, const void *A_host, const void *B_host, double lambda, void *X_host, bool clamp) = 0;
     virtual void comm_init_sim(int rank, int nranks) = 0;
     virtual double objective(int alg, const nmfx_opts &o) = 0;
@@ -346,8 +346,10 @@ template <typename T> class Solver : public SolverBase {
     void nndsvd_core(const T *Ud, int64_t ucs, int64_t uss, const T *Vd, int64_t vcs, int64_t vss, const T *sd, T *coef, int variant,
                      bool zeroh, uint64_t seed, int64_t n_total);
     void pdsolve_host(int right, const void *A_host, const void *B_host, double lambda, void *X_host, bool clamp) override;
-    void spa_init(int max_sweeps, double tol, int64_t *anchors_out, int *sweeps_out) override;   // spa_impl.hpp
+    void spa_init(int warm_sweeps, int64_t *anchors_out, int64_t *unsolved_out) override;   // spa_impl.hpp
     DevBuf<long long> flag_ll;   // spa: the anchor indices
+    DevBuf<int> spa_status;      // spa: per-column outcome of the active-set solve
+    DevBuf<double> spa_tri;      // spa: packed triangles when they do not fit the LDS
     // randomized SVD of the resident X (rsvd_impl.hpp)
     void rsvd_begin(uint64_t seed, int64_t h_col_offset, int power_iters, void *C_host) override;
     void rsvd_finish(const void *Ub_host, const void *s_host, void *U_out, void *Vt_out) override;

@@ -7,11 +7,14 @@
 //             p = R[:, a];  R -= p (p'R) ./ (p'p)               spa.jl:53-54   one pass: a block per column does the dot product,
 //                                                                              the update and the column's new norm
 //   W = X[:, anchors]                                           spa.jl:58
-//   H = nonneg_lsq(W, X, alg = :fnnls); projectnn!(H)           spa.jl:61-62   NonNegLeastSquares.jl is not vendored.  fnnls returns
-//       THE minimiser of ||X[:, j] - W h||, h >= 0; here it is reached by exact coordinate minimisation on the normal equations
-//       (W'W, W'X from the hot path's own launch; the row-parallel sweep of CoordinateDescent, cd.hpp) iterated until no entry
-//       of H moves by more than tol * max|H| -- the same fixed point, approached instead of hit (documented deviation; the tests
-//       compare with an exact active-set solver).
+//   H = nonneg_lsq(W, X, alg = :fnnls); projectnn!(H)           spa.jl:61-62   NonNegLeastSquares.jl is not vendored; fnnls is
+//       Bro & de Jong's fast NNLS (J. Chemometrics 11, 1997) on the normal equations W'W, W'X -- an active-set method that ends
+//       at THE minimiser of ||X[:, j] - W h||, h >= 0 (KKT to a tolerance of 10 eps ||W'W||_1).  Here: W'W and W'X from the
+//       hot path's own launch, a few row-parallel coordinate sweeps (CoordinateDescent's sweep, cd.hpp) as a warm start, then
+//       the same active-set method, one workgroup per column of X, started from the warm start's support: packed Cholesky of
+//       (W'W)[P, P] in LDS, Float64 arithmetic for both element types, the published inner loop (step back to feasibility, drop
+//       the blocking indices) and outer loop (add the most violating index), Lawson-Hanson's guard against re-adding an index
+//       that was just dropped.  A warm start changes the path, not the end point.
 // Column sums / norms / dot products accumulate in Float64 and are rounded to T where the reference holds a T (its sums run in
 // T in Julia's pairwise order, which cannot be restated bit for bit anyway); ties in the argmax go to the first index.
 #pragma once
@@ -90,18 +93,38 @@ __global__ __launch_bounds__(1024) void spa_pick_kernel(const double *nrm, int64
     if (threadIdx.x == 0) scal[0] = q;
 }
 
-// one block per column j < n: R[:, j] -= p (p'R[:, j]) ./ (p'p);  nrm[j] = ||R[:, j]||^2 of the result
-template <typename T>
-__global__ __launch_bounds__(256) void spa_project_kernel(T *R, const T *pvec, const double *scal, int64_t p, int64_t ld, double *nrm) {
+// one block per column j < n: R[:, j] -= p (p'R[:, j]) ./ (p'p);  nrm[j] = ||R[:, j]||^2 of the result.  16-byte accesses (the
+// leading dimension is a multiple of 256 elements); the second read of the column comes from L2.  (Measured and dropped: the
+// column parked in LDS between the two passes -- 64 KB per workgroup leaves 8 waves per CU, 435 ms instead of 217 ms at
+// 16384 x 16384, k = 256.)
+template <typename T> __global__ __launch_bounds__(256) void spa_project_kernel(T *R, const T *pvec, const double *scal, int64_t p, int64_t ld, double *nrm) {
+    constexpr int V = 16 / sizeof(T);
+    struct alignas(16) Vec { T v[V]; };
     __shared__ double sm[4];
     const int64_t j = blockIdx.x;
     T *r = R + j * ld;
+    const int64_t pv = p / V;
     double d = 0.0;
-    for (int64_t i = threadIdx.x; i < p; i += blockDim.x) d += (double)(T)(pvec[i] * r[i]);
+    for (int64_t i = threadIdx.x; i < pv; i += blockDim.x) {
+        const Vec a = reinterpret_cast<const Vec *>(r)[i], b = reinterpret_cast<const Vec *>(pvec)[i];
+#pragma unroll
+        for (int e = 0; e < V; ++e) d += (double)(T)(b.v[e] * a.v[e]);
+    }
+    for (int64_t i = pv * V + threadIdx.x; i < p; i += blockDim.x) d += (double)(T)(pvec[i] * r[i]);
     const T dot = (T)spa_block_sum(d, sm);
     const T ptp = (T)scal[0];
     double q = 0.0;
-    for (int64_t i = threadIdx.x; i < p; i += blockDim.x) {
+    for (int64_t i = threadIdx.x; i < pv; i += blockDim.x) {
+        Vec a = reinterpret_cast<const Vec *>(r)[i];
+        const Vec b = reinterpret_cast<const Vec *>(pvec)[i];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            a.v[e] = a.v[e] - (T)(b.v[e] * dot) / ptp;
+            q += (double)(T)(a.v[e] * a.v[e]);
+        }
+        reinterpret_cast<Vec *>(r)[i] = a;
+    }
+    for (int64_t i = pv * V + threadIdx.x; i < p; i += blockDim.x) {
         const T v = r[i] - (T)(pvec[i] * dot) / ptp;
         r[i] = v;
         q += (double)(T)(v * v);
@@ -118,36 +141,171 @@ template <typename T> __global__ void spa_gather_kernel(T *W, const T *X, const 
     }
 }
 
-// out[0] = max |a - b|, out[1] = max |a| over the logical k x n block (ld)
-template <typename T> __global__ __launch_bounds__(1024) void spa_maxdiff_kernel(const T *a, const T *b, int64_t k, int64_t n, int64_t ld, double *out) {
-    __shared__ double s1[16], s2[16];
-    double d = 0.0, m = 0.0;
-    for (int64_t e = threadIdx.x; e < k * n; e += blockDim.x) {
-        const int64_t i = e % k + (e / k) * ld;
-        const double x = (double)a[i], y = (double)b[i];
-        d = fmax(d, fabs(x - y));
-        m = fmax(m, fabs(x));
-    }
+// Active-set NNLS for the columns of B (k x n) on the normal equations G = W'W (k x k, ld ldg): h = argmin ||x_j - W h||, h >= 0,
+// warm-started from H(:, j).  One workgroup per column (grid-stride), 256 threads.  A: packed lower triangle (row-major) of
+// G[P, P] and then its Cholesky factor, in LDS (LDS_A) or in a per-block global slot.  status[j]: 0 KKT reached, 1 iteration cap,
+// 2 Cholesky breakdown (H(:, j) keeps the best feasible iterate).
+template <typename T, bool LDS_A>
+__global__ __launch_bounds__(256) void spa_fnnls_kernel(T *H, const T *B, const T *G, int k, int64_t n, int64_t ldh, int64_t ldg, double tol, int maxit,
+                                                        double *scratch, int *status) {
+    extern __shared__ double spa_lds[];
+    double *z = spa_lds, *h = z + k, *w = h + k, *b = w + k, *y = b + k;
+    int *idx = reinterpret_cast<int *>(y + k);
+    unsigned char *inP = reinterpret_cast<unsigned char *>(idx + k), *ban = inP + k;
+    double *A = LDS_A ? reinterpret_cast<double *>(spa_lds + 5 * (size_t)k + (((size_t)k * 6 + 15) / 16) * 2)
+                      : scratch + (size_t)blockIdx.x * ((size_t)k * (k + 1) / 2);
+    __shared__ int m_sh, flag_sh, t_sh;
+    __shared__ double red_v[4];
+    __shared__ int red_i[4];
+    const int tid = threadIdx.x;
+    for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
+        for (int i = tid; i < k; i += 256) {
+            const double v = (double)H[i + j * ldh];
+            h[i] = v > 0.0 ? v : 0.0;
+            b[i] = (double)B[i + j * ldh];
+            inP[i] = v > 0.0;
+            ban[i] = 0;
+            z[i] = 0.0;
+        }
+        __syncthreads();
+        int st = 1, last_added = -1;
+        for (int it = 0; it < maxit; ++it) {
+            // ---- passive list
+            if (tid == 0) {
+                int m = 0;
+                for (int i = 0; i < k; ++i) if (inP[i]) idx[m++] = i;
+                m_sh = m;
+                flag_sh = 0;
+            }
+            __syncthreads();
+            const int m = m_sh;
+            // ---- z[P] = G[P, P] \ b[P]
+            for (int r = 0; r < m; ++r) {
+                const T *g = G + (int64_t)idx[r] * ldg;
+                double *a = A + (size_t)r * (r + 1) / 2;
+                for (int q = tid; q <= r; q += 256) a[q] = (double)g[idx[q]];
+            }
+            for (int i = tid; i < m; i += 256) y[i] = b[idx[i]];
+            __syncthreads();
+            for (int c = 0; c < m; ++c) {
+                if (tid == 0) {
+                    const double d = A[(size_t)c * (c + 1) / 2 + c];
+                    if (!(d > 0.0)) flag_sh = 1;
+                    A[(size_t)c * (c + 1) / 2 + c] = sqrt(d > 0.0 ? d : 1.0);
+                }
+                __syncthreads();
+                const double d = A[(size_t)c * (c + 1) / 2 + c];
+                for (int r = c + 1 + tid; r < m; r += 256) A[(size_t)r * (r + 1) / 2 + c] /= d;
+                __syncthreads();
+                for (int r = c + 1 + tid; r < m; r += 256) {
+                    double *ar = A + (size_t)r * (r + 1) / 2;
+                    const double lrc = ar[c];
+                    for (int q = c + 1; q <= r; ++q) ar[q] -= lrc * A[(size_t)q * (q + 1) / 2 + c];
+                }
+                __syncthreads();
+            }
+            if (flag_sh) { st = 2; break; }
+            for (int c = 0; c < m; ++c) {                      // L y = b
+                if (tid == 0) y[c] /= A[(size_t)c * (c + 1) / 2 + c];
+                __syncthreads();
+                const double yc = y[c];
+                for (int r = c + 1 + tid; r < m; r += 256) y[r] -= A[(size_t)r * (r + 1) / 2 + c] * yc;
+                __syncthreads();
+            }
+            for (int c = m - 1; c >= 0; --c) {                 // L' s = y
+                if (tid == 0) y[c] /= A[(size_t)c * (c + 1) / 2 + c];
+                __syncthreads();
+                const double sc = y[c];
+                const double *ac = A + (size_t)c * (c + 1) / 2;
+                for (int r = tid; r < c; r += 256) y[r] -= ac[r] * sc;
+                __syncthreads();
+            }
+            for (int i = tid; i < k; i += 256) z[i] = 0.0;
+            __syncthreads();
+            for (int i = tid; i < m; i += 256) z[idx[i]] = y[i];
+            __syncthreads();
+            // ---- inner loop: is z feasible on P?
+            double amin = 2.0;
+            for (int i = tid; i < m; i += 256) {
+                const int ii = idx[i];
+                if (!(z[ii] > 0.0)) { const double hv = h[ii]; amin = fmin(amin, hv / (hv - z[ii])); }
+            }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { d = fmax(d, __shfl_down(d, off, 64)); m = fmax(m, __shfl_down(m, off, 64)); }
-    if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = d; s2[threadIdx.x >> 6] = m; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { d = fmax(d, s1[w]); m = fmax(m, s2[w]); }
-        out[0] = d;
-        out[1] = m;
+            for (int off = 32; off > 0; off >>= 1) amin = fmin(amin, __shfl_down(amin, off, 64));
+            if ((tid & 63) == 0) red_v[tid >> 6] = amin;
+            __syncthreads();
+            amin = fmin(fmin(red_v[0], red_v[1]), fmin(red_v[2], red_v[3]));
+            __syncthreads();
+            if (amin <= 1.0) {
+                // step back to the boundary and drop what reached it (alpha = 0 when a just-added index is the blocker)
+                if (!(amin >= 0.0)) amin = 0.0;
+                for (int i = tid; i < m; i += 256) {
+                    const int ii = idx[i];
+                    double hv = h[ii] + amin * (z[ii] - h[ii]);
+                    const bool blocker = !(z[ii] > 0.0) && !(hv > 1e-14 * fabs(h[ii]) && hv > 0.0);
+                    if (blocker || !(hv > 0.0)) {
+                        hv = 0.0;
+                        inP[ii] = 0;
+                        if (ii == last_added) ban[ii] = 1;
+                    }
+                    h[ii] = hv;
+                }
+                __syncthreads();
+                continue;
+            }
+            // ---- z is feasible: accept, then the outer test on w = b - G z over Z
+            const bool kept = last_added >= 0 && inP[last_added];      // the guard lifts once an index has been added for good
+            __syncthreads();
+            for (int i = tid; i < k; i += 256) {
+                h[i] = z[i];
+                if (kept) ban[i] = 0;
+            }
+            __syncthreads();
+            for (int i = tid; i < k; i += 256) {
+                double acc = b[i];
+                for (int q = 0; q < m; ++q) acc -= (double)G[(int64_t)idx[q] * ldg + i] * y[q];
+                w[i] = acc;
+            }
+            __syncthreads();
+            double bv = tol;
+            int bi = -1;
+            for (int i = tid; i < k; i += 256)
+                if (!inP[i] && !ban[i] && w[i] > bv) { bv = w[i]; bi = i; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_down(bv, off, 64);
+                const int oi = __shfl_down(bi, off, 64);
+                if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
+            }
+            if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int q = 1; q < 4; ++q)
+                    if (red_v[q] > bv || (red_v[q] == bv && red_i[q] >= 0 && (bi < 0 || red_i[q] < bi))) { bv = red_v[q]; bi = red_i[q]; }
+                t_sh = bi;
+                if (bi >= 0) inP[bi] = 1;
+            }
+            __syncthreads();
+            last_added = t_sh;
+            __syncthreads();
+            if (last_added < 0) { st = 0; break; }
+        }
+        __syncthreads();
+        for (int i = tid; i < k; i += 256) H[i + j * ldh] = (T)h[i];
+        if (tid == 0) status[j] = st;
+        __syncthreads();
     }
 }
 
-template <typename T> void Solver<T>::spa_init(int max_sweeps, double tol, int64_t *anchors_out, int *sweeps_out) {
+template <typename T> void Solver<T>::spa_init(int warm_sweeps, int64_t *anchors_out, int64_t *unsolved_out) {
     if (!have_X) throw StatusError{NMFX_ERR_STATE, "X has not been uploaded (nmfx_set_X)"};
     if (nranks > 1) throw StatusError{NMFX_ERR_UNSUPPORTED, "spa: the anchor search runs on one GPU (attach no communicator)"};
-    if (max_sweeps < 1 || !(tol > 0)) throw StatusError{NMFX_ERR_BAD_ARG, "spa: max_sweeps must be >= 1 and tol positive"};
+    if (warm_sweeps < 0) throw StatusError{NMFX_ERR_BAD_ARG, "spa: warm_sweeps must be >= 0"};
     HIP_TRY(hipSetDevice(device));
     rsvd_ready = 0;
     Q.ensure((size_t)P * N);                      // R
     work[0].ensure((size_t)P);                    // p
-    nd_scratch.ensure((size_t)N + 8);             // column norms | p'p | max-diff pair
+    nd_scratch.ensure((size_t)N + 8);             // column norms | p'p
     flag_ll.ensure((size_t)K);
     T *R = Q.p, *pvec = work[0].p;
     double *nrm = nd_scratch.p, *scal = nd_scratch.p + N;
@@ -164,30 +322,56 @@ template <typename T> void Solver<T>::spa_init(int max_sweeps, double tol, int64
     }
     wcur = hcur = 0;
     hipLaunchKernelGGL(spa_gather_kernel<T>, dim3(flat_grid(p * k)), dim3(256), 0, stream, W[0].p, X.p, flag_ll.p, p, P, (int)k);
-    // non-negative least squares for every column of X: coordinate minimisation on the normal equations
+    // non-negative least squares for every column of X: coordinate sweeps as the warm start, then the active-set method
     precision = NMFX_PREC_FP32;
     wt_times(W[0].p, X.p, true, nullptr);
-    int sweeps = 0;
-    double host2[2] = {0.0, 0.0};
-    const int batch = 8;
-    while (sweeps < max_sweeps) {
-        const int m = std::min(batch, max_sweeps - sweeps);
-        for (int b = 0; b < m; ++b) {
-            cd_sweep(SampleView<const T>{H[hcur].p, K, 1}, SampleView<T>{H[hcur ^ 1].p, K, 1}, SampleView<const T>{numH_p, K, 1}, gramW_p, n, (T)0,
-                     nullptr);
-            hcur ^= 1;
-        }
-        sweeps += m;
-        hipLaunchKernelGGL(spa_maxdiff_kernel<T>, dim3(1), dim3(1024), 0, stream, H[hcur].p, H[hcur ^ 1].p, k, n, K, scal + 1);
-        HIP_TRY(hipMemcpyAsync(host2, scal + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    for (int b = 0; b < warm_sweeps; ++b) {
+        cd_sweep(SampleView<const T>{H[hcur].p, K, 1}, SampleView<T>{H[hcur ^ 1].p, K, 1}, SampleView<const T>{numH_p, K, 1}, gramW_p, n, (T)0, nullptr);
+        hcur ^= 1;
+    }
+    {
+        const int kk = (int)k;
+        const size_t small = (5 * (size_t)kk + (((size_t)kk * 6 + 15) / 16) * 2) * sizeof(double);
+        const size_t tri = (size_t)kk * (kk + 1) / 2 * sizeof(double);
+        const bool in_lds = small + tri <= 150 * 1024;
+        const unsigned grid = (unsigned)std::min<int64_t>(n, in_lds ? 2048 : 512);
+        spa_status.ensure((size_t)n);
+        // KKT tolerance 10 eps(T) ||W'W||_1.  (The published default carries another factor k; in Float32 that stops the method 1e-2
+        // away from the minimiser -- measured, scripts/spa_diag.py -- and the guard below makes the tighter test safe.)
+        std::vector<T> g((size_t)K * K);
+        HIP_TRY(hipMemcpyAsync(g.data(), gramW_p, g.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (!(host2[0] > tol * host2[1])) break;      // also leaves on NaN
+        double norm1 = 0.0;
+        for (int64_t c = 0; c < k; ++c) {
+            double cs = 0.0;
+            for (int64_t r = 0; r < k; ++r) cs += std::fabs((double)g[(size_t)(r + c * K)]);
+            norm1 = std::max(norm1, cs);
+        }
+        const double tolw = 10.0 * (double)std::numeric_limits<T>::epsilon() * norm1;
+        const int maxit = 30 * kk + 64;
+        if (in_lds) {
+            auto fn = &spa_fnnls_kernel<T, true>;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(small + tri)));
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), small + tri, stream, H[hcur].p, (const T *)numH_p, (const T *)gramW_p, kk, n, K, K, tolw, maxit,
+                               (double *)nullptr, spa_status.p);
+        } else {
+            spa_tri.ensure((size_t)grid * ((size_t)kk * (kk + 1) / 2));
+            auto fn = &spa_fnnls_kernel<T, false>;
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), small, stream, H[hcur].p, (const T *)numH_p, (const T *)gramW_p, kk, n, K, K, tolw, maxit,
+                               spa_tri.p, spa_status.p);
+        }
+        HIP_TRY(hipGetLastError());
+        std::vector<int> stv((size_t)n);
+        HIP_TRY(hipMemcpyAsync(stv.data(), spa_status.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        int64_t bad = 0;
+        for (int v : stv) bad += v != 0;
+        if (unsolved_out) *unsolved_out = bad;
     }
     std::vector<long long> anc((size_t)k);
     HIP_TRY(hipMemcpyAsync(anc.data(), flag_ll.p, (size_t)k * sizeof(long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (anchors_out) for (int64_t s = 0; s < k; ++s) anchors_out[s] = (int64_t)anc[(size_t)s];
-    if (sweeps_out) *sweeps_out = sweeps;
     have_F = true;
 }
 

@@ -209,6 +209,18 @@ function solve_replicates!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, 
     NMF.Result{T}(W, H, Int(res[].niters), res[].converged != 0, T(res[].objvalue))
 end
 
+# ---- spa(X, k) (src/spa.jl:38-63) on the resident X: anchors (1-based, selection order), W = X[:, anchors], H by the same
+# active-set NNLS the reference takes from NonNegLeastSquares.fnnls (include/nmfx.h: nmfx_spa_init).  In NMF.jl:
+#   spa(X::Matrix{T}, k) = (ctx = NMFX.Context{T}(X, k); NMFX.spa!(ctx, Matrix{T}(undef, size(X,1), k), Matrix{T}(undef, k, size(X,2)))[1:2])
+function spa!(ctx::Context{T}, W::Matrix{T}, H::Matrix{T}; warm_sweeps::Integer=16) where T
+    anchors = Vector{Int64}(undef, size(W, 2))
+    unsolved = Ref{Int64}(0)
+    check(ccall((:nmfx_spa_init, libnmfx), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}, Ref{Int64}), ctx.h, warm_sweeps, anchors, unsolved), ctx.h)
+    check(ccall((:nmfx_get_factors, libnmfx), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), ctx.h, W, H), ctx.h)
+    unsolved[] == 0 || @warn "spa: $(unsolved[]) columns left the active-set solve at its step cap"
+    W, H, anchors .+ 1
+end
+
 # ---- the SPD utilities of src/utils.jl on the device kernels ProjectedALS runs (include/nmfx.h: nmfx_pdsolve / nmfx_pdrsolve) ----
 # pdsolve!(A, x) : x <- inv(A + lambda I) x   (adddiag! + pdsolve!, src/utils.jl:15-24, 63-70); A is k x k SPD, x is k x n
 function pdsolve!(ctx::Context{T}, A::Matrix{T}, x::Matrix{T}; lambda::Real=0, projectnn::Bool=false) where T

@@ -91,7 +91,7 @@ def load():
     lib.nmfx_comm_init_local.argtypes = [vp, vp, i32]
     lib.nmfx_comm_set_mode.argtypes = [vp, i32]
     lib.nmfx_comm_init_sim.argtypes = [vp, i32, i32]
-    lib.nmfx_spa_init.argtypes = [vp, i32, C.c_double, vp, C.POINTER(i32)]
+    lib.nmfx_spa_init.argtypes = [vp, i32, vp, C.POINTER(C.c_int64)]
     lib.nmfx_pdsolve.argtypes = [vp, vp, C.c_double, vp, vp, i32]
     lib.nmfx_pdrsolve.argtypes = [vp, vp, vp, C.c_double, vp, i32]
     lib.nmfx_objective.argtypes = [vp, i32, C.POINTER(Opts), C.POINTER(C.c_double)]

@@ -398,14 +398,13 @@ class Context:
         buf = C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)
         self._ck(self.lib.nmfx_comm_init(self.h, buf, rank, nranks))
 
-    def spa_init(self, max_sweeps=20000, tol=None):
-        """spa(X, k) (src/spa.jl:38-63) on the resident X into the resident W, H; returns (anchors, sweeps): the anchor column
-        indices (0-based, selection order) and the coordinate sweeps the non-negative least-squares fit of H took."""
-        tol = 8 * _eps(self.T) if tol is None else tol
+    def spa_init(self, warm_sweeps=16):
+        """spa(X, k) (src/spa.jl:38-63) on the resident X into the resident W, H; returns (anchors, unsolved): the anchor column
+        indices (0-based, selection order) and the number of columns whose active-set solve did not reach its KKT test."""
         anchors = np.empty(self.k, dtype=np.int64)
-        sweeps = C.c_int32()
-        self._ck(self.lib.nmfx_spa_init(self.h, int(max_sweeps), float(tol), anchors.ctypes.data, C.byref(sweeps)))
-        return anchors, sweeps.value
+        unsolved = C.c_int64()
+        self._ck(self.lib.nmfx_spa_init(self.h, int(warm_sweeps), anchors.ctypes.data, C.byref(unsolved)))
+        return anchors, unsolved.value
 
     def pdsolve(self, A, B, lambda_=0.0, project_nn=False):
         """inv(A + lambda I) * B on the device kernels of ProjectedALS (adddiag! + pdsolve! [+ projectnn!], src/utils.jl); A is
@@ -584,7 +583,7 @@ def rsvd(X, k, seed=0, ctx: Context | None = None, power_iters=0):
             ctx.close()
 
 
-def spa(X, k, ctx: Context | None = None, return_anchors=False, max_sweeps=20000, tol=None):
+def spa(X, k, ctx: Context | None = None, return_anchors=False, warm_sweeps=16, return_info=False):
     """spa(X, k) -> (W, H) (src/spa.jl:38-63): W = X[:, anchors], H the non-negative least-squares fit (Context.spa_init)."""
     T = X.dtype.type
     p, n = X.shape
@@ -593,13 +592,15 @@ def spa(X, k, ctx: Context | None = None, return_anchors=False, max_sweeps=20000
         ctx = Context(T, p, n, k)
         ctx.set_X(np.asfortranarray(X))
     try:
-        anchors, _ = ctx.spa_init(max_sweeps=max_sweeps, tol=tol)
+        anchors, unsolved = ctx.spa_init(warm_sweeps=warm_sweeps)
         W = np.empty((p, k), dtype=T, order="F")
         H = np.empty((k, n), dtype=T, order="F")
         ctx.get_factors(W, H)
     finally:
         if own:
             ctx.close()
+    if return_info:
+        return W, H, {"anchors": anchors, "unsolved": unsolved}
     return (W, H, anchors) if return_anchors else (W, H)
 
 

@@ -1,10 +1,13 @@
 """GPU parity: spa(X, k) / nnmf(init = :spa) / nnmf(alg = :spa) through the C ABI (src/spa.jl, src/interf.jl:50-51, 73-77).
 
 Stated tolerances.  Anchors: identical indices to the oracle's (the inputs keep the arg-max margins far above rounding).
-W = X[:, anchors]: bit-exact.  H: the reference takes the exact NNLS minimiser from NonNegLeastSquares.fnnls; the device reaches
-the same minimiser by coordinate minimisation until no entry moves by more than 8 eps(T) max|H|: compared with the oracle's
-active-set solution to 2e-5 (f64) / 2e-2 (f32) of max|H| entrywise -- H inherits cond(W'W), up to 1e5 on these inputs -- and
-through the residual ||X - WH||, which is what NNLS minimises, to 1e-9 (f64) / 1e-4 (f32) relative."""
+W = X[:, anchors]: bit-exact.  H: the reference takes the NNLS minimiser from NonNegLeastSquares.fnnls; the device runs the same
+active-set method (warm-started), the oracle uses SciPy's Lawson-Hanson solver on W, x directly: same minimiser, different
+arithmetic (normal equations vs QR).  Entrywise: 2e-6 (f64) / 5e-3 (f32) of max|H| -- H inherits cond(W'W) eps(T), cond up to
+4.5e7 for the square-W shape, where Float32 normal equations carry no digits and only the residual is compared.  Residual
+||X - WH||, which is what NNLS minimises: within 1e-9 (f64) / 1e-3 (f32) of ||X|| of the oracle's -- normal equations formed in T
+resolve the residual to sqrt(eps(T)) ||X|| (3.4e-4 in f32; measured 1.7e-4, scripts/spa_diag.py), for the reference's fnnls too,
+which receives W'W and W'X in T."""
 import numpy as np
 import pytest
 
@@ -13,8 +16,8 @@ import nmfx
 from test_oracle_kat import separable_data
 
 pytestmark = pytest.mark.gpu
-HTOL = {np.float64: 2e-5, np.float32: 2e-2}
-RTOL = {np.float64: 1e-9, np.float32: 1e-4}
+HTOL = {np.float64: 2e-6, np.float32: 5e-3}
+RTOL = {np.float64: 1e-9, np.float32: 1e-3}
 
 
 @pytest.mark.parametrize("T", [np.float64, np.float32])
@@ -57,12 +60,15 @@ def near_separable(p, n, k, T, seed, noise=0.0):
 def test_spa_vs_oracle(built, T, shape, noise):
     p, n, k = shape
     X = near_separable(p, n, k, T, seed=p + k, noise=noise)
-    W, H, anchors = nmfx.spa(X, k, return_anchors=True)
+    W, H, info = nmfx.spa(X, k, return_info=True)
+    anchors = info["anchors"]
     Wo, Ho, ao = orc.spa(X, k)
     assert anchors.tolist() == list(ao)
+    assert info["unsolved"] == 0
     assert np.array_equal(W, Wo)
     assert np.all(H >= 0)
-    assert np.max(np.abs(H - Ho)) <= HTOL[T] * np.max(np.abs(Ho))
+    if not (T == np.float32 and p == k):
+        assert np.max(np.abs(H - Ho)) <= HTOL[T] * np.max(np.abs(Ho))
     rg, ro = np.linalg.norm(X - W @ H), np.linalg.norm(X - Wo @ Ho)
     assert rg <= ro + RTOL[T] * np.linalg.norm(X)
 
@@ -77,6 +83,27 @@ def test_nnmf_spa_init(built, alg):
     ro = orc.solve(alg, X, W0.copy(order="F"), H0.copy(order="F"), orc.Opts(maxiter=30, tol=1e-30))
     assert r.niters == ro.niters == 30
     assert abs(r.objvalue - ro.objvalue) <= 1e-6 * abs(ro.objvalue)
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_spa_cold_start_equals_warm_start(built, T):
+    """warm_sweeps = 0 is the published method from h = 0; the warm start must end at the same minimiser."""
+    X = near_separable(90, 300, 12, T, seed=5, noise=0.05)
+    Wc, Hc, ic = nmfx.spa(X, 12, warm_sweeps=0, return_info=True)
+    Ww, Hw, iw = nmfx.spa(X, 12, warm_sweeps=16, return_info=True)
+    assert ic["unsolved"] == iw["unsolved"] == 0 and np.array_equal(Wc, Ww)
+    assert np.max(np.abs(Hc - Hw)) <= {np.float64: 1e-10, np.float32: 5e-3}[T] * np.max(np.abs(Hc))
+
+
+def test_spa_large_k_uses_the_global_triangle(built):
+    """k = 256 in Float64: the packed triangle (263 KB) does not fit the LDS and lives in the per-block global slot."""
+    T = np.float64
+    p, n, k = 320, 700, 256
+    X = near_separable(p, n, k, T, seed=2, noise=0.01)
+    W, H, info = nmfx.spa(X, k, return_info=True)
+    Wo, Ho, ao = orc.spa(X, k)
+    assert info["anchors"].tolist() == list(ao) and info["unsolved"] == 0
+    assert np.linalg.norm(X - W @ H) <= np.linalg.norm(X - Wo @ Ho) + 1e-9 * np.linalg.norm(X)
 
 
 def test_nnmf_alg_spa(built):
@@ -101,7 +128,9 @@ def test_spa_headline_shape_properties(built):
     T = np.float32
     p, n, k = 1024, 4096, 32
     X = near_separable(p, n, k, T, seed=1)
-    W, H, anchors = nmfx.spa(X, k, return_anchors=True)
+    W, H, info = nmfx.spa(X, k, return_info=True)
+    anchors = info["anchors"]
+    assert info["unsolved"] == 0
     assert len(set(anchors.tolist())) == k and np.array_equal(W, X[:, anchors])
     assert np.all(H >= 0)
-    assert np.linalg.norm(X - W @ H) <= 1e-4 * np.linalg.norm(X)
+    assert np.linalg.norm(X - W @ H) <= 1e-3 * np.linalg.norm(X)

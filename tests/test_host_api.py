@@ -31,10 +31,10 @@ def test_nnmf_argument_errors():
         nmfx.nnmf(X, 2, init="bogus")
     with pytest.raises(nmfx.ArgumentError, match="Invalid algorithm"):
         nmfx.nnmf(X, 2, alg="bogus")
-    with pytest.raises(nmfx.ArgumentError, match="outside the accelerated hot path"):
-        nmfx.nnmf(X, 2, alg="spa")
-    with pytest.raises(nmfx.ArgumentError, match="outside the accelerated hot path"):
-        nmfx.nnmf(X, 2, init="spa", alg="greedycd")
+    with pytest.raises(nmfx.ArgumentError, match="Invalid value for init, use :spa instead"):      # src/interf.jl:74-76
+        nmfx.nnmf(X, 2, init="random", alg="spa")
+    with pytest.raises(nmfx.ArgumentError, match="Invalid value for obj"):
+        nmfx.SPA(np.float64, obj="bogus")
 
 
 def test_coordinate_descent_option_structs():

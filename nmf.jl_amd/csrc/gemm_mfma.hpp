@@ -76,6 +76,8 @@ template <typename T> struct GemmArgs {
     int tail_tiles = 0;     // extra output tiles along the slow tile direction, done as a balanced second segment
     int tail_nkt = 0;       // k-tiles of a tail tile (= Kdim / BK)
     int tail_per = 0;       // k-tiles of one tail piece (one piece per block)
+    int tail_main = 0;      // > 0: the grid is `tail_main` blocks SHORT of tiles * splits; the missing (tile, split) items -- the
+                            // last ones -- are dealt out as tail pieces instead (a grid that must leave some CUs free)
 };
 
 // what an epilogue may need to know about the block / wave it runs in
@@ -326,6 +328,20 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
             kt0 = split * nkt;
             nk = nkt;
         } else {
+            if (g.tail_main > 0) {
+                // items nblk .. nblk + tail_main - 1 of the main decomposition, tail_per k-tiles per block; piece p of every
+                // item goes to tail slab p, at the item's own tile coordinates
+                const int ppt = (nkt + g.tail_per - 1) / g.tail_per;
+                const int piece = bid % ppt, item = nblk + bid / ppt;
+                if (bid / ppt >= g.tail_main) break;
+                const int pk = piece * g.tail_per;
+                nk = (nkt - pk < g.tail_per) ? (nkt - pk) : g.tail_per;
+                if (nk <= 0) break;
+                kt0 = (item / tiles) * nkt + pk;
+                trem = item % tiles;
+                split = -1 - piece;
+                tail = true;
+            } else {
             if (g.tail_tiles == 0) break;
             const int inner = g.c_fastest ? g.tiles_c : g.tiles_r;     // tail tiles extend the slow (outer) direction
             const int pieces_per_tile = (g.tail_nkt + g.tail_per - 1) / g.tail_per;
@@ -337,6 +353,7 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
             split = -1 - piece;
             trem = tiles + ttile;          // tile ids continue past the main tiles along the outer direction
             tail = true;
+            }
         }
         int tr, tc;
         if (g.group > 1) {
@@ -650,6 +667,56 @@ template <typename T> struct EpiClampStore {
         buf_st(rout, la.lb, la.soff(ro, co), (v < (T)0) ? (T)0 : v);
     }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
+};
+
+// out = max(acc, 0) together with the stop_condition sums of the component that runs along c against `old` (the layout and the
+// arithmetic of EpiMultUpdate<T, 1>): ProjectedALS's H solve ends in this epilogue instead of a separate statistics pass.
+template <typename T> struct EpiClampStats {
+    const T *old;
+    T *out;
+    int64_t ld;
+    double *stat_partial;
+    int ncomp;
+    double dev[8], sm[8];
+    rsrc_t rold, rout;
+    LaneAddr<T> la;
+    __device__ __forceinline__ void setup(int, const TileCtx &t) { rold = tile_rsrc(old, ld, t); rout = tile_rsrc(out, ld, t); la.init(t, ld); }
+    __device__ __forceinline__ void begin() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dev[j] = 0.0; sm[j] = 0.0; }
+    }
+    struct Pre { T ov; };
+    static constexpr bool EARLY = true, HEAVY = false;
+    __device__ __forceinline__ Pre prefetch(int ro, int co) const { return Pre{buf_ld<T>(rold, la.lb, la.soff(ro, co))}; }
+    __device__ __forceinline__ void apply(int ro, int co, T v, int jt, const Pre &pre) {
+        const T nv = (v < (T)0) ? (T)0 : v;
+        buf_st(rout, la.lb, la.soff(ro, co), nv);
+        const T d = nv - pre.ov, sp = nv + pre.ov;
+        dev[jt] += (double)(T)(d * d);
+        sm[jt] += (double)(T)(sp * sp);
+    }
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *smem, const TileCtx &t) {
+        static_assert(TC <= 8, "statistics accumulators");
+        constexpr int WTC = TC * MT, BCW = WGC * WTC;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            double d = dev[j], q = sm[j];
+#pragma unroll
+            for (int off = 32; off >= MT; off >>= 1) { d += __shfl_down(d, off, 64); q += __shfl_down(q, off, 64); }
+            if (t.lane < MT) {
+                const int cl = t.wc * WTC + j * MT + t.lane;
+                smem[(t.wr * BCW + cl) * 2] = d;
+                smem[(t.wr * BCW + cl) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        for (int e = t.tid; e < BCW * 2; e += t.nthreads) {
+            double s = 0.0;
+            for (int w = 0; w < WGR; ++w) s += smem[w * BCW * 2 + e];
+            stat_partial[((int64_t)t.tr * ncomp) * 2 + (t.c0) * 2 + e] = s;
+        }
+    }
 };
 
 // out = acc - sub   (projected-gradient G = Gram*Z - B, src/alspgrad.jl:124-127, 280-283)

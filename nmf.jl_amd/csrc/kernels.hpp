@@ -386,4 +386,16 @@ __global__ void gathered_to_full_kernel(T *full, const unsigned char *recv, int 
         }
 }
 
+// dst[c + r*ldd] = sum_p src[p*stride + c + r*cols] (p ascending): the tail pieces of a short grid (GemmArgs::tail_main) summed into the
+// slab region the missing blocks would have written
+template <typename T>
+__global__ void reduce_pieces_kernel(T *dst, int64_t ldd, const T *src, int64_t rows, int64_t cols, int npieces, int64_t stride, const int *done) {
+    if (done && *done) return;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < rows * cols; e += (int64_t)gridDim.x * blockDim.x) {
+        T acc = src[e];
+        for (int q = 1; q < npieces; ++q) acc += src[e + q * stride];
+        dst[(e % cols) + (e / cols) * ldd] = acc;
+    }
+}
+
 }  // namespace nmfx

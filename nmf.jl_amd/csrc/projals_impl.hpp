@@ -24,7 +24,7 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
             hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, A, K, (int)k, lambda, done);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_upper_kernel<T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
-        hipLaunchKernelGGL((potrf_upper_kernel<T>), dim3(1), dim3(1024), lds32, stream, A, K, (int)k, ctrl, (int)NMFX_ERR_NOT_POSDEF);
+        hipLaunchKernelGGL((potrf_upper_kernel<T>), dim3(1), dim3(potrf_nt), lds32, stream, A, K, (int)k, ctrl, (int)NMFX_ERR_NOT_POSDEF);
         HIP_TRY(hipGetLastError());
     });
     timed(tag_trtri, (double)k * k * k / 3.0, 0.0, [&] {
@@ -108,36 +108,90 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     work[1].ensure(kk);              // Uinv
     work[2].ensure(kk);              // inv(HH' + lw I)
     T *Y = work[0].p, *Uinv = work[1].p, *invA = work[2].p;
-    // (Running the factorisation on a second stream UNDER the big GEMM was built and measured: it never becomes co-resident --
-    // two 184-register GEMM waves per SIMD are allocated as 2 x 256 and fill the register file, so the Cholesky workgroup only
-    // starts when GEMM blocks drain; 2.76 ms per iteration either way.  DESIGN.md section 3.2.)
     const bool rs = row_sharded();
+    // The factorisations run UNDER the big products.  Each is one workgroup (potrf) and a few small ones (trtri, potri) whose
+    // 32-step dependency chains take 265 us per side at k = 256 -- 19 % of an iteration when they sit between the products.
+    // A big product is ONE wave of 2 blocks per CU that stay resident for the whole launch and own every register of their
+    // SIMDs, so a second stream never gets a workgroup placed beside them (measured in round 2: 2.76 ms either way; CU masks do
+    // not help either: the hardware deals workgroups to shader engines round-robin whatever their CU count, so a mask that
+    // takes one CU from one engine slows the whole product by 1/8 -- scripts/kbench/cu_mask_probe.hip).  What works: the Gram
+    // by its own small launch first, then the product launched `chol_slots` blocks SHORT (plan_short_grid: the missing items
+    // ride as tail pieces, +1.6 % work per block) -- that leaves chol_slots half-empty CUs -- and the factorisation on a
+    // high-priority side stream with a 512-thread Cholesky workgroup (2 waves per SIMD x 128 registers = the free half of a
+    // CU).  Sharing its CU with a GEMM block the chain runs 4x slower (potrf 650 us, trtri 400 us), which still fits under the
+    // 1.02 ms product: 2.75 -> 2.36 ms per iteration at 16384 x 16384, k = 256.  Replicated-W multi-GPU mode keeps the serial
+    // order (its Gram travels inside the one packed all-reduce that follows the product).
+    const bool under = chol_slots > 0 && !use_bf16x3() && K % 128 == 0 && (nranks == 1 || rs);
+    if (under) ensure_fstream();
+    auto factor_under = [&](T *G, T lambda, const char *t1, const char *t2, bool with_potri) {
+        HIP_TRY(hipEventRecord(ev_fork, stream));
+        HIP_TRY(hipStreamWaitEvent(fstream, ev_fork, 0));
+        std::swap(stream, fstream);
+        potrf_nt = 512;
+        spd_factor(G, lambda, Uinv, t1, t2, done);
+        potrf_nt = 1024;
+        if (with_potri) {            // potri! + copytri! (src/utils.jl:79-80) belong to the factorisation, not to the product
+            EpiStore<T> e1{invA, K, 0, nullptr};
+            gemm<KSTRIDED, KSTRIDED>("gemm_potri", Uinv, K, K, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * K * sizeof(T));
+        }
+        std::swap(stream, fstream);
+        HIP_TRY(hipEventRecord(ev_join, fstream));
+    };
     if (o.update_H) {
         const T *Wp = W[wcur].p;
         const T *Ho = H[hcur].p;
         T *Hn = H[hcur ^ 1].p;
-        wt_times(Wp, X.p, true, done);                                     // :92 W'W, :93 H <- W'X (one launch)
-        spd_factor(gramW_p, (T)o.lambda_h, Uinv, "potrf_WtW", "trtri_WtW", done);   // :92 adddiag!, :94 potrf!
-        spd_solve_left(Uinv, numH_p, Y, Hn, true, done);                   // :94 potrs!, :95 projectnn!
-        stats_h(Hn, Ho, done);
+        if (under) {
+            gram_w_only(Wp, done);                                             // :92 W'W (W is replicated: no exchange)
+            factor_under(gramW_p, (T)o.lambda_h, "potrf_WtW", "trtri_WtW", false);   // :92 adddiag!, :94 potrf!
+            short_grid = true;
+            wt_times(Wp, X.p, false, done);                                    // :93 H <- W'X
+            short_grid = false;
+            HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
+        } else {
+            wt_times(Wp, X.p, true, done);                                     // :92 W'W, :93 H <- W'X (one launch)
+            spd_factor(gramW_p, (T)o.lambda_h, Uinv, "potrf_WtW", "trtri_WtW", done);
+        }
+        {   // :94 potrs! as Uinv * (Uinv' * B), :95 projectnn! and stop_condition's sums over H in the second product's epilogue
+            EpiStore<T> e1{Y, K, 0, nullptr};
+            gemm<KCONTIG, KCONTIG>("gemm_UinvtB", numH_p, K, N, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * N * sizeof(T));
+            EpiClampStats<T> e2{Ho, Hn, K, stat_part.p, (int)K};
+            gemm<KCONTIG, KSTRIDED>("gemm_UinvY_clampH", Y, K, N, Uinv, K, K, K, 1, true, e2, done, 3.0 * K * N * sizeof(T));
+            stats_h_finalize(last_tiles_r, done);
+        }
         hcur ^= 1;
     }
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
-    w_blocked = rs;
-    times_ht(X.p, Hp, true, done);                                         // :100 HH', :101 XH' (one launch)
-    w_blocked = false;
-    if (rs) scatter_w_numerator(o.update_H != 0, done);                    // sharded: numerator rows of this rank + summed HH'
-    else allreduce_w_side(o.update_H != 0, done);
-    spd_factor(gramH_p, (T)o.lambda_w, Uinv, "potrf_HHt", "trtri_HHt", done);       // :100 adddiag!, :102 potrf!
-    // :102 potri! + copytri! + mul!, :103 projectnn!; sharded: rows of W are independent, this rank forms ITS Pc rows
+    if (under) {
+        gram_h_only(Hp, done);                                                 // :100 HH' of this rank's columns ...
+        if (rs) timed("all_reduce_HHt", 0.0, (double)kk * sizeof(T), [&] { comm->all_reduce(gramH_p, kk, CT, false, stream); });   // ... summed
+        factor_under(gramH_p, (T)o.lambda_w, "potrf_HHt", "trtri_HHt", true);  // :100 adddiag!, :102 potrf!, potri!, copytri!
+        w_blocked = rs;
+        short_grid = true;
+        times_ht(X.p, Hp, false, done);                                        // :101 XH'
+        short_grid = false;
+        w_blocked = false;
+        if (rs) scatter_w_numerator(o.update_H != 0, done, /*with_tail=*/false);
+        HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
+        const int64_t r0 = rs ? row0 : 0, rows = rs ? Pc : P;
+        EpiClampStore<T> e2{Wn + r0, P};                                       // :102 mul!, :103 projectnn!
+        gemm<KSTRIDED, KSTRIDED>("gemm_XHtInv_clampW", invA, K, K, numW_p + r0, P, rows, K, 1, false, e2, done, 2.0 * rows * K * sizeof(T));
+    } else {
+        w_blocked = rs;
+        times_ht(X.p, Hp, true, done);                                         // :100 HH', :101 XH' (one launch)
+        w_blocked = false;
+        if (rs) scatter_w_numerator(o.update_H != 0, done);                    // sharded: numerator rows of this rank + summed HH'
+        else allreduce_w_side(o.update_H != 0, done);
+        spd_factor(gramH_p, (T)o.lambda_w, Uinv, "potrf_HHt", "trtri_HHt", done);   // :100 adddiag!, :102 potrf!
+        // :102 potri! + copytri! + mul!, :103 projectnn!; sharded: rows of W are independent, this rank forms ITS Pc rows
+        spd_solve_right(Uinv, invA, numW_p + (rs ? row0 : 0), Wn + (rs ? row0 : 0), rs ? Pc : P, true, done);
+    }
     if (rs) {
-        spd_solve_right(Uinv, invA, numW_p + row0, Wn + row0, Pc, true, done);
         stats_w_rows(Wn, Wo, done);
         gather_w_rows(Wn, true, done);
     } else {
-        spd_solve_right(Uinv, invA, numW_p, Wn, P, true, done);
         stats_w(Wn, Wo, done);
     }
     wcur ^= 1;

@@ -123,6 +123,10 @@ template <typename T> class Solver : public SolverBase {
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         num_cu = prop.multiProcessorCount;
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // ProjectedALS runs its single-workgroup factorisations UNDER the big products (projals_impl.hpp): the products launch
+        // `chol_slots` blocks short of two per CU, a high-priority side stream owns the half-empty CUs that leaves.
+        // NMFX_CHOL_SLOTS=0 turns it off (factorisations between the products, as in round 1).
+        if (const char *e = std::getenv("NMFX_CHOL_SLOTS")) chol_slots = std::max(0, std::min(128, std::atoi(e)));
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
@@ -197,6 +201,12 @@ template <typename T> class Solver : public SolverBase {
             for (int c = 0; c < PIPE_C; ++c) { (void)hipEventDestroy(ev_red[c]); (void)hipEventDestroy(ev_rs[c]); (void)hipEventDestroy(ev_pack[c]); (void)hipEventDestroy(ev_ag[c]); }
             (void)hipEventDestroy(ev_tail);
             (void)hipStreamDestroy(cstream);
+        }
+        if (fstream) {
+            (void)hipStreamSynchronize(fstream);
+            (void)hipEventDestroy(ev_fork);
+            (void)hipEventDestroy(ev_join);
+            (void)hipStreamDestroy(fstream);
         }
         for (auto &e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (pg_state) (void)hipFree(pg_state);
@@ -416,6 +426,30 @@ template <typename T> class Solver : public SolverBase {
     int64_t Rc = 0, Pcc = 0;              // rows per super-chunk, rows per (super-chunk, rank)
     size_t agc_bytes = 0;
     hipStream_t cstream = nullptr;        // the collectives of the pipelined mode
+    int chol_slots = 8;                   // block slots (half CUs) the big products of ProjectedALS leave to the factorisation stream
+    bool short_grid = false;              // set around the products that must leave those slots
+    int potrf_nt = 1024;                  // threads of the Cholesky workgroup (512 when it has to fit beside a GEMM block)
+    hipStream_t fstream = nullptr;        // the factorisation stream (created by the first ProjectedALS iteration)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void ensure_fstream() {
+        if (fstream) return;
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&fstream, hipStreamNonBlocking, hi));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    // the k x k Gram products by their own launches (the overlapped ProjectedALS path needs them BEFORE the big product)
+    void gram_w_only(const T *Wp, const int *done) {
+        EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
+        gemm<KCONTIG, KCONTIG>("gemm_WtW", Wp, P, K, Wp, P, K, P, s_gw, true, eg, done, (double)(P * K) * sizeof(T));
+        reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gw, done);
+    }
+    void gram_h_only(const T *Hp, const int *done) {
+        EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
+        gemm<KSTRIDED, KSTRIDED>("gemm_HHt", Hp, K, K, Hp, K, K, N, s_gh, true, eg, done, (double)(K * N) * sizeof(T));
+        reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gh, done);
+    }
     hipEvent_t ev_red[PIPE_C] = {}, ev_rs[PIPE_C] = {}, ev_pack[PIPE_C] = {}, ev_ag[PIPE_C] = {}, ev_tail = nullptr;
     bool pipe_pending = false;            // an iteration's W is still in flight (all-gather not consumed, stop check not run)
     long long pipe_t = 0;                 // ... that iteration's number
@@ -458,8 +492,9 @@ template <typename T> class Solver : public SolverBase {
 
     template <typename F> void timed(const char *name, double flops, double bytes, F &&launch) {
         if (!profiling) { launch(); return; }
-        // mode 2: only the GEMMs that carry the iteration's flops (>= 1 GFLOP per launch), every 4th launch of each
-        if (profiling == 2 && (flops < 1e9 || ((prof_seen[name]++) & 3) != 0)) { launch(); return; }
+        // mode 2: only the products that carry the iteration's flops (>= 10 GFLOP per launch: the p*n*k ones, not the k x k x n
+        // Gram / update products), every 4th launch of each
+        if (profiling == 2 && (flops < 1e10 || ((prof_seen[name]++) & 3) != 0)) { launch(); return; }
         if (ev_used == (int)ev_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));
@@ -475,7 +510,7 @@ template <typename T> class Solver : public SolverBase {
 
     template <int LA, int LB, int BR, int BC, int WGR, int WGC, int AUX, typename Epi>
     void launch_gemm_cfg(const GemmArgs<T> &g, const Epi &epi) {
-        const int blocks = g.tiles_r * g.tiles_c * g.splits;
+        const int blocks = g.tiles_r * g.tiles_c * g.splits - g.tail_main;
         hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi, AUX>), dim3(blocks), dim3(WGR * WGC * 64), 0,
                            stream, g, epi);
         HIP_TRY(hipGetLastError());
@@ -486,6 +521,7 @@ template <typename T> class Solver : public SolverBase {
         const T *A2 = nullptr; int64_t lda2 = 0, r_split = INT64_MAX;
         const T *B2 = nullptr; int64_t ldb2 = 0, c_split = INT64_MAX;
         int tail_tiles = 0;    // extra tiles along the slow direction, processed as a balanced tail segment
+        int tail_main = 0, tail_per = 0;   // short grid: the last tail_main (tile, split) items as pieces of tail_per k-tiles
         const T *a_aux = nullptr, *b_aux = nullptr;   // operand computed on the fly (projected-gradient trial step)
         const double *alpha_ptr = nullptr;
     };
@@ -498,6 +534,7 @@ template <typename T> class Solver : public SolverBase {
         g.A2 = seg.A2; g.lda2 = seg.lda2; g.r_split = seg.r_split;
         g.B2 = seg.B2; g.ldb2 = seg.ldb2; g.c_split = seg.c_split;
         g.tail_tiles = seg.tail_tiles; g.tail_nkt = (int)(Kdim / BK);
+        g.tail_main = seg.tail_main; g.tail_per = seg.tail_per;
         g.a_aux = seg.a_aux; g.b_aux = seg.b_aux; g.alpha_ptr = seg.alpha_ptr;
         g.splits = splits;
         g.kchunk = (int)(Kdim / splits);
@@ -623,6 +660,36 @@ template <typename T> class Solver : public SolverBase {
         if (use_bf16x3() && P % 128 == 0 && N % 128 == 0) launch_bf16x3<0, 1>(name, Hp, K, N, Wp, P, P, K, 1, true, epi, done, bytes);
         else gemm<KCONTIG, KSTRIDED>(name, Hp, K, N, Wp, P, P, K, 1, true, epi, done, bytes);
     }
+    // A product whose (tile, split) items would fill every block slot of the chip (two 128 x 128 blocks per CU, all resident for
+    // the whole launch) while another stream has a workgroup to place: launch `chol_slots` blocks short and deal the missing items
+    // out as tail pieces (GemmArgs::tail_main), +chol_slots / (2 num_cu) of work per block.  leftover = 0: launch as usual;
+    // `inner` = tiles along the fast tile direction (leftover tiles are whole lines of it: a rectangle of the output).
+    struct ShortGrid { int leftover = 0, per = 0, pieces = 0; };
+    ShortGrid plan_short_grid(int tiles, int splits, int inner, int64_t Kdim) const {
+        ShortGrid sg;
+        if (!short_grid || chol_slots <= 0 || K % 128 != 0) return sg;
+        const int items = tiles * splits, slots = 2 * num_cu - chol_slots;
+        if (items <= slots || items > 2 * num_cu) return sg;      // already leaves room / more than one wave of blocks
+        int left = items - slots;
+        left = (left + inner - 1) / inner * inner;
+        while (((items - left) & 7) && left < tiles) left += inner;
+        const int grid = items - left;
+        if (left > tiles || grid <= 0 || (grid & 7)) return sg;
+        const int nkt = (int)(Kdim / splits / BK);
+        int per = std::max(1, (int)(((int64_t)nkt * left + grid - 1) / grid));
+        while ((int64_t)left * ((nkt + per - 1) / per) > grid) ++per;
+        const int pieces = (nkt + per - 1) / per;
+        if ((size_t)pieces * left * 128 * 128 > (size_t)max_gram_slabs * K * K) return sg;
+        sg.leftover = left; sg.per = per; sg.pieces = pieces;
+        return sg;
+    }
+    void reduce_pieces(const char *name, T *dst, int64_t ldd, const T *src, int64_t rows, int64_t cols, int npieces, const int *done) {
+        timed(name, 0.0, (double)rows * cols * (npieces + 1) * sizeof(T), [&] {
+            hipLaunchKernelGGL(reduce_pieces_kernel<T>, dim3((unsigned)std::min<int64_t>((rows * cols + 255) / 256, 4096)), dim3(256), 0, stream, dst, ldd, src,
+                               rows, cols, npieces, rows * cols, done);
+            HIP_TRY(hipGetLastError());
+        });
+    }
     void wt_times(const T *Wp, const T *Bmat, bool with_gram, const int *done, bool keep_slabs = false) {
         T *reg = slabs.p;
         if (use_bf16x3()) {
@@ -663,6 +730,17 @@ template <typename T> class Solver : public SolverBase {
         }
         h_nslab = s_h; h_stride = (int64_t)K * N;
         EpiStore<T> e{reg, K, h_stride, nullptr};
+        const ShortGrid shg = with_gram ? ShortGrid() : plan_short_grid((int)((N / 128) * (K / 128)), s_h, (int)(K / 128), P);
+        if (shg.leftover) {
+            // the last lines of tiles (columns of numH from c0 on) of the last split arrive as pieces
+            const int64_t lines = shg.leftover / (K / 128), c0 = N - lines * 128;
+            e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = lines * 128 * K; e.r_off = c0; e.c_off = 0;
+            Seg sg;
+            sg.tail_main = shg.leftover; sg.tail_per = shg.per;
+            gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done, (double)(P * N + P * K) * sizeof(T), sg);
+            reduce_pieces("reduce_WtX_pieces", reg + (int64_t)(s_h - 1) * h_stride + c0 * K, lines * 128 * K, slabs.p + gram_slab_off, 1, lines * 128 * K,
+                          shg.pieces, done);
+        } else
         gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                (double)(P * N + P * K) * sizeof(T));
         const bool red = !keep_slabs || h_nslab > 2;
@@ -721,6 +799,16 @@ template <typename T> class Solver : public SolverBase {
         }
         w_nslab = s_w; w_stride = (int64_t)P * K;
         EpiStore<T> e{reg, P, w_stride, nullptr};
+        const ShortGrid shg = with_gram ? ShortGrid() : plan_short_grid((int)((K / 128) * (P / 128)), s_w, (int)(K / 128), N);
+        if (shg.leftover) {
+            // the last lines of tiles (rows of numW from r0 on) of the last split arrive as pieces, compact (ld = rows)
+            const int64_t lines = shg.leftover / (K / 128), r0 = P - lines * 128, rows = lines * 128;
+            e.C2 = slabs.p + gram_slab_off; e.ld2 = rows; e.stride2 = rows * K; e.r_off = 0; e.c_off = r0;
+            Seg sg;
+            sg.tail_main = shg.leftover; sg.tail_per = shg.per;
+            gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done, (double)(P * N + K * N) * sizeof(T), sg);
+            reduce_pieces("reduce_XHt_pieces", reg + (int64_t)(s_w - 1) * w_stride + r0, P, slabs.p + gram_slab_off, K, rows, shg.pieces, done);
+        } else
         gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                  (double)(P * N + K * N) * sizeof(T));
         const bool pair = with_gram && !w_blocked && (!keep_slabs || w_nslab > 2);   // both combines in one launch

@@ -140,3 +140,34 @@ def test_projals_large_k(built, T, k):
     assert r.niters == ro.niters
     assert rel_trace_err(r.trace, ro.trace) < (tol if T == np.float64 else 3e-4)      # well conditioned: 8e-5 measured in f32
     assert np.max(np.abs(Wg - Wc)) <= 50 * tol * np.max(np.abs(Wc))
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_projals_factorisation_under_the_products(built, T, monkeypatch):
+    """At 4096 x 4096, k = 256 each big product is exactly one wave of 2 blocks per CU (64 tiles x 8 splits = 512 items), so the
+    default path launches it 8 blocks short (the missing items ride as tail pieces) and runs the Cholesky / inverse on the side
+    stream under it.  NMFX_CHOL_SLOTS=0 is the serial order of round 1.  Same algorithm, different
+    summation order inside W'X / XH' for the tail pieces: the two trajectories agree to rounding, and with the oracle."""
+    p = n = 4096
+    k = 256
+    X, W0, H0 = uniform(p, n, k, T, seed=77)
+    lam = 0.5
+    alg = nmfx.ProjectedALS(T, maxiter=4, tol=1e-30, lambda_w=lam, lambda_h=lam)
+    runs = {}
+    for slots in ("8", "0"):
+        monkeypatch.setenv("NMFX_CHOL_SLOTS", slots)
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        r = nmfx.solve(alg, X, W, H, track_objective=True)
+        runs[slots] = (r, W, H)
+    ra, rb = runs["8"][0], runs["0"][0]
+    assert ra.niters == rb.niters == 4
+    # f32: the Grams of this start have cond ~ 1e3-1e4 and the first iterations amplify rounding by it (module docstring):
+    # two fp32 summation orders differ by 4e-4 here, the file's f32 trajectory tolerance is 2e-3
+    tol = {np.float64: 1e-10, np.float32: TOL[np.float32]}[T]
+    assert rel_trace_err(ra.trace, rb.trace) < tol
+    np.testing.assert_allclose(ra.info["relchange"][1:], rb.info["relchange"][1:], rtol=10 * tol)
+    if T == np.float64:
+        assert np.max(np.abs(runs["8"][1] - runs["0"][1])) <= 1e-7 * np.max(np.abs(runs["0"][1]))
+    if T == np.float64:
+        ro = orc.solve("projals", X, W0.copy(order="F"), H0.copy(order="F"), orc.Opts(maxiter=4, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+        assert rel_trace_err(ra.trace, ro.trace) < 1e-9

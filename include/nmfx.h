@@ -14,6 +14,13 @@
  * Every function returns an nmfx_status; nmfx_last_error(ctx) gives the text.
  * A context may be used by one host thread at a time; the library never calls
  * back into the host language and keeps no global mutable state.
+ *
+ * Two path switches are read from the environment when a context is created (development / A-B aids; results agree to
+ * rounding either way, tests/test_gpu_multupd.py, tests/test_gpu_projals_alspgrad.py):
+ *   NMFX_SMALLK=0       MultUpdate-MSE with k <= 64 in Float32 stays on the general split-K path (default: the 4-launch
+ *                       stripe kernels when p*n <= 4096^2)
+ *   NMFX_CHOL_SLOTS=0   ProjectedALS factors between its big products instead of under them (default 8: block slots
+ *                       the products leave to the factorisation stream)
  */
 #ifndef NMFX_H
 #define NMFX_H

@@ -13,6 +13,7 @@
 #include "rsvd_impl.hpp"
 #include "pipeline_impl.hpp"
 #include "spa_impl.hpp"
+#include "smallk_impl.hpp"
 
 using namespace nmfx;
 

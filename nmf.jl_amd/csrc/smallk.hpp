@@ -1,0 +1,312 @@
+// smallk.hpp -- MultUpdate (MSE) for k <= 64 in Float32: a low-latency path, 4 launches per outer iteration instead of 12.
+// update_wh!(::MultUpdMSE), src/multupd.jl:83-116, in Gram form like solver_impl.hpp.
+//
+// At k = 64 (BASELINE config 2: 4096 x 4096) the general path is launch / latency bound: its two p*n*k products run 16-way split-K
+// (27 us each against a 13.7 us MFMA floor, then a slab reduction), and ten more launches of 6-9 us carry ~1 us of work each.
+// Here one workgroup owns a 16-wide stripe of the output for the WHOLE contraction, so nothing is split and everything that
+// follows the product happens in the same launch:
+//   smallk_h_kernel : stripe = 16 columns of X.  num = W' X[:, stripe] (64 x 16) over all p rows; den = (W'W) H[:, stripe];
+//                     H <- H .* max(0, num - lh) ./ (den + delta)  (:98-103); stop_condition's sums for the stripe (common.jl:100-104);
+//                     the stripe's contribution to HH' (64 x 64, for the W side's denominator, :110).
+//   smallk_w_kernel : stripe = 16 rows of X.  num = X[stripe, :] H' (16 x 64) over all n columns; den = W[stripe, :] (HH');
+//                     the W update (:109-114), its stop_condition sums, the stripe's contribution to W'W (next iteration's :99).
+// After each: one launch sums the stripes' Gram contributions (fixed order) and one finalises the statistics.
+// Matrix cores: v_mfma_f32_16x16x4_f32 (16 x 16 output tiles: a 64 x 16 stripe is 4 of them, one per wave; the contraction is
+// split once more inside the workgroup, 8 waves = 2 per SIMD, halves combined through LDS).
+// Measured alternatives (scripts/kbench/mfma16_probe.hip gives the issue-rate yardstick: 34 cycles per MFMA per SIMD, i.e. 14 us
+// for one stripe pass at 4096^2): fragments loaded straight from global memory with no LDS and no barrier -- each wave owning
+// 1/8 of the contraction for the whole stripe, three register sets, loads two chunks ahead (the schedule had to be pinned with
+// sched_barrier: the machine scheduler sinks the loads to their uses) -- 50 us per launch against 37 us for the LDS-staged form;
+// the same loop with the loads removed still takes 32 us, so ~17 us of every launch are not the main loop at all (launch, the
+// cold first stage, the Gram / stripe prologue, combine + epilogue + stripe Gram), and the staged form is within 25 % of what
+// this decomposition can do.
+// Rounding: the numerator is two accumulation chains over the contraction per half (the general path sums 16 split-K slabs), the
+// Gram contributions are summed stripe by stripe: same arithmetic class, not the same bits as the general path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "kernels.hpp"
+
+namespace nmfx {
+
+typedef float smallk_v4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ smallk_v4 smallk_mfma(float a, float b, smallk_v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+constexpr int SMALLK_THREADS = 512;
+// LDS floats: staged operands (2 stages) | Gram | old-factor stripe | half-combine | new-factor stripe
+constexpr int SMALLK_H_LDS = 2 * 64 * 68 + 2 * 16 * 68 + 64 * 80 + 16 * 68 + 4 * 64 * 4 + 16 * 80;
+constexpr int SMALLK_W_LDS = 2 * 64 * 80 + 2 * 64 * 16 + 64 * 80 + 64 * 16 + 4 * 64 * 4 + 16 * 80;
+
+// multiplicative update of one element (EpiMultUpdate::apply, gemm_mfma.hpp): max(zero(T), num - lambda) with Julia's NaN rule
+__device__ __forceinline__ float smallk_update(float ov, float nu, float dn, float lambda, float delta) {
+    float t = nu - lambda;
+    t = (t > 0.0f) ? t : ((t != t) ? t : 0.0f);
+    return ov * (t / (dn + delta));
+}
+
+// block -> stripe: blocks are dealt round-robin to the 8 XCDs; neighbouring stripes (which share 128-byte lines of X on the W
+// side) go to the same XCD's L2
+__device__ __forceinline__ int smallk_stripe() {
+    const int nb = gridDim.x, b = blockIdx.x;
+    return ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+}
+
+// the part both kernels share once the new stripe sits in LDS as S[line][comp] (16 lines of 64 components, row stride 80):
+// its Gram contribution S' S (64 x 64) -> slab; 16 output tiles over 8 waves
+__device__ __forceinline__ void smallk_stripe_gram(const float *S, float *slab, int wave, int i, int kg) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int tt = 2 * wave + q, tr = tt >> 2, tc = tt & 3;
+        smallk_v4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) g = smallk_mfma(S[(4 * m + kg) * 80 + 16 * tr + i], S[(4 * m + kg) * 80 + 16 * tc + i], g);
+        *reinterpret_cast<smallk_v4 *>(slab + (16 * tc + i) * 64 + 16 * tr + 4 * kg) = g;
+    }
+}
+
+// H side.  X: P x N (ld ldx), W: P x 64 (ld ldx), gramW: 64 x 64, Ho / Hn: 64 x N (ld 64).  grid = N / 16, 512 threads.
+// Main loop: 64 rows of the contraction per stage, both operands staged through LDS in their natural layout (coalesced float4
+// loads, 256 contiguous bytes per 16 threads), double-buffered, one barrier per stage; two register sets keep the global loads
+// two stages ahead.  Wave (w, half): output tile w (components 16w ..), contraction rows 32 half .. of every stage; every
+// fragment read is a conflict-free ds_read_b32 (row strides 68 / 80 / 16 floats put the 64 lanes on 64 different banks).
+__global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X, int64_t ldx, int64_t P, const float *W, const float *gramW, const float *Ho,
+                                                                  float *Hn, float lambda, float delta, float *gram_slabs, double *stat_part,
+                                                                  const int *done) {
+    if (done && *done) return;
+    extern __shared__ __attribute__((aligned(16))) float smallk_lds[];
+    float *Wc = smallk_lds;              // [2][64 comps][68]   W(p, comp), p contiguous
+    float *Xc = Wc + 2 * 64 * 68;        // [2][16 cols][68]    X(p, col)
+    float *Gs = Xc + 2 * 16 * 68;        // [64 a][80]          gramW(comp, a), comp contiguous
+    float *Hs = Gs + 64 * 80;            // [16 cols][68]       Ho(a, col), a contiguous
+    float *Cx = Hs + 16 * 68;            // [4 waves][64 lanes][4]
+    float *Sn = Cx + 4 * 64 * 4;         // [16 cols][80]       Hn(comp, col), comp contiguous
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = wave & 3, half = wave >> 2, i = lane & 15, kg = lane >> 4;
+    const int stripe = smallk_stripe();
+    const int64_t c0 = (int64_t)stripe * 16;
+    // operands of the epilogue (independent of the main loop): gramW and the old stripe
+    for (int e = tid; e < 64 * 16; e += SMALLK_THREADS) {
+        const int a = e >> 4, c4 = e & 15;
+        *reinterpret_cast<smallk_v4 *>(Gs + a * 80 + 4 * c4) = *reinterpret_cast<const smallk_v4 *>(gramW + a * 64 + 4 * c4);
+    }
+    if (tid < 256) {
+        const int col = tid >> 4, a4 = tid & 15;
+        *reinterpret_cast<smallk_v4 *>(Hs + col * 68 + 4 * a4) = *reinterpret_cast<const smallk_v4 *>(Ho + (c0 + col) * 64 + 4 * a4);
+    }
+    // staging: W stage = 1024 float4 (2 per thread), X stage = 256 float4 (threads 0..255)
+    const int wc0 = tid >> 4, wp4 = tid & 15;
+    const float *wsrc0 = W + (int64_t)wc0 * ldx + 4 * wp4, *wsrc1 = W + (int64_t)(wc0 + 32) * ldx + 4 * wp4;
+    const float *xsrc = X + (c0 + (tid >> 4)) * ldx + 4 * (tid & 15);
+    smallk_v4 rw0[2], rw1[2], rx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto gload = [&](int set, int64_t p0) {
+        rw0[set] = *reinterpret_cast<const smallk_v4 *>(wsrc0 + p0);
+        rw1[set] = *reinterpret_cast<const smallk_v4 *>(wsrc1 + p0);
+        if (tid < 256) rx[set] = *reinterpret_cast<const smallk_v4 *>(xsrc + p0);
+    };
+    auto lstore = [&](int set, int buf) {
+        *reinterpret_cast<smallk_v4 *>(Wc + buf * 64 * 68 + wc0 * 68 + 4 * wp4) = rw0[set];
+        *reinterpret_cast<smallk_v4 *>(Wc + buf * 64 * 68 + (wc0 + 32) * 68 + 4 * wp4) = rw1[set];
+        if (tid < 256) *reinterpret_cast<smallk_v4 *>(Xc + buf * 16 * 68 + (tid >> 4) * 68 + 4 * (tid & 15)) = rx[set];
+    };
+    const int T = (int)(P / 64);      // even: P is a multiple of 256
+    gload(0, 0);
+    lstore(0, 0);
+    gload(0, 64);
+    if (T > 2) gload(1, 128);
+    __syncthreads();
+    smallk_v4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int t, auto SET) {
+        constexpr int set = decltype(SET)::value;      // = t & 1: stage t+1 waits in register set t & 1
+        const int buf = t & 1;
+        const float *wa = Wc + buf * 64 * 68 + (16 * w + i) * 68 + 32 * half + kg;
+        const float *xb = Xc + buf * 16 * 68 + i * 68 + 32 * half + kg;
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) {
+            acc0 = smallk_mfma(wa[4 * m], xb[4 * m], acc0);
+            acc1 = smallk_mfma(wa[4 * m + 4], xb[4 * m + 4], acc1);
+        }
+        if (t + 1 < T) lstore(set, buf ^ 1);
+        if (t + 3 < T) gload(set, (int64_t)(t + 3) * 64);
+        __syncthreads();
+    };
+    for (int t = 0; t < T; t += 2) {
+        step(t, std::integral_constant<int, 0>{});
+        step(t + 1, std::integral_constant<int, 1>{});
+    }
+    smallk_v4 num = acc0 + acc1;
+    if (half) *reinterpret_cast<smallk_v4 *>(Cx + (w * 64 + lane) * 4) = num;
+    __syncthreads();
+    if (!half) {
+        num += *reinterpret_cast<const smallk_v4 *>(Cx + (w * 64 + lane) * 4);
+        // den = (W'W)[comps of this wave, :] * Ho[:, stripe]
+        smallk_v4 den = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 16; ++m) den = smallk_mfma(Gs[(4 * m + kg) * 80 + 16 * w + i], Hs[i * 68 + 4 * m + kg], den);
+        // lane: column c0 + i, components 16w + 4kg + r
+        smallk_v4 nv;
+        double dv[4], sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ov = Hs[i * 68 + 16 * w + 4 * kg + r];
+            nv[r] = smallk_update(ov, num[r], den[r], lambda, delta);
+            const float d = nv[r] - ov, sp = nv[r] + ov;
+            dv[r] = (double)(float)(d * d);
+            sv[r] = (double)(float)(sp * sp);
+        }
+        *reinterpret_cast<smallk_v4 *>(Hn + (c0 + i) * 64 + 16 * w + 4 * kg) = nv;
+        *reinterpret_cast<smallk_v4 *>(Sn + i * 80 + 16 * w + 4 * kg) = nv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) { dv[r] += __shfl_xor(dv[r], off, 64); sv[r] += __shfl_xor(sv[r], off, 64); }
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int comp = 16 * w + 4 * kg + r;
+                stat_part[((int64_t)stripe * 64 + comp) * 2] = dv[r];
+                stat_part[((int64_t)stripe * 64 + comp) * 2 + 1] = sv[r];
+            }
+        }
+    }
+    __syncthreads();
+    smallk_stripe_gram(Sn, gram_slabs + (int64_t)stripe * 4096, wave, i, kg);
+}
+
+// W side.  gramH: 64 x 64, Wo / Wn: P x 64 (ld ldx), H: 64 x N (ld 64).  grid = P / 16, 512 threads.
+// Same structure with 64 COLUMNS per stage (H staged component-contiguous, X row-contiguous).
+__global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X, int64_t ldx, int64_t N, const float *H, const float *gramH, const float *Wo,
+                                                                  float *Wn, float lambda, float delta, float *gram_slabs, double *stat_part,
+                                                                  const int *done) {
+    if (done && *done) return;
+    extern __shared__ __attribute__((aligned(16))) float smallk_lds[];
+    float *Hc = smallk_lds;              // [2][64 cols][80]    H(comp, col), comp contiguous
+    float *Xc = Hc + 2 * 64 * 80;        // [2][64 cols][16]    X(row, col), row contiguous
+    float *Gs = Xc + 2 * 64 * 16;        // [64 a][80]          gramH(comp, a)
+    float *Ws = Gs + 64 * 80;            // [64 a][16 rows]     Wo(row, a), row contiguous
+    float *Cx = Ws + 64 * 16;            // [4][64][4]
+    float *Sn = Cx + 4 * 64 * 4;         // [16 rows][80]       Wn(row, comp), comp contiguous
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = wave & 3, half = wave >> 2, i = lane & 15, kg = lane >> 4;
+    const int stripe = smallk_stripe();
+    const int64_t r0 = (int64_t)stripe * 16;
+    for (int e = tid; e < 64 * 16; e += SMALLK_THREADS) {
+        const int a = e >> 4, c4 = e & 15;
+        *reinterpret_cast<smallk_v4 *>(Gs + a * 80 + 4 * c4) = *reinterpret_cast<const smallk_v4 *>(gramH + a * 64 + 4 * c4);
+    }
+    if (tid < 256) {
+        const int a = tid >> 2, r4 = tid & 3;
+        *reinterpret_cast<smallk_v4 *>(Ws + a * 16 + 4 * r4) = *reinterpret_cast<const smallk_v4 *>(Wo + r0 + 4 * r4 + (int64_t)a * ldx);
+    }
+    // staging: H stage = 64 cols x 64 comps = 1024 float4 (2 per thread), X stage = 64 cols x 16 rows = 256 float4
+    const int hc0 = tid >> 4, h4 = tid & 15;
+    const float *hsrc0 = H + (int64_t)hc0 * 64 + 4 * h4, *hsrc1 = H + (int64_t)(hc0 + 32) * 64 + 4 * h4;
+    const float *xsrc = X + r0 + 4 * (tid & 3) + (int64_t)(tid >> 2) * ldx;
+    smallk_v4 rh0[2], rh1[2], rx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // two stages ahead, as in smallk_h_kernel
+    auto gload = [&](int set, int64_t j0) {
+        rh0[set] = *reinterpret_cast<const smallk_v4 *>(hsrc0 + j0 * 64);
+        rh1[set] = *reinterpret_cast<const smallk_v4 *>(hsrc1 + j0 * 64);
+        if (tid < 256) rx[set] = *reinterpret_cast<const smallk_v4 *>(xsrc + j0 * ldx);
+    };
+    auto lstore = [&](int set, int buf) {
+        *reinterpret_cast<smallk_v4 *>(Hc + buf * 64 * 80 + hc0 * 80 + 4 * h4) = rh0[set];
+        *reinterpret_cast<smallk_v4 *>(Hc + buf * 64 * 80 + (hc0 + 32) * 80 + 4 * h4) = rh1[set];
+        if (tid < 256) *reinterpret_cast<smallk_v4 *>(Xc + buf * 64 * 16 + (tid >> 2) * 16 + 4 * (tid & 3)) = rx[set];
+    };
+    const int T = (int)(N / 64);      // even: N is a multiple of 256
+    gload(0, 0);
+    lstore(0, 0);
+    gload(0, 64);
+    if (T > 2) gload(1, 128);
+    __syncthreads();
+    smallk_v4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int t, auto SET) {
+        constexpr int set = decltype(SET)::value;
+        const int buf = t & 1;
+        const float *ha = Hc + buf * 64 * 80 + (32 * half + kg) * 80 + 16 * w + i;
+        const float *xb = Xc + buf * 64 * 16 + (32 * half + kg) * 16 + i;
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) {
+            acc0 = smallk_mfma(ha[4 * m * 80], xb[4 * m * 16], acc0);
+            acc1 = smallk_mfma(ha[(4 * m + 4) * 80], xb[(4 * m + 4) * 16], acc1);
+        }
+        if (t + 1 < T) lstore(set, buf ^ 1);
+        if (t + 3 < T) gload(set, (int64_t)(t + 3) * 64);
+        __syncthreads();
+    };
+    for (int t = 0; t < T; t += 2) {
+        step(t, std::integral_constant<int, 0>{});
+        step(t + 1, std::integral_constant<int, 1>{});
+    }
+    smallk_v4 num = acc0 + acc1;
+    if (half) *reinterpret_cast<smallk_v4 *>(Cx + (w * 64 + lane) * 4) = num;
+    __syncthreads();
+    if (!half) {
+        num += *reinterpret_cast<const smallk_v4 *>(Cx + (w * 64 + lane) * 4);
+        // den(comp, row) = sum_a (HH')(comp, a) Wo(row, a)
+        smallk_v4 den = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 16; ++m) den = smallk_mfma(Gs[(4 * m + kg) * 80 + 16 * w + i], Ws[(4 * m + kg) * 16 + i], den);
+        // lane: row r0 + i, components 16w + 4kg + r
+        smallk_v4 nv;
+        double dv[4], sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int comp = 16 * w + 4 * kg + r;
+            const float ov = Ws[comp * 16 + i];
+            nv[r] = smallk_update(ov, num[r], den[r], lambda, delta);
+            const float d = nv[r] - ov, sp = nv[r] + ov;
+            dv[r] = (double)(float)(d * d);
+            sv[r] = (double)(float)(sp * sp);
+            Wn[r0 + i + (int64_t)comp * ldx] = nv[r];
+        }
+        *reinterpret_cast<smallk_v4 *>(Sn + i * 80 + 16 * w + 4 * kg) = nv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) { dv[r] += __shfl_xor(dv[r], off, 64); sv[r] += __shfl_xor(sv[r], off, 64); }
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int comp = 16 * w + 4 * kg + r;
+                stat_part[((int64_t)stripe * 64 + comp) * 2] = dv[r];
+                stat_part[((int64_t)stripe * 64 + comp) * 2 + 1] = sv[r];
+            }
+        }
+    }
+    __syncthreads();
+    smallk_stripe_gram(Sn, gram_slabs + (int64_t)stripe * 4096, wave, i, kg);
+}
+
+// After a stripe kernel, ONE launch: blocks [0, 256) sum the stripes' Gram contributions (16 elements per block, 16 slab-lanes per
+// element: every load of a thread is independent, one round trip; the 16 partial sums are added in lane order: fixed order),
+// blocks [256, 256 + 32) sum the statistics partials (128 values, a wave per value as in finalize_partials_kernel).
+__global__ __launch_bounds__(256) void smallk_finish_kernel(float *gram, const float *slabs, int nstripes, const double *stat_part, double *stat_out,
+                                                           const int *done) {
+    if (done && *done) return;
+    if (blockIdx.x < 256) {
+        __shared__ float sm[16][16];
+        const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+        const int64_t i = (int64_t)blockIdx.x * 16 + e;
+        float acc = 0.f;
+        for (int k = sl; k < nstripes; k += 16) acc += slabs[(int64_t)k * 4096 + i];
+        sm[sl][e] = acc;
+        __syncthreads();
+        if (sl == 0) {
+            float t = sm[0][e];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) t += sm[q][e];
+            gram[i] = t;
+        }
+    } else {
+        const int e = (blockIdx.x - 256) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        double s = 0.0;
+        for (int c = lane; c < nstripes; c += 64) s += stat_part[(int64_t)c * 128 + e];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) stat_out[e] = s;
+    }
+}
+
+}  // namespace nmfx

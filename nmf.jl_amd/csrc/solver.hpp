@@ -127,6 +127,7 @@ template <typename T> class Solver : public SolverBase {
         // `chol_slots` blocks short of two per CU, a high-priority side stream owns the half-empty CUs that leaves.
         // NMFX_CHOL_SLOTS=0 turns it off (factorisations between the products, as in round 1).
         if (const char *e = std::getenv("NMFX_CHOL_SLOTS")) chol_slots = std::max(0, std::min(128, std::atoi(e)));
+        if (const char *e = std::getenv("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
@@ -178,7 +179,7 @@ template <typename T> class Solver : public SolverBase {
         slabs.alloc(gram_slab_off + (size_t)max_gram_slabs * K * K);
         stat_chunks_w = (int)std::max<int64_t>(1, std::min<int64_t>(64, P / 1024));
         stat_chunks_h = (int)std::max<int64_t>(1, std::min<int64_t>(256, N / 64));
-        stat_part.alloc((size_t)std::max<int64_t>(std::max(stat_chunks_w, stat_chunks_h), N / 64) * 2 * K);
+        stat_part.alloc((size_t)std::max<int64_t>(std::max(stat_chunks_w, stat_chunks_h), std::max(N, P) / 16) * 2 * K);   // smallk: one partial per 16-wide stripe
         wstat.alloc((size_t)2 * K);
         hstat.alloc((size_t)2 * K);
         svec.alloc((size_t)K);
@@ -884,6 +885,18 @@ template <typename T> class Solver : public SolverBase {
 
     void enqueue_objective(int alg, const nmfx_opts &o, double *dst, const int *done);
     void enqueue_multmse(const nmfx_opts &o, long long t);
+    // k <= 64, Float32, one GPU: the 4-launch path of smallk.hpp (smallk_impl.hpp)
+    bool smallk_enabled = true;          // NMFX_SMALLK=0 keeps the general path
+    bool smallk_grams_valid = false;     // gramW_p / gramH_p hold the Grams of the CURRENT factors (reset by every iterate())
+    DevBuf<T> smallk_slabs;              // the stripes' Gram contributions
+    // measured crossover (scripts/bench: 1024^2 2.4x, 2048^2 1.75x, 4096^2 1.25x faster than the general path; 8192^2 0.8x): a stripe
+    // kernel re-reads the whole other factor per 16-wide stripe, which stops paying once the problem is large enough to keep the
+    // split-K products busy; very skewed shapes leave one side with too few stripes
+    bool smallk_ok() const {
+        return sizeof(T) == 4 && K == 64 && nranks == 1 && smallk_enabled && !use_bf16x3() && P * N <= (int64_t)4096 * 4096 &&
+               std::max(P, N) <= 4 * std::min(P, N);
+    }
+    void enqueue_multmse_smallk(const nmfx_opts &o);
     void enqueue_multdiv(const nmfx_opts &o, long long t);
     void enqueue_projals(const nmfx_opts &o, long long t);
     void spd_factor(T *A, T lambda, T *Uinv, const char *tag_potrf, const char *tag_trtri, const int *done);

@@ -132,6 +132,7 @@ template <typename T> void Solver<T>::gather_w_rows(T *Wfull, bool with_stats, c
 // ---------------------------------------------------------------------------
 template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long long t) {
     (void)t;
+    if (smallk_ok()) { enqueue_multmse_smallk(o); return; }
     const int *done = done_flag();
     if (o.update_H) {
         const T *Wp = W[wcur].p;
@@ -264,6 +265,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     if (o.precision != NMFX_PREC_FP32 && o.precision != NMFX_PREC_BF16X3) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for precision."};
     precision = o.precision;
     pipe_pending = false;
+    smallk_grams_valid = false;
     rsvd_ready = 0;   // the iteration overwrites the buffers a pending rsvd keeps its Q / B in
     HIP_TRY(hipSetDevice(device));
     std::memset(out, 0, sizeof *out);

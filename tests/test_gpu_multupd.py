@@ -127,3 +127,34 @@ def test_multdiv_raw_abi_lambda_zero_padded_k(built, T):
     Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
     ro = orc.solve("multdiv", X, Wc, Hc, orc.Opts(maxiter=12, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
     assert rel_trace_err(trace[:13], ro.trace) < TOL[T][0]
+
+
+@pytest.mark.parametrize("shape", [(300, 260, 5), (1000, 1500, 64), (4096, 4096, 64), (700, 2100, 33)])
+@pytest.mark.parametrize("update_H", [True, False])
+def test_multmse_small_k_path(built, shape, update_H, monkeypatch):
+    """k <= 64, Float32, P*N <= 4096^2: MultUpdate-MSE runs on the 4-launch stripe kernels (csrc/smallk.hpp) instead of the 12-launch
+    general path.  Same algorithm, different summation order inside W'X / XH' / the Grams: the two device paths agree to f32 rounding
+    (1e-5 on the objective trajectory, the tolerance this file states for f32 against the oracle), iteration counts are identical,
+    and the oracle comparison holds for the new path on its own."""
+    p, n, k = shape
+    T = np.float32
+    X, W0, H0 = planted(p, n, k, T, seed=p + k)
+    lam = 1e-3
+    alg = nmfx.MultUpdate(T, obj="mse", maxiter=12, tol=1e-30, lambda_w=lam, lambda_h=lam, update_H=update_H)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NMFX_SMALLK", mode)
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        runs[mode] = (nmfx.solve(alg, X, W, H, track_objective=True), W, H)
+    ra, rb = runs["1"][0], runs["0"][0]
+    assert ra.niters == rb.niters == 12
+    assert rel_trace_err(ra.trace, rb.trace) < 1e-5
+    np.testing.assert_allclose(ra.info["relchange"][1:], rb.info["relchange"][1:], rtol=1e-3)
+    assert np.max(np.abs(runs["1"][1] - runs["0"][1])) <= 1e-4 * np.max(np.abs(runs["0"][1]))
+    assert np.max(np.abs(runs["1"][2] - runs["0"][2])) <= 1e-4 * np.max(np.abs(runs["0"][2]))
+    if not update_H:
+        assert np.array_equal(runs["1"][2], H0)
+    if p * n <= 2_000_000:
+        ro = orc.solve("multmse", X, W0.copy(order="F"), H0.copy(order="F"),
+                       orc.Opts(maxiter=12, tol=1e-30, lambda_w=lam, lambda_h=lam, update_H=update_H, track_objective=True))
+        assert rel_trace_err(ra.trace, ro.trace) < 1e-5

@@ -2,7 +2,10 @@
 // RandomizedLinAlg.jl, un-vendored: randomized range finder + SVD of the projected matrix, Halko-Martinsson-Tropp 2011).
 // Every p*n*k product is one of the hot path's own GEMM launches:
 //     Y = X * Omega          == X * H'   with H := Omega' (k x n Gaussian)      -> times_ht   (+ the packed all-reduce when sharded)
-//     Q = orth(Y)            classical Gram-Schmidt with re-orthogonalisation (CGS2), column by column, p x k
+//     Q = orth(Y)            (shifted) Cholesky QR: passes of { G = Y'Y (Gram launch), U = chol(G [+ s I]), Y <- Y inv(U) (ProjectedALS's
+//                            potrf / trtri kernels + one product) }, verified a posteriori -- rsvd_cholqr2 below; 3-5 passes of 5
+//                            launches on non-negative data.  Falls back to classical Gram-Schmidt with re-orthogonalisation (CGS2),
+//                            column by column (5 k launches; rank-deficient sketches end with zero columns there)
 //     B = Q' * X             == W' * X   with W := Q                             -> wt_times
 //     C = B * B'             k x k Gram of B                                     -> gram GEMM (+ all-reduce when sharded)
 // The k x k symmetric eigenproblem C = Ub S^2 Ub' is the host's (LAPACK in Julia / NumPy, like the reference's small svd):
@@ -11,6 +14,7 @@
 // cannot be reproduced, so parity with the reference's rsvd is UNPINNED by construction -- the tests pin the mathematical
 // contract instead (orthonormal U, V; reconstruction error within a factor of the optimal rank-k truncation).
 #pragma once
+#include <cstdio>
 #include "frontend_impl.hpp"
 
 namespace nmfx {
@@ -77,6 +81,74 @@ template <typename T> __global__ void scale_rows_inv_kernel(T *Vt, int64_t ld, i
     Vt[a + j * ld] = (sa > (T)0) ? Vt[a + j * ld] / sa : (T)0;
 }
 
+// Q <- orth(Q) by Cholesky QR (Q: P x K, ld P; tmp: same size): passes of { G = Q'Q, U = chol(G + s I), Q <- Q inv(U) }.
+// A pass without shift whose factor has diag(U) within 1 / (8 sqrt(eps)) is followed by exactly one more (CholeskyQR2:
+// orthogonal to rounding).  Otherwise the pass is redone with s = 1e-3 trace(G) -- G + s I is safely positive definite in T and
+// the pass divides the condition number by >= ~30 (shifted Cholesky QR, Fukaya et al., SIAM J. Sci. Comput. 42, 2020; the shift
+// of the paper's bound is meaningless in Float32 at p = 16384, hence the a-posteriori control).  Non-negative data make this the
+// normal case: the Perron direction puts cond(X Omega) at 1e3 .. 1e4.  At most 6 passes; the result is VERIFIED (one more Gram:
+// max |Q'Q - I| <= 64 eps sqrt(k)) and false is returned -- with Q restored by the caller -- when anything is off, e.g. a
+// rank-deficient sketch: then Gram-Schmidt runs.
+template <typename T> bool Solver<T>::rsvd_cholqr2(T *Qbuf, T *tmp) {
+    const size_t kk = (size_t)K * K;
+    work[1].ensure(kk);
+    work[2].ensure(kk);
+    T *Uinv = work[1].p, *Gkeep = work[2].p, *src = Qbuf, *dst = tmp;
+    std::vector<T> gh(kk);
+    const double eps = (double)std::numeric_limits<T>::epsilon(), limit = 1.0 / (8.0 * std::sqrt(eps));
+    const bool dbg = std::getenv("NMFX_DEBUG") != nullptr;
+    Ctrl init;
+    std::memset(&init, 0, sizeof init);
+    auto factor = [&](T shift, double &dmin, double &dmax) {      // gramW_p <- chol(gramW_p + shift I); false on a non-positive pivot
+        HIP_TRY(hipMemcpyAsync(ctrl, &init, sizeof init, hipMemcpyHostToDevice, stream));
+        spd_factor(gramW_p, shift, Uinv, "potrf_YtY", "trtri_YtY", nullptr);
+        HIP_TRY(hipMemcpyAsync(ctrl_host, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpy2DAsync(gh.data(), sizeof(T), gramW_p, (size_t)(K + 1) * sizeof(T), sizeof(T), (size_t)k, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const bool ok = ctrl_host->status == 0;
+        HIP_TRY(hipMemcpyAsync(ctrl, &init, sizeof init, hipMemcpyHostToDevice, stream));      // a failed potrf raised the stop flag
+        dmin = 1e300; dmax = 0.0;
+        for (int64_t j = 0; j < k; ++j) { dmin = std::min(dmin, (double)gh[(size_t)j]); dmax = std::max(dmax, (double)gh[(size_t)j]); }
+        return ok && dmin > 0.0 && std::isfinite(dmax);
+    };
+    bool clean_pass_done = false, good = false;
+    for (int pass = 0; pass < 6 && !good; ++pass) {
+        gram_w_only(src, nullptr);
+        HIP_TRY(hipMemcpyAsync(Gkeep, gramW_p, kk * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        double dmin, dmax;
+        bool ok = factor((T)0, dmin, dmax);
+        const bool clean = ok && dmax <= limit * dmin;
+        if (dbg) std::fprintf(stderr, "[nmfx] cholqr pass %d: posdef %d, diag(U) in [%g, %g] -> %s\n", pass, (int)ok, dmin, dmax, clean ? "plain" : "shifted");
+        if (!clean) {
+            if (clean_pass_done) return false;       // got worse after a clean pass: not a case for this method
+            HIP_TRY(hipMemcpy2DAsync(gh.data(), sizeof(T), Gkeep, (size_t)(K + 1) * sizeof(T), sizeof(T), (size_t)k, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            double tr = 0.0;
+            for (int64_t j = 0; j < k; ++j) tr += (double)gh[(size_t)j];
+            if (!(tr > 0.0) || !std::isfinite(tr)) return false;
+            HIP_TRY(hipMemcpyAsync(gramW_p, Gkeep, kk * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            if (!factor((T)(1e-3 * tr), dmin, dmax)) return false;
+        }
+        EpiStore<T> e{dst, P, 0, nullptr};       // dst(i, a) = sum_b src(i, b) Uinv(b, a)
+        gemm<KCONTIG, KSTRIDED>("gemm_YUinv", Uinv, K, K, src, P, P, K, 1, false, e, nullptr, 2.0 * P * K * sizeof(T));
+        std::swap(src, dst);
+        good = clean && clean_pass_done;             // the second of two plain passes
+        clean_pass_done = clean_pass_done || clean;
+    }
+    if (!good) return false;
+    // verify
+    gram_w_only(src, nullptr);
+    HIP_TRY(hipMemcpy2DAsync(gh.data(), k * sizeof(T), gramW_p, K * sizeof(T), k * sizeof(T), k, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    double worst = 0.0;
+    for (int64_t j = 0; j < k; ++j)
+        for (int64_t i = 0; i < k; ++i) worst = std::max(worst, std::fabs((double)gh[(size_t)(i + j * k)] - (i == j ? 1.0 : 0.0)));
+    if (dbg) std::fprintf(stderr, "[nmfx] cholqr: max |Q'Q - I| = %g\n", worst);
+    if (!(worst <= 64.0 * eps * std::sqrt((double)k))) return false;
+    if (src != Qbuf) HIP_TRY(hipMemcpyAsync(Qbuf, src, (size_t)P * K * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    return true;
+}
+
 template <typename T> void Solver<T>::rsvd_begin(uint64_t seed, int64_t h_col_offset, int power_iters, void *C_host) {
     if (power_iters < 0 || power_iters > 8) throw StatusError{NMFX_ERR_BAD_ARG, "power_iters must be in 0..8"};
     if (!have_X) throw StatusError{NMFX_ERR_STATE, "X has not been uploaded (nmfx_set_X)"};
@@ -100,8 +172,10 @@ template <typename T> void Solver<T>::rsvd_begin(uint64_t seed, int64_t h_col_of
         times_ht(X.p, Hlike, false, nullptr);
         allreduce_w_side(false, nullptr);
         HIP_TRY(hipMemcpyAsync(Q, numW_p, pk * sizeof(T), hipMemcpyDeviceToDevice, stream));
-        // 3. Q = orth(Y): classical Gram-Schmidt with re-orthogonalisation (two passes per column)
-        for (int j = 0; j < (int)k; ++j) {
+        // 3. Q = orth(Y): CholeskyQR2 when the sketch is well conditioned, else column-by-column Gram-Schmidt (two passes per column)
+        const bool blocked = rsvd_cholqr2(Q, work[5].p);
+        if (!blocked) HIP_TRY(hipMemcpyAsync(Q, numW_p, pk * sizeof(T), hipMemcpyDeviceToDevice, stream));     // Y again
+        for (int j = 0; j < (int)k && !blocked; ++j) {
             for (int pass = 0; pass < 2; ++pass) {
                 if (j > 0) hipLaunchKernelGGL(cgs_dots_kernel<T>, dim3((unsigned)j), dim3(256), 0, stream, Q, p, P, j, c);
                 hipLaunchKernelGGL(cgs_update_kernel<T>, dim3(rb), dim3(256), 0, stream, Q, p, P, j, c, part);

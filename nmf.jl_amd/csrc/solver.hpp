@@ -357,6 +357,7 @@ template <typename T> class Solver : public SolverBase {
     void nndsvd_core(const T *Ud, int64_t ucs, int64_t uss, const T *Vd, int64_t vcs, int64_t vss, const T *sd, T *coef, int variant,
                      bool zeroh, uint64_t seed, int64_t n_total);
     void pdsolve_host(int right, const void *A_host, const void *B_host, double lambda, void *X_host, bool clamp) override;
+    bool rsvd_cholqr2(T *Qbuf, T *tmp);   // rsvd_impl.hpp
     void spa_init(int warm_sweeps, int64_t *anchors_out, int64_t *unsolved_out) override;   // spa_impl.hpp
     DevBuf<long long> flag_ll;   // spa: the anchor indices
     DevBuf<int> spa_status;      // spa: per-column outcome of the active-set solve

@@ -10,11 +10,10 @@ template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o)
         const int *done = done_flag();
         const int64_t stripes_h = N / 16, stripes_w = P / 16;
         smallk_slabs.ensure((size_t)std::max(stripes_h, stripes_w) * 4096);
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!smallk_attr_set) {      // per context: the attribute belongs to the device the context lives on
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&smallk_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMALLK_H_LDS * 4));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&smallk_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMALLK_W_LDS * 4));
-            attr_set = true;
+            smallk_attr_set = true;
         }
         if (!smallk_grams_valid) {
             // first iteration of a solve: the Grams of the factors as they were handed in (later ones come out of the kernels)

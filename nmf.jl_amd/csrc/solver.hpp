@@ -888,6 +888,7 @@ template <typename T> class Solver : public SolverBase {
     void enqueue_multmse(const nmfx_opts &o, long long t);
     // k <= 64, Float32, one GPU: the 4-launch path of smallk.hpp (smallk_impl.hpp)
     bool smallk_enabled = true;          // NMFX_SMALLK=0 keeps the general path
+    bool smallk_attr_set = false;
     bool smallk_grams_valid = false;     // gramW_p / gramH_p hold the Grams of the CURRENT factors (reset by every iterate())
     DevBuf<T> smallk_slabs;              // the stripes' Gram contributions
     // measured crossover (scripts/bench: 1024^2 2.4x, 2048^2 1.75x, 4096^2 1.25x faster than the general path; 8192^2 0.8x): a stripe

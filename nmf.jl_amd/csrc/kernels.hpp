@@ -398,4 +398,117 @@ __global__ void reduce_pieces_kernel(T *dst, int64_t ldd, const T *src, int64_t 
     }
 }
 
+// ---- multdiv, single GPU: everything that follows a numerator product in ONE pass over the factor (src/multupd.jl:176-179, 188-191
+// + stop_condition's sums, src/common.jl:95-104): split-K slabs summed (ascending, in T, like reduce_slabs_kernel), the scaling
+// of div_update_kernel, the statistics of row_stats_kernel / col_stats_kernel and the OTHER side's next divisor (sum over the
+// other axis of the NEW factor) -- same chunking and the same arithmetic as the separate kernels: bit-identical results, 4
+// launches and 3 passes over the factor fewer per side.
+//   partial[(chunk*K + j)*2 + {0,1}] = dev, sum;   partial[2*K*nchunks + chunk*K + j] = sum of the new factor's component j
+template <typename T>
+__global__ void div_h_fused_kernel(T *Hn, const T *Ho, const T *num, int nslab, int64_t slab_stride, const T *sW, int64_t k, int64_t n,
+                                   int64_t cols, int64_t ld, int K, T lambda, double *partial, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int chunk = blockIdx.x, nchunks = gridDim.x;
+    const int64_t per = (cols + nchunks - 1) / nchunks;
+    const int64_t beg = chunk * per, end = (beg + per < cols) ? beg + per : cols;
+    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+        double dev = 0.0, sum = 0.0, rs = 0.0;
+        const T d = (j < k) ? sW[j] + lambda : (T)1;
+        // 4 columns per trip: 4 x (nslab + 2) independent loads in flight per thread (one column per trip left the pass latency
+        // bound: 61 us for 4 x 16 MB); the sums are still added in column order
+        for (int64_t i0 = beg; i0 < end; i0 += 4) {
+            T a[4], b[4], nu[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + u, o = j + i * ld;
+                const bool in = i < end;
+                b[u] = in ? Ho[o] : (T)0;
+                a[u] = in ? Hn[o] : (T)0;                 // padding: whatever the buffer holds (zeros), never written
+                nu[u] = (in && j < k && i < n) ? num[o] : (T)0;
+            }
+            for (int s = 1; s < nslab; ++s) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = i0 + u;
+                    if (i < end && j < k && i < n) nu[u] += num[(int64_t)s * slab_stride + j + i * ld];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + u;
+                if (i >= end) break;
+                if (j < k && i < n) {
+                    a[u] = b[u] * (nu[u] / d);
+                    Hn[j + i * ld] = a[u];
+                }
+                const T df = a[u] - b[u], sp = a[u] + b[u];
+                dev += (double)(T)(df * df);
+                sum += (double)(T)(sp * sp);
+                rs += (double)a[u];
+            }
+        }
+        partial[((int64_t)chunk * K + j) * 2] = dev;
+        partial[((int64_t)chunk * K + j) * 2 + 1] = sum;
+        partial[(int64_t)2 * K * nchunks + (int64_t)chunk * K + j] = rs;
+    }
+}
+
+// grid = (chunks, K): one block per (row chunk, component)
+template <typename T>
+__global__ void div_w_fused_kernel(T *Wn, const T *Wo, const T *num, int nslab, int64_t slab_stride, const T *sH, int64_t p, int64_t k,
+                                   int64_t rows, int64_t ld, int K, T lambda, double *partial, const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ double sm[12];
+    const int j = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int64_t per = (rows + nchunks - 1) / nchunks;
+    const int64_t beg = chunk * per, end = (beg + per < rows) ? beg + per : rows;
+    const T d = (j < k) ? sH[j] + lambda : (T)1;
+    double dev = 0.0, sum = 0.0, cs = 0.0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+        const int64_t o = i + (int64_t)j * ld;
+        const T b = Wo[o];
+        T a = Wn[o];
+        if (j < k && i < p) {
+            T nu = num[o];
+            for (int s = 1; s < nslab; ++s) nu += num[(int64_t)s * slab_stride + o];
+            a = b * (nu / d);
+            Wn[o] = a;
+        }
+        const T df = a - b, sp = a + b;
+        dev += (double)(T)(df * df);
+        sum += (double)(T)(sp * sp);
+        cs += (double)a;
+    }
+    for (int off = 32; off > 0; off >>= 1) { dev += __shfl_down(dev, off, 64); sum += __shfl_down(sum, off, 64); cs += __shfl_down(cs, off, 64); }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[w] = dev; sm[4 + w] = sum; sm[8 + w] = cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int q = 0; q < nw; ++q) { a += sm[q]; b += sm[4 + q]; c += sm[8 + q]; }
+        partial[((int64_t)chunk * K + j) * 2] = a;
+        partial[((int64_t)chunk * K + j) * 2 + 1] = b;
+        partial[(int64_t)2 * K * nchunks + (int64_t)chunk * K + j] = c;
+    }
+}
+
+// statistics (2K doubles) and component sums (K values of T) of the fused kernels above in one launch; a wave per output, the
+// chunk order of finalize_partials_kernel
+template <typename T>
+__global__ void finalize_div_kernel(const double *partial, int nchunks, int K, double *stat_out, T *sum_out, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (e >= 3 * K) return;
+    const int lane = threadIdx.x & 63;
+    const double *src = (e < 2 * K) ? partial + e : partial + (int64_t)2 * K * nchunks + (e - 2 * K);
+    const int stride = (e < 2 * K) ? 2 * K : K;
+    double s = 0.0;
+    for (int c = lane; c < nchunks; c += 64) s += src[(int64_t)c * stride];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+        if (e < 2 * K) stat_out[e] = s;
+        else sum_out[e - 2 * K] = (T)s;
+    }
+}
+
 }  // namespace nmfx

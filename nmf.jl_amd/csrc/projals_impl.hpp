@@ -126,15 +126,19 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     auto factor_under = [&](T *G, T lambda, const char *t1, const char *t2, bool with_potri) {
         HIP_TRY(hipEventRecord(ev_fork, stream));
         HIP_TRY(hipStreamWaitEvent(fstream, ev_fork, 0));
-        std::swap(stream, fstream);
-        potrf_nt = 512;
-        spd_factor(G, lambda, Uinv, t1, t2, done);
-        potrf_nt = 1024;
-        if (with_potri) {            // potri! + copytri! (src/utils.jl:79-80) belong to the factorisation, not to the product
-            EpiStore<T> e1{invA, K, 0, nullptr};
-            gemm<KSTRIDED, KSTRIDED>("gemm_potri", Uinv, K, K, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * K * sizeof(T));
+        {
+            // every launch helper targets `stream`: point it at the side stream for the duration (restored on any exit path)
+            struct Swap {
+                Solver<T> &s;
+                explicit Swap(Solver<T> &s_) : s(s_) { std::swap(s.stream, s.fstream); s.potrf_nt = 512; }
+                ~Swap() { std::swap(s.stream, s.fstream); s.potrf_nt = 1024; }
+            } on_side(*this);
+            spd_factor(G, lambda, Uinv, t1, t2, done);
+            if (with_potri) {            // potri! + copytri! (src/utils.jl:79-80) belong to the factorisation, not to the product
+                EpiStore<T> e1{invA, K, 0, nullptr};
+                gemm<KSTRIDED, KSTRIDED>("gemm_potri", Uinv, K, K, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * K * sizeof(T));
+            }
         }
-        std::swap(stream, fstream);
         HIP_TRY(hipEventRecord(ev_join, fstream));
     };
     if (o.update_H) {
@@ -145,7 +149,7 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
             gram_w_only(Wp, done);                                             // :92 W'W (W is replicated: no exchange)
             factor_under(gramW_p, (T)o.lambda_h, "potrf_WtW", "trtri_WtW", false);   // :92 adddiag!, :94 potrf!
             short_grid = true;
-            wt_times(Wp, X.p, false, done);                                    // :93 H <- W'X
+            try { wt_times(Wp, X.p, false, done); } catch (...) { short_grid = false; throw; }   // :93 H <- W'X
             short_grid = false;
             HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
         } else {
@@ -170,7 +174,7 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
         factor_under(gramH_p, (T)o.lambda_w, "potrf_HHt", "trtri_HHt", true);  // :100 adddiag!, :102 potrf!, potri!, copytri!
         w_blocked = rs;
         short_grid = true;
-        times_ht(X.p, Hp, false, done);                                        // :101 XH'
+        try { times_ht(X.p, Hp, false, done); } catch (...) { short_grid = false; w_blocked = false; throw; }   // :101 XH'
         short_grid = false;
         w_blocked = false;
         if (rs) scatter_w_numerator(o.update_H != 0, done, /*with_tail=*/false);

@@ -128,6 +128,7 @@ template <typename T> class Solver : public SolverBase {
         // NMFX_CHOL_SLOTS=0 turns it off (factorisations between the products, as in round 1).
         if (const char *e = std::getenv("NMFX_CHOL_SLOTS")) chol_slots = std::max(0, std::min(128, std::atoi(e)));
         if (const char *e = std::getenv("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
+        if (const char *e = std::getenv("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
@@ -178,8 +179,8 @@ template <typename T> class Solver : public SolverBase {
         max_gram_slabs = (int)std::max<size_t>((size_t)std::max(s_gw, s_gh), max_pieces) * PIPE_C;
         slabs.alloc(gram_slab_off + (size_t)max_gram_slabs * K * K);
         stat_chunks_w = (int)std::max<int64_t>(1, std::min<int64_t>(64, P / 1024));
-        stat_chunks_h = (int)std::max<int64_t>(1, std::min<int64_t>(256, N / 64));
-        stat_part.alloc((size_t)std::max<int64_t>(std::max(stat_chunks_w, stat_chunks_h), std::max(N, P) / 16) * 2 * K);   // smallk: one partial per 16-wide stripe
+        stat_chunks_h = (int)std::max<int64_t>(1, std::min<int64_t>(1024, N / 16));   // 4 chips' worth of workgroups for the column-chunked passes over H
+        stat_part.alloc((size_t)std::max<int64_t>(std::max(stat_chunks_w, stat_chunks_h), std::max(N, P) / 16) * 3 * K);   // smallk: one partial per 16-wide stripe; multdiv: 3 values per (chunk, component)
         wstat.alloc((size_t)2 * K);
         hstat.alloc((size_t)2 * K);
         svec.alloc((size_t)K);
@@ -900,6 +901,9 @@ template <typename T> class Solver : public SolverBase {
     }
     void enqueue_multmse_smallk(const nmfx_opts &o);
     void enqueue_multdiv(const nmfx_opts &o, long long t);
+    // multdiv on one GPU: the passes behind each numerator product fused (kernels.hpp: div_h_fused_kernel / div_w_fused_kernel);
+    // svec / sH_p then carry sum(W, dims=1) / sum(H, dims=2) of the CURRENT factors from one side's pass to the other's
+    bool div_fused = true, div_sw_valid = false, div_sh_valid = false;
     void enqueue_projals(const nmfx_opts &o, long long t);
     void spd_factor(T *A, T lambda, T *Uinv, const char *tag_potrf, const char *tag_trtri, const int *done);
     void spd_solve_left(const T *Uinv, const T *B, T *Y, T *out, bool clamp, const int *done);

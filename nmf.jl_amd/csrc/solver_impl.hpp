@@ -187,12 +187,33 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
     // gets the same floor here, so a zero column sum can never divide by zero
     const T lam_floor = std::sqrt(std::numeric_limits<T>::epsilon());
     const T lambda_h = std::max((T)o.lambda_h, lam_floor), lambda_w = std::max((T)o.lambda_w, lam_floor);
+    const bool fused = nranks == 1 && div_fused;
     if (o.update_H) {
         const T *Wp = W[wcur].p;
         const T *Ho = H[hcur].p;
         T *Hn = H[hcur ^ 1].p;
         EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                           // :172-174
         gemm_wh("gemm_WH_ratio", Ho, Wp, er, done, qbytes);
+        if (fused) {
+            // single GPU: the slab sum, the scaling, stop_condition's sums and sum(H, dims=2) for the W side in one pass
+            wt_times(Wp, Q.p, false, done, /*keep_slabs=*/true);           // :175
+            if (!div_sw_valid) {                                           // :176 (later iterations: from the W side's pass)
+                timed("colsum_W", 0.0, (double)P * K * sizeof(T), [&] {
+                    hipLaunchKernelGGL(col_sum_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wp, P, P, (int)K, stat_part.p, done);
+                    hipLaunchKernelGGL(finalize_partials_kernel<T>, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, stream, stat_part.p, stat_chunks_w, (int)K,
+                                       (int)K, svec.p, done);
+                });
+            }
+            timed("div_update_H", 0.0, (3.0 + h_num_nslab()) * K * N * sizeof(T), [&] {   // :177-179
+                hipLaunchKernelGGL(div_h_fused_kernel<T>, dim3(stat_chunks_h), dim3(256), 0, stream, Hn, Ho, h_num(), h_num_nslab(), h_stride, svec.p, k, n,
+                                   N, K, (int)K, lambda_h, stat_part.p, done);
+                hipLaunchKernelGGL(finalize_div_kernel<T>, dim3((unsigned)((3 * K + 3) / 4)), dim3(256), 0, stream, stat_part.p, stat_chunks_h, (int)K, hstat.p,
+                                   sH_p, done);
+                HIP_TRY(hipGetLastError());
+            });
+            div_sh_valid = true;
+            hcur ^= 1;
+        } else {
         wt_times(Wp, Q.p, false, done);                                    // :175
         timed("colsum_W", 0.0, (double)P * K * sizeof(T), [&] {            // :176
             hipLaunchKernelGGL(col_sum_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wp, P, P, (int)K,
@@ -206,6 +227,7 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
         });
         stats_h(Hn, Ho, done);
         hcur ^= 1;
+        }
     }
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;
@@ -213,6 +235,27 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
     EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                               // :184-186
     gemm_wh("gemm_WH_ratio", Hp, Wo, er, done, qbytes);
     const bool rs = row_sharded();
+    if (fused) {
+        times_ht(Q.p, Hp, false, done, /*keep_slabs=*/true);               // :187
+        if (!div_sh_valid) {                                               // :188 (update_H = false: H never changes)
+            timed("rowsum_H", 0.0, (double)K * N * sizeof(T), [&] {
+                hipLaunchKernelGGL(row_sum_kernel<T>, dim3(stat_chunks_h), dim3(256), 0, stream, Hp, N, K, (int)K, stat_part.p, done);
+                hipLaunchKernelGGL(finalize_partials_kernel<T>, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, stream, stat_part.p, stat_chunks_h, (int)K, (int)K,
+                                   sH_p, done);
+            });
+            div_sh_valid = true;
+        }
+        timed("div_update_W", 0.0, (3.0 + w_num_nslab()) * P * K * sizeof(T), [&] {   // :189-191
+            hipLaunchKernelGGL(div_w_fused_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wn, Wo, w_num(), w_num_nslab(), w_stride, sH_p, p,
+                               k, P, P, (int)K, lambda_w, stat_part.p, done);
+            hipLaunchKernelGGL(finalize_div_kernel<T>, dim3((unsigned)((3 * K + 3) / 4)), dim3(256), 0, stream, stat_part.p, stat_chunks_w, (int)K, wstat.p,
+                               svec.p, done);
+            HIP_TRY(hipGetLastError());
+        });
+        div_sw_valid = true;
+        wcur ^= 1;
+        return;
+    }
     w_blocked = rs;
     times_ht(Q.p, Hp, false, done);                                        // :187
     w_blocked = false;
@@ -266,6 +309,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     precision = o.precision;
     pipe_pending = false;
     smallk_grams_valid = false;
+    div_sw_valid = div_sh_valid = false;
     rsvd_ready = 0;   // the iteration overwrites the buffers a pending rsvd keeps its Q / B in
     HIP_TRY(hipSetDevice(device));
     std::memset(out, 0, sizeof *out);

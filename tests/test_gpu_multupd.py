@@ -158,3 +158,25 @@ def test_multmse_small_k_path(built, shape, update_H, monkeypatch):
         ro = orc.solve("multmse", X, W0.copy(order="F"), H0.copy(order="F"),
                        orc.Opts(maxiter=12, tol=1e-30, lambda_w=lam, lambda_h=lam, update_H=update_H, track_objective=True))
         assert rel_trace_err(ra.trace, ro.trace) < 1e-5
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(300, 260, 5), (1000, 1500, 70), (513, 2100, 130)])
+@pytest.mark.parametrize("update_H", [True, False])
+def test_multdiv_fused_passes_are_bit_identical(built, T, shape, update_H, monkeypatch):
+    """On one GPU multdiv's slab sum, scaling, stop_condition sums and the other side's divisor run as ONE pass per side
+    (kernels.hpp: div_h_fused_kernel / div_w_fused_kernel) with the chunking and arithmetic of the separate kernels, which the
+    multi-GPU paths still use (NMFX_DIV_FUSED=0 selects them here): every bit of W, H, the trace and the iteration count agrees."""
+    p, n, k = shape
+    X, W0, H0 = planted(p, n, k, T, seed=n + k)
+    alg = nmfx.MultUpdate(T, obj="div", maxiter=9, tol=1e-30, update_H=update_H)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NMFX_DIV_FUSED", mode)
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        runs[mode] = (nmfx.solve(alg, X, W, H, track_objective=True), W, H)
+    ra, rb = runs["1"][0], runs["0"][0]
+    assert ra.niters == rb.niters == 9
+    assert np.array_equal(ra.trace, rb.trace)
+    assert np.array_equal(runs["1"][1], runs["0"][1]) and np.array_equal(runs["1"][2], runs["0"][2])
+    assert np.array_equal(ra.info["relchange"][1:], rb.info["relchange"][1:])

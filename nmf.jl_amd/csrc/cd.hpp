@@ -212,14 +212,52 @@ template <typename T> __device__ __forceinline__ void greedy_sd(T w, T g, T prr,
     d = op_sub(op_mul(-g, s), op_mul(op_mul((T)0.5, prr), op_mul(s, s)));
 }
 
-// (value, index) arg-max over the wave with first-index tie break; invalid slots carry index INT_MAX and value -inf
+// (value, index) arg-max over the wave with first-index tie break; invalid slots carry index INT_MAX and value -inf.
+// DPP row shifts + row broadcasts (an inclusive scan: the total lands in lane 63) instead of 12 ds_bpermute round trips through
+// the LDS crossbar -- this reduction sits on the dependency chain of EVERY greedy step.  The result is wave-uniform (SGPRs): the
+// step's control flow, the row of P it loads and the lane that owns S(q) are scalar from here on.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_mov(int ident, int v) {
+    return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ void argmax_dpp_step(float &v, int &idx) {
+    const float ov = __int_as_float(dpp_mov<CTRL, ROW_MASK>(__float_as_int(-INFINITY), __float_as_int(v)));
+    const int oi = dpp_mov<CTRL, ROW_MASK>(0x7fffffff, idx);
+    const bool take = ov > v || (ov == v && oi < idx);
+    v = take ? ov : v;
+    idx = take ? oi : idx;
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ void argmax_dpp_step(double &v, int &idx) {
+    const long long ident = __double_as_longlong(-INFINITY), b = __double_as_longlong(v);
+    const int lo = dpp_mov<CTRL, ROW_MASK>((int)(ident & 0xffffffffll), (int)(b & 0xffffffffll));
+    const int hi = dpp_mov<CTRL, ROW_MASK>((int)(ident >> 32), (int)(b >> 32));
+    const double ov = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    const int oi = dpp_mov<CTRL, ROW_MASK>(0x7fffffff, idx);
+    const bool take = ov > v || (ov == v && oi < idx);
+    v = take ? ov : v;
+    idx = take ? oi : idx;
+}
+// v of lane `l` (wave-uniform l): v_readlane with a scalar lane select
+__device__ __forceinline__ float lane_read(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_read(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ double lane63(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 template <typename T> __device__ __forceinline__ void wave_argmax(T &v, int &idx) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const T ov = __shfl_xor(v, off, 64);
-        const int oi = __shfl_xor(idx, off, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    argmax_dpp_step<0x111, 0xf>(v, idx);     // row_shr:1
+    argmax_dpp_step<0x112, 0xf>(v, idx);     // row_shr:2
+    argmax_dpp_step<0x114, 0xf>(v, idx);     // row_shr:4
+    argmax_dpp_step<0x118, 0xf>(v, idx);     // row_shr:8   -> lane 15 of every row holds the row's result
+    argmax_dpp_step<0x142, 0xa>(v, idx);     // row_bcast:15 into rows 1 and 3
+    argmax_dpp_step<0x143, 0xc>(v, idx);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
+    v = lane63(v);
+    idx = __builtin_amdgcn_readlane(idx, 63);
 }
 
 template <typename T, int KMAX> struct GreedyRow {
@@ -243,7 +281,9 @@ template <typename T, int KMAX> struct GreedyRow {
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
             const int c = lane + 64 * m;
-            if ((m < km) && (c < k) && (d[m] > best)) { best = d[m]; q = c; }   // ascending c per lane: first index wins locally
+            const bool take = (m < km) && (c < k) && (d[m] > best);               // ascending c per lane: first index wins locally
+            best = take ? d[m] : best;
+            q = take ? c : q;
         }
         wave_argmax(best, q);
     }
@@ -291,14 +331,10 @@ template <typename T> __global__ void greedy_pinit_reduce_kernel(const T *part, 
     }
 }
 
-template <typename T, int KMAX>
-__global__ __launch_bounds__(256) void greedy_sweep_kernel(SampleView<const T> Wold, SampleView<T> Wout, SampleView<const T> G,
-                                                           const T *__restrict__ P, int64_t ldp, int64_t nsamples, int k, T lambda,
-                                                           T epsT, const T *pinit, long long *steps_total, const int *done) {
-    NMFX_DONE_GUARD(done);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
-    if (i >= nsamples) return;
+// The sweep of one sample row by one wave; `fetch(q, m)` returns P(q, lane + 64 m) (q wave-uniform).
+template <typename T, int KMAX, typename Fetch>
+__device__ __forceinline__ void greedy_sweep_row(SampleView<const T> Wold, SampleView<T> Wout, SampleView<const T> G, const T *__restrict__ P, int64_t ldp,
+                                                 int64_t i, int k, T lambda, T epsT, const T *pinit, long long *steps_total, int lane, Fetch fetch) {
     const int km = (k + 63) / 64;
     GreedyRow<T, KMAX> row;
     row.load(Wold, G, P, ldp, i, k, km, lane, lambda, epsT);
@@ -311,20 +347,18 @@ __global__ __launch_bounds__(256) void greedy_sweep_kernel(SampleView<const T> W
     const long long max_steps = (long long)k * k;
     long long step = 0;
     for (; step < max_steps; ++step) {
-        if (dq < thresh) break;
+        if (dq < thresh) break;                       // wave-uniform (dq, q come out of wave_argmax as scalars)
         // S(q): owned by lane q % 64, slot q / 64
         const int ql = q & 63, qm = q >> 6;
-        T sq_owner = (T)0;
+        T sq_owner = row.s[0];
 #pragma unroll
-        for (int m = 0; m < KMAX; ++m) if (m == qm) sq_owner = row.s[m];
-        const T sq = __shfl(sq_owner, ql, 64);
+        for (int m = 1; m < KMAX; ++m) sq_owner = (m == qm) ? row.s[m] : sq_owner;
+        const T sq = lane_read(sq_owner, ql);
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
-            const int c = lane + 64 * m;
-            const bool ok = (m < km) && (c < k);
-            if (m == qm && lane == ql) wnew[m] = op_add(wnew[m], sq);
-            if (ok) {
-                const T pq = P[(int64_t)q * ldp + c];
+            wnew[m] = (m == qm && lane == ql) ? op_add(wnew[m], sq) : wnew[m];
+            if (m < km) {                             // uniform; lanes c in [k, K) of a live slot read P's zero padding: G stays put
+                const T pq = fetch(q, m);
                 row.g[m] = op_add(row.g[m], op_mul(sq, pq));
                 greedy_sd(row.w[m], row.g[m], row.prr[m], epsT, row.s[m], row.d[m]);
             }
@@ -342,6 +376,23 @@ __global__ __launch_bounds__(256) void greedy_sweep_kernel(SampleView<const T> W
         }
     }
 }
+
+template <typename T, int KMAX>
+__global__ __launch_bounds__(256) void greedy_sweep_kernel(SampleView<const T> Wold, SampleView<T> Wout, SampleView<const T> G,
+                                                           const T *__restrict__ P, int64_t ldp, int64_t nsamples, int k, T lambda,
+                                                           T epsT, const T *pinit, long long *steps_total, const int *done) {
+    NMFX_DONE_GUARD(done);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= nsamples) return;
+    greedy_sweep_row<T, KMAX>(Wold, Wout, G, P, ldp, i, k, lambda, epsT, pinit, steps_total, lane,
+                              [&](int q, int m) { return P[(int64_t)q * ldp + lane + 64 * m]; });
+}
+
+// (Measured and dropped: the same sweep with the packed upper triangle of P -- 131.6 KB for K = 256 in Float32 -- resident in LDS,
+// 16 rows per workgroup sharing it: bit-identical, and SLOWER, 10.2 against 7.8 ms per iteration at 16384^2, k = 256, and 0.73
+// against 0.68 ms even with one row per CU, where only the dependency chain counts: the L2 round trip for the row of P is not
+// what the chain is made of -- the arg-max reduction and the four IEEE divisions of every step are.)
 
 // sum_i |x_i| partials (norm(W, 1), greedycd.jl:81-86): Float64 accumulation, one partial per block
 template <typename T> __global__ void sumabs_kernel(const T *x, int64_t count, double *partial, const int *done) {

@@ -184,3 +184,4 @@ def test_cd_shuffle_reference_kat(built):
         H = Hg.copy(order="F")
         nmfx.solve(nmfx.CoordinateDescent(T, alpha=1e-4, l1ratio=0.5, shuffle=True, maxiter=1000, tol=1e-9), X, W, H)
         assert np.allclose(X, W @ H, atol=1e-2, rtol=0)
+

@@ -143,13 +143,13 @@ def test_projals_large_k(built, T, k):
 
 
 @pytest.mark.parametrize("T", [np.float64, np.float32])
-def test_projals_factorisation_under_the_products(built, T, monkeypatch):
+@pytest.mark.parametrize("shape", [(4096, 4096, 256), (2048, 8192, 128)])
+def test_projals_factorisation_under_the_products(built, T, shape, monkeypatch):
     """At 4096 x 4096, k = 256 each big product is exactly one wave of 2 blocks per CU (64 tiles x 8 splits = 512 items), so the
     default path launches it 8 blocks short (the missing items ride as tail pieces) and runs the Cholesky / inverse on the side
     stream under it.  NMFX_CHOL_SLOTS=0 is the serial order of round 1.  Same algorithm, different
     summation order inside W'X / XH' for the tail pieces: the two trajectories agree to rounding, and with the oracle."""
-    p = n = 4096
-    k = 256
+    p, n, k = shape      # (2048, 8192, 128): 64 x 8 and 16 x 32 (tile, split) items = 512 each, one tile per line of the leftover
     X, W0, H0 = uniform(p, n, k, T, seed=77)
     lam = 0.5
     alg = nmfx.ProjectedALS(T, maxiter=4, tol=1e-30, lambda_w=lam, lambda_h=lam)

@@ -554,7 +554,11 @@ template <typename T> class Solver : public SolverBase {
         const bool small_k = (Kdim <= 1024) && splits == 1 && seg.tail_tiles == 0 &&
                              (prefer_half || (R / 128) * (C / 128) < 2 * (int64_t)num_cu);
         timed(name, flops, bytes, [&] {
-            if (small_k && R % 64 == 0 && C % 64 == 0 && std::max(R / 64 * (C / 128), R / 128 * (C / 64)) < 2 * (int64_t)num_cu) {
+            // heavy epilogues (update / gradient / line search) also when the half-size tiles make exactly ONE resident wave of two
+            // blocks per CU: those run prologue, 16 k-tiles and epilogue in lockstep; four quarter-size blocks per CU overlap one
+            // block's epilogue with another's k-loop (update products at 16384 x 256 x 256: 45 -> 38 us)
+            const int64_t half_blocks = std::max(R / 64 * (C / 128), R / 128 * (C / 64));
+            if (small_k && R % 64 == 0 && C % 64 == 0 && (half_blocks < 2 * (int64_t)num_cu || (Epi::HEAVY && half_blocks == 2 * (int64_t)num_cu))) {
                 // even the half-size tiles leave CUs idle (e.g. the 4096 x 512 projected-gradient products of a C5 shard:
                 // 256 blocks): quarter-size tiles, 4 waves of 32 x 32
                 g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 64);

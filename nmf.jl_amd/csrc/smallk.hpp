@@ -86,15 +86,6 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = wave & 3, half = wave >> 2, i = lane & 15, kg = lane >> 4;
     const int stripe = smallk_stripe();
     const int64_t c0 = (int64_t)stripe * 16;
-    // operands of the epilogue (independent of the main loop): gramW and the old stripe
-    for (int e = tid; e < 64 * 16; e += SMALLK_THREADS) {
-        const int a = e >> 4, c4 = e & 15;
-        *reinterpret_cast<smallk_v4 *>(Gs + a * 80 + 4 * c4) = *reinterpret_cast<const smallk_v4 *>(gramW + a * 64 + 4 * c4);
-    }
-    if (tid < 256) {
-        const int col = tid >> 4, a4 = tid & 15;
-        *reinterpret_cast<smallk_v4 *>(Hs + col * 68 + 4 * a4) = *reinterpret_cast<const smallk_v4 *>(Ho + (c0 + col) * 64 + 4 * a4);
-    }
     // staging: W stage = 1024 float4 (2 per thread), X stage = 256 float4 (threads 0..255)
     const int wc0 = tid >> 4, wp4 = tid & 15;
     const float *wsrc0 = W + (int64_t)wc0 * ldx + 4 * wp4, *wsrc1 = W + (int64_t)(wc0 + 32) * ldx + 4 * wp4;
@@ -112,9 +103,21 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X
     };
     const int T = (int)(P / 64);      // even: P is a multiple of 256
     gload(0, 0);
-    lstore(0, 0);
-    gload(0, 64);
-    if (T > 2) gload(1, 128);
+    // operands of the epilogue (independent of the main loop): gramW and the old stripe -- requested behind the first stage so
+    // that the cold round trips overlap
+    {
+        const int a = tid >> 4, c4 = tid & 15;
+        const smallk_v4 g0 = *reinterpret_cast<const smallk_v4 *>(gramW + a * 64 + 4 * c4);
+        const smallk_v4 g1 = *reinterpret_cast<const smallk_v4 *>(gramW + (a + 32) * 64 + 4 * c4);
+        smallk_v4 h0 = {0.f, 0.f, 0.f, 0.f};
+        if (tid < 256) h0 = *reinterpret_cast<const smallk_v4 *>(Ho + (c0 + (tid >> 4)) * 64 + 4 * (tid & 15));
+        lstore(0, 0);
+        gload(0, 64);
+        if (T > 2) gload(1, 128);
+        *reinterpret_cast<smallk_v4 *>(Gs + a * 80 + 4 * c4) = g0;
+        *reinterpret_cast<smallk_v4 *>(Gs + (a + 32) * 80 + 4 * c4) = g1;
+        if (tid < 256) *reinterpret_cast<smallk_v4 *>(Hs + (tid >> 4) * 68 + 4 * (tid & 15)) = h0;
+    }
     __syncthreads();
     smallk_v4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     auto step = [&](int t, auto SET) {
@@ -191,14 +194,6 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = wave & 3, half = wave >> 2, i = lane & 15, kg = lane >> 4;
     const int stripe = smallk_stripe();
     const int64_t r0 = (int64_t)stripe * 16;
-    for (int e = tid; e < 64 * 16; e += SMALLK_THREADS) {
-        const int a = e >> 4, c4 = e & 15;
-        *reinterpret_cast<smallk_v4 *>(Gs + a * 80 + 4 * c4) = *reinterpret_cast<const smallk_v4 *>(gramH + a * 64 + 4 * c4);
-    }
-    if (tid < 256) {
-        const int a = tid >> 2, r4 = tid & 3;
-        *reinterpret_cast<smallk_v4 *>(Ws + a * 16 + 4 * r4) = *reinterpret_cast<const smallk_v4 *>(Wo + r0 + 4 * r4 + (int64_t)a * ldx);
-    }
     // staging: H stage = 64 cols x 64 comps = 1024 float4 (2 per thread), X stage = 64 cols x 16 rows = 256 float4
     const int hc0 = tid >> 4, h4 = tid & 15;
     const float *hsrc0 = H + (int64_t)hc0 * 64 + 4 * h4, *hsrc1 = H + (int64_t)(hc0 + 32) * 64 + 4 * h4;
@@ -216,9 +211,19 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X
     };
     const int T = (int)(N / 64);      // even: N is a multiple of 256
     gload(0, 0);
-    lstore(0, 0);
-    gload(0, 64);
-    if (T > 2) gload(1, 128);
+    {
+        const int a = tid >> 4, c4 = tid & 15;
+        const smallk_v4 g0 = *reinterpret_cast<const smallk_v4 *>(gramH + a * 64 + 4 * c4);
+        const smallk_v4 g1 = *reinterpret_cast<const smallk_v4 *>(gramH + (a + 32) * 64 + 4 * c4);
+        smallk_v4 w0 = {0.f, 0.f, 0.f, 0.f};
+        if (tid < 256) w0 = *reinterpret_cast<const smallk_v4 *>(Wo + r0 + 4 * (tid & 3) + (int64_t)(tid >> 2) * ldx);
+        lstore(0, 0);
+        gload(0, 64);
+        if (T > 2) gload(1, 128);
+        *reinterpret_cast<smallk_v4 *>(Gs + a * 80 + 4 * c4) = g0;
+        *reinterpret_cast<smallk_v4 *>(Gs + (a + 32) * 80 + 4 * c4) = g1;
+        if (tid < 256) *reinterpret_cast<smallk_v4 *>(Ws + (tid >> 2) * 16 + 4 * (tid & 3)) = w0;
+    }
     __syncthreads();
     smallk_v4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     auto step = [&](int t, auto SET) {

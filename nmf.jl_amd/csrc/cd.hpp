@@ -205,8 +205,17 @@ __global__ __launch_bounds__(256) void cd_sweep16_kernel(SampleView<const T> Wol
 // recompute S, D;  q = argmax.   Finally W = max(W + Wnew, 0) (:160-161).
 // G arrives as W*P - Z from the GEMM; + lambda (:113-115) is applied on load.
 // ---------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ void greedy_sd(T w, T g, T prr, T epsT, T &s, T &d) {
-    T t = op_sub(w, g / op_add(epsT, prr));
+// g / den, correctly rounded, with den loop-invariant.  Float32: (float)((double)g * (1.0 / den)) IS the correctly rounded quotient --
+// the Float64 product is within 2^-52 of g / den, while a quotient of two 24-bit significands that is not itself a float stays at
+// least 2^-49 (relative) away from every rounding boundary of the float grid (g - m den is a non-zero multiple of the last place
+// of the 49-bit product m den), so the final rounding cannot go the other way; infinities, NaN and signed zeros behave like the
+// division (tests/test_host_api.py::test_greedy_division_identity checks 4e6 operand pairs incl. adversarial ones).  3 operations on
+// the greedy step's dependency chain instead of the ~12 of v_div_scale / v_rcp / fma x5 / v_div_fmas / v_div_fixup.  Float64 divides.
+__device__ __forceinline__ float greedy_div(float g, float, double rden) { return (float)((double)g * rden); }
+__device__ __forceinline__ double greedy_div(double g, double den, double) { return g / den; }
+
+template <typename T> __device__ __forceinline__ void greedy_sd(T w, T g, T prr, T den, double rden, T &s, T &d) {
+    T t = op_sub(w, greedy_div(g, den, rden));
     t = (t > (T)0) ? t : ((t != t) ? t : (T)0);
     s = op_sub(t, w);
     d = op_sub(op_mul(-g, s), op_mul(op_mul((T)0.5, prr), op_mul(s, s)));
@@ -259,9 +268,31 @@ template <typename T> __device__ __forceinline__ void wave_argmax(T &v, int &idx
     v = lane63(v);
     idx = __builtin_amdgcn_readlane(idx, 63);
 }
+// the value half alone (v never NaN: callers only feed values that compared greater than something)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ void max_dpp_step(float &v) {
+    const float ov = __int_as_float(dpp_mov<CTRL, ROW_MASK>(__float_as_int(-INFINITY), __float_as_int(v)));
+    v = (ov > v) ? ov : v;
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ void max_dpp_step(double &v) {
+    const long long ident = __double_as_longlong(-INFINITY), b = __double_as_longlong(v);
+    const int lo = dpp_mov<CTRL, ROW_MASK>((int)(ident & 0xffffffffll), (int)(b & 0xffffffffll));
+    const int hi = dpp_mov<CTRL, ROW_MASK>((int)(ident >> 32), (int)(b >> 32));
+    const double ov = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    v = (ov > v) ? ov : v;
+}
+template <typename T> __device__ __forceinline__ T wave_max_uniform(T v) {
+    max_dpp_step<0x111, 0xf>(v);
+    max_dpp_step<0x112, 0xf>(v);
+    max_dpp_step<0x114, 0xf>(v);
+    max_dpp_step<0x118, 0xf>(v);
+    max_dpp_step<0x142, 0xa>(v);
+    max_dpp_step<0x143, 0xc>(v);
+    return lane63(v);
+}
 
 template <typename T, int KMAX> struct GreedyRow {
-    T w[KMAX], g[KMAX], s[KMAX], d[KMAX], prr[KMAX];
+    T w[KMAX], g[KMAX], s[KMAX], d[KMAX], prr[KMAX], den[KMAX];   // den = eps + P(r, r) (greedycd.jl:121, :151)
+    double rden[KMAX];                                              // 1 / den (Float32 rows only; dead code for Float64)
     __device__ __forceinline__ void load(const SampleView<const T> &W, const SampleView<const T> &G, const T *P, int64_t ldp,
                                          int64_t i, int k, int km, int lane, T lambda, T epsT) {
 #pragma unroll
@@ -272,20 +303,30 @@ template <typename T, int KMAX> struct GreedyRow {
             g[m] = ok ? G.at(i, c) : (T)0;
             if (ok && lambda > (T)0) g[m] = op_add(g[m], lambda);
             prr[m] = ok ? P[(int64_t)c * ldp + c] : (T)1;
-            greedy_sd(w[m], g[m], prr[m], epsT, s[m], d[m]);
+            den[m] = op_add(epsT, prr[m]);
+            rden[m] = 1.0 / (double)den[m];
+            greedy_sd(w[m], g[m], prr[m], den[m], rden[m], s[m], d[m]);
         }
     }
+    // arg-max of D with the first index on ties: the VALUE by a DPP max reduction (2 operations per step instead of the 7 of a
+    // (value, index) reduction -- this sits on every greedy step's dependency chain), then the index from wave ballots: slots are
+    // visited in ascending m and a slot's lowest set lane is its smallest component index c = lane + 64 m
     __device__ __forceinline__ void argmax(int k, int km, int lane, T &best, int &q) const {
         best = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) {
+            const int c = lane + 64 * m;
+            const bool take = (m < km) && (c < k) && (d[m] > best);
+            best = take ? d[m] : best;
+        }
+        best = wave_max_uniform(best);
         q = 0x7fffffff;
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
             const int c = lane + 64 * m;
-            const bool take = (m < km) && (c < k) && (d[m] > best);               // ascending c per lane: first index wins locally
-            best = take ? d[m] : best;
-            q = take ? c : q;
+            const unsigned long long hit = __ballot((m < km) && (c < k) && (d[m] == best));
+            if (hit != 0ull && q == 0x7fffffff) q = 64 * m + (int)__builtin_ctzll(hit);
         }
-        wave_argmax(best, q);
     }
 };
 
@@ -360,7 +401,7 @@ __device__ __forceinline__ void greedy_sweep_row(SampleView<const T> Wold, Sampl
             if (m < km) {                             // uniform; lanes c in [k, K) of a live slot read P's zero padding: G stays put
                 const T pq = fetch(q, m);
                 row.g[m] = op_add(row.g[m], op_mul(sq, pq));
-                greedy_sd(row.w[m], row.g[m], row.prr[m], epsT, row.s[m], row.d[m]);
+                greedy_sd(row.w[m], row.g[m], row.prr[m], row.den[m], row.rden[m], row.s[m], row.d[m]);
             }
         }
         row.argmax(k, km, lane, dq, q);

@@ -101,3 +101,24 @@ def test_randinit_properties():
     assert H.shape == (3, 11) and (H >= 0).all() and (H < 1).all()
     _, Hz = nmfx.randinit(X, 3, zeroh=True)
     assert not Hz.any()
+
+
+def test_greedy_division_identity():
+    """csrc/cd.hpp::greedy_div replaces the Float32 division on GreedyCD's step chain by (float)((double)g * (1.0 / den)): that IS
+    the correctly rounded quotient (argument in the source).  Checked here on wide-range random operands and on operands built to
+    put the quotient next to a rounding boundary of the float grid."""
+    rng = np.random.default_rng(0)
+    n = 2_000_000
+    g = (rng.standard_normal(n) * np.exp(rng.uniform(-40, 40, n))).astype(np.float32)
+    den = np.exp(rng.uniform(-30, 30, n)).astype(np.float32)
+    with np.errstate(over="ignore", under="ignore"):
+        q1 = g / den
+        q2 = (g.astype(np.float64) * (1.0 / den.astype(np.float64))).astype(np.float32)
+    assert np.array_equal(q1.view(np.uint32), q2.view(np.uint32))
+    den = (1 + rng.random(n)).astype(np.float32)
+    qf = (1 + rng.random(n)).astype(np.float32)
+    mid = qf.astype(np.float64) + np.spacing(qf).astype(np.float64) / 2
+    g = (mid * den.astype(np.float64)).astype(np.float32)          # the float nearest to (midpoint of two floats) * den
+    q1 = g / den
+    q2 = (g.astype(np.float64) * (1.0 / den.astype(np.float64))).astype(np.float32)
+    assert np.array_equal(q1.view(np.uint32), q2.view(np.uint32))

@@ -24,7 +24,7 @@ template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o)
         if (o.update_H) {
             const T *Ho = H[hcur].p;
             T *Hn = H[hcur ^ 1].p;
-            timed("smallk_H", 2.0 * P * N * K + 2.0 * K * K * N * 2, (double)(P * N + P * K * (N / 16) / 1 + 2 * K * N) * sizeof(T), [&] {
+            timed("smallk_H", 2.0 * P * N * K + 2.0 * K * K * N * 2, (double)(P * N + P * K + 2 * K * N) * sizeof(T), [&] {
                 hipLaunchKernelGGL(smallk_h_kernel, dim3((unsigned)stripes_h), dim3(SMALLK_THREADS), SMALLK_H_LDS * 4, stream, X.p, P, P, W[wcur].p, gramW_p,
                                    Ho, Hn, (float)o.lambda_h, (float)o.delta, smallk_slabs.p, stat_part.p, done);
                 HIP_TRY(hipGetLastError());

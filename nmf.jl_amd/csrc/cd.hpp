@@ -39,12 +39,32 @@ template <typename T> __device__ __forceinline__ T wave_max(T v) {
 
 // exactly-rounded single operations (no fused multiply-add contraction): the greedy sweep restates the reference's
 // expressions operation by operation
-__device__ __forceinline__ float op_mul(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ double op_mul(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ float op_add(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ double op_add(double a, double b) { return __dadd_rn(a, b); }
-__device__ __forceinline__ float op_sub(float a, float b) { return __fsub_rn(a, b); }
-__device__ __forceinline__ double op_sub(double a, double b) { return __dsub_rn(a, b); }
+// (HIP's __fmul_rn / __fadd_rn are plain `*` / `+`, which -ffp-contract=fast fuses across the call: the `contract(off)` pragma
+// is what keeps  G(r) += S(q) P(q, r)  a rounded product followed by a rounded sum, as in the reference.)
+__device__ __forceinline__ float op_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double op_mul(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float op_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double op_add(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float op_sub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ double op_sub(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
 
 // shuffle = true (src/coorddesc.jl:130-131): sweeping the components in the order perm[0], perm[1], ... is the in-order sweep of
 // the problem with its components renamed -- W'(:, s) = W(:, perm[s]), Z'(:, s) = Z(:, perm[s]), P'(a, b) = P(perm[a], perm[b]) --

@@ -241,29 +241,11 @@ template <typename T> __device__ __forceinline__ void greedy_sd(T w, T g, T prr,
     d = op_sub(op_mul(-g, s), op_mul(op_mul((T)0.5, prr), op_mul(s, s)));
 }
 
-// (value, index) arg-max over the wave with first-index tie break; invalid slots carry index INT_MAX and value -inf.
-// DPP row shifts + row broadcasts (an inclusive scan: the total lands in lane 63) instead of 12 ds_bpermute round trips through
-// the LDS crossbar -- this reduction sits on the dependency chain of EVERY greedy step.  The result is wave-uniform (SGPRs): the
-// step's control flow, the row of P it loads and the lane that owns S(q) are scalar from here on.
+// Wave-wide maximum by DPP row shifts + row broadcasts (an inclusive scan: the total lands in lane 63) instead of ds_bpermute round
+// trips through the LDS crossbar -- this reduction sits on the dependency chain of EVERY greedy step.  The result is wave-uniform
+// (SGPRs): the step's control flow, the row of P it loads and the lane that owns S(q) are scalar from here on.
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_mov(int ident, int v) {
     return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xf, false);
-}
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ void argmax_dpp_step(float &v, int &idx) {
-    const float ov = __int_as_float(dpp_mov<CTRL, ROW_MASK>(__float_as_int(-INFINITY), __float_as_int(v)));
-    const int oi = dpp_mov<CTRL, ROW_MASK>(0x7fffffff, idx);
-    const bool take = ov > v || (ov == v && oi < idx);
-    v = take ? ov : v;
-    idx = take ? oi : idx;
-}
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ void argmax_dpp_step(double &v, int &idx) {
-    const long long ident = __double_as_longlong(-INFINITY), b = __double_as_longlong(v);
-    const int lo = dpp_mov<CTRL, ROW_MASK>((int)(ident & 0xffffffffll), (int)(b & 0xffffffffll));
-    const int hi = dpp_mov<CTRL, ROW_MASK>((int)(ident >> 32), (int)(b >> 32));
-    const double ov = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-    const int oi = dpp_mov<CTRL, ROW_MASK>(0x7fffffff, idx);
-    const bool take = ov > v || (ov == v && oi < idx);
-    v = take ? ov : v;
-    idx = take ? oi : idx;
 }
 // v of lane `l` (wave-uniform l): v_readlane with a scalar lane select
 __device__ __forceinline__ float lane_read(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -278,17 +260,7 @@ __device__ __forceinline__ double lane63(double v) {
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-template <typename T> __device__ __forceinline__ void wave_argmax(T &v, int &idx) {
-    argmax_dpp_step<0x111, 0xf>(v, idx);     // row_shr:1
-    argmax_dpp_step<0x112, 0xf>(v, idx);     // row_shr:2
-    argmax_dpp_step<0x114, 0xf>(v, idx);     // row_shr:4
-    argmax_dpp_step<0x118, 0xf>(v, idx);     // row_shr:8   -> lane 15 of every row holds the row's result
-    argmax_dpp_step<0x142, 0xa>(v, idx);     // row_bcast:15 into rows 1 and 3
-    argmax_dpp_step<0x143, 0xc>(v, idx);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
-    v = lane63(v);
-    idx = __builtin_amdgcn_readlane(idx, 63);
-}
-// the value half alone (v never NaN: callers only feed values that compared greater than something)
+// (v never NaN: callers only feed values that compared greater than something)
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ void max_dpp_step(float &v) {
     const float ov = __int_as_float(dpp_mov<CTRL, ROW_MASK>(__float_as_int(-INFINITY), __float_as_int(v)));
     v = (ov > v) ? ov : v;

@@ -263,8 +263,9 @@ def main():
         if shards != world:
             out["sim_ranks"] = shards
             out["metric"] += f"_SIMULATED_rank0_of_{shards}_compute_only"
-        if world == 1 and shards == 1 and not a.no_cpu_baseline and a.alg == "multmse":
-            out["cpu_baseline"] = cpu_baseline(p, n, k, T, Xt, W0, H0, a.cpu_sample_cols)
+        if world == 1 and shards == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = (cpu_baseline(p, n, k, T, Xt, W0, H0, a.cpu_sample_cols) if a.alg == "multmse" else
+                                   cpu_baseline_generic(a.alg, p, n, k, T, Xt, W0, H0, a.cpu_sample_cols, lam, a.maxsubiter))
         if a.alg == "greedycd":
             out["greedy_steps_per_step"] = res.inner_iters / a.steps
         if a.alg == "alspgrad":
@@ -315,6 +316,37 @@ def cpu_baseline(p, n, k, T, Xt, W0, H0, ns):
            "gflops_reference_equiv": round(12.0 * p * n * k / t_iter_full / 1e9, 1), "blas": blas}
     out["julia_reference"] = julia_reference(p, ns, k, T)
     return out
+
+
+def cpu_baseline_generic(alg, p, n, k, T, Xt, W0, H0, ns, lam, maxsubiter):
+    """The other algorithms: NMF.solve! of the NumPy restatement on the first `ns` columns, timed as (3 iterations) - (1 iteration)
+    so that prepare_state and the final objective cancel; scaled by n / ns.  A slow first run (> 20 s) is reported as it is."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nmf_oracle as orc
+    ns = min(ns, n)
+    Xs = np.asfortranarray(Xt[:ns, :].cpu().numpy().T)
+    tiny = float(np.finfo(T).tiny)
+
+    def run(iters):
+        Ws, Hs = W0.copy(order="F"), np.asfortranarray(H0[:, :ns].copy())
+        o = orc.Opts(maxiter=iters, tol=tiny, lambda_w=lam, lambda_h=lam)
+        if hasattr(o, "maxsubiter"):
+            o.maxsubiter = maxsubiter
+        t0 = time.perf_counter()
+        orc.solve(alg, Xs, Ws, Hs, o)
+        return time.perf_counter() - t0
+
+    t1 = run(1)
+    if t1 > 20.0:
+        t_iter, how = t1, "ONE outer iteration incl. prepare_state and the final objective (a second run would exceed the time bound)"
+    else:
+        t3 = run(3)
+        t_iter, how = max((t3 - t1) / 2.0, 1e-9), "(3 iterations) - (1 iteration) over 2: prepare_state and the final objective cancel"
+    t_full = t_iter * (n / ns)
+    return {"value": round(1.0 / t_full, 5), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"first {ns} of {n} columns of the same X = {ns / n:.4f} of the workload (p={p}, k={k}); NMF.solve!({alg}) of "
+                      f"oracle/nmf_oracle.py, {how}; OpenBLAS threads = all cores; time scaled by n/{ns}",
+            "seconds_per_iter_full_est": round(t_full, 3)}
 
 
 def julia_reference(p, ns, k, T):

@@ -156,7 +156,7 @@ def main():
 
     if a.warmup > 0:
         ctx.iterate(algid, opts(a.warmup))
-    # hipEvent pairs on the solver stream around the dominant GEMM launches (1 in 4 sampled: a pair costs ~10 us)
+    # hipEvent pairs on the solver stream around the dominant GEMM launches (1 in 8 sampled: a pair costs ~10 us)
     ctx.profile_enable(0 if a.no_events else (1 if a.all_events else 2))
     barrier()
     t0 = time.perf_counter()

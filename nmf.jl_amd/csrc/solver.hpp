@@ -496,8 +496,8 @@ template <typename T> class Solver : public SolverBase {
     template <typename F> void timed(const char *name, double flops, double bytes, F &&launch) {
         if (!profiling) { launch(); return; }
         // mode 2: only the products that carry the iteration's flops (the p*n*k ones, not the k x k x n Gram / update products),
-        // every 4th launch of each
-        if (profiling == 2 && (flops < (double)P * (double)N * (double)K || ((prof_seen[name]++) & 3) != 0)) { launch(); return; }
+        // every 8th launch of each
+        if (profiling == 2 && (flops < (double)P * (double)N * (double)K || ((prof_seen[name]++) & 7) != 0)) { launch(); return; }
         if (ev_used == (int)ev_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));

@@ -443,7 +443,7 @@ class Context:
         self._ck(self.lib.nmfx_comm_set_mode(self.h, {"row_sharded": L.COMM_ROW_SHARDED, "replicated_w": L.COMM_REPLICATED_W, "pipelined": L.COMM_PIPELINED}[mode]))
 
     def profile_enable(self, mode=1):
-        """0 off, 1 every launch (slow), 2 dominant GEMMs sampled 1-in-4 (bench roofline)."""
+        """0 off, 1 every launch (slow), 2 dominant GEMMs sampled 1-in-8 (bench roofline)."""
         self._ck(self.lib.nmfx_profile_enable(self.h, int(mode)))
 
     def profile_get(self):

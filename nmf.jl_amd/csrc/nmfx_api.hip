@@ -54,7 +54,7 @@ template <typename F> static int guarded(nmfx_ctx *ctx, F &&f) {
 
 extern "C" {
 
-const char *nmfx_version(void) { return "nmfx 0.1 (gfx950, hand-written HIP/MFMA)"; }
+const char *nmfx_version(void) { return "nmfx 0.2 (gfx950, hand-written HIP/MFMA)"; }
 
 const char *nmfx_last_error(const nmfx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 

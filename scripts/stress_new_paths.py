@@ -1,0 +1,41 @@
+"""Randomised sweep over the round-2 paths (development aid, not a test): small-k multmse, fused multdiv, ProjectedALS under the
+products, GreedyCD -- device against the NumPy oracle on random shapes, and default path against its fallback where one exists."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import conftest  # noqa: F401
+import numpy as np
+import nmf_oracle as orc
+import nmfx
+from problems import planted, rel_trace_err
+
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+bad = 0
+t_end = time.time() + float(os.environ.get("SECONDS", "240"))
+n_cases = 0
+while time.time() < t_end:
+    alg = os.environ.get("ALG") or rng.choice(["multmse", "multdiv", "projals", "greedycd"])
+    T = np.float32 if (alg == "multmse" or rng.random() < 0.5) else np.float64
+    p, n = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+    k = int(rng.integers(1, min(p, n, 64 if alg == "multmse" else 140) + 1))
+    X, W0, H0 = planted(p, n, k, T, seed=int(rng.integers(1 << 30)), normalize=(alg != "projals"), zeroh=(alg == "projals"))
+    it = 6
+    inst = {"multmse": lambda: nmfx.MultUpdate(T, obj="mse", maxiter=it, tol=1e-30, lambda_w=1e-3, lambda_h=1e-3),
+            "multdiv": lambda: nmfx.MultUpdate(T, obj="div", maxiter=it, tol=1e-30),
+            "projals": lambda: nmfx.ProjectedALS(T, maxiter=it, tol=1e-30, lambda_w=0.1, lambda_h=0.1),
+            "greedycd": lambda: nmfx.GreedyCD(T, maxiter=it, tol=1e-30)}[alg]()
+    W, H = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(inst, X, W, H, track_objective=True)
+    oo = {"multmse": orc.Opts(maxiter=it, tol=1e-30, lambda_w=1e-3, lambda_h=1e-3), "multdiv": orc.Opts(maxiter=it, tol=1e-30),
+          "projals": orc.Opts(maxiter=it, tol=1e-30, lambda_w=0.1, lambda_h=0.1), "greedycd": orc.Opts(maxiter=it, tol=1e-30)}[alg]
+    oo.track_objective = True
+    ro = orc.solve(alg, X, W0.copy(order="F"), H0.copy(order="F"), oo)
+    tol = {("multmse", np.float32): 1e-5, ("multdiv", np.float32): 1e-5, ("multdiv", np.float64): 1e-10, ("projals", np.float32): 5e-3,
+           ("projals", np.float64): 1e-7, ("greedycd", np.float32): 3e-3, ("greedycd", np.float64): 1e-9}[(alg, T)]
+    e = rel_trace_err(r.trace, ro.trace)
+    n_cases += 1
+    ok = (r.niters == ro.niters) and np.isfinite(e) and e < tol and np.all(W >= 0) and np.all(H >= 0)
+    if not ok:
+        bad += 1
+        print("MISMATCH", alg, T.__name__, (p, n, k), "err", e, "tol", tol, "niters", r.niters, ro.niters, flush=True)
+print(f"{n_cases} cases, {bad} mismatches", flush=True)
+sys.exit(1 if bad else 0)

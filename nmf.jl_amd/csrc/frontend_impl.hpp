@@ -220,7 +220,7 @@ void Solver<T>::nndsvd_core(const T *Ud, int64_t ucs, int64_t uss, const T *Vd, 
     hipLaunchKernelGGL(posneg_sumsq_kernel<T>, dim3((unsigned)k), dim3(256), 0, stream, Vd, n, vcs, vss, vnorm);
     HIP_TRY(hipMemsetAsync(xsum, 0, nsum * sizeof(double), stream));
     if (variant != 0) hipLaunchKernelGGL(sum_block_kernel<T>, dim3(nsum), dim3(256), 0, stream, X.p, p, n, P, xsum);
-    if (nranks > 1) {   // V rows (= columns of X, H) are sharded: the norms of V's columns and sum(X) are global quantities
+    if (sharded()) {   // V rows (= columns of X, H) are sharded: the norms of V's columns and sum(X) are global quantities
         comm->group_start();
         comm->all_reduce(vnorm, (size_t)2 * k, CT_F64, false, stream);
         comm->all_reduce(xsum, (size_t)nsum, CT_F64, false, stream);

@@ -67,8 +67,8 @@ template <typename T> void Solver<T>::times_ht_chunk(const T *Amat, const T *Hp,
 
 // Consume the W that is in flight: per super-chunk wait for its all-gather, unpack its rows (+ add its statistics), and, if
 // asked, launch the part of W'X / W'W that contracts over those rows.  Ends with the stop check of the iteration that produced
-// this W.
-template <typename T> void Solver<T>::pipe_consume_w(const nmfx_opts &o, bool launch_wtx) {
+// this W (unless the caller runs that check itself, see run_check).
+template <typename T> void Solver<T>::pipe_consume_w(const nmfx_opts &o, bool launch_wtx, bool run_check) {
     const int *done = done_flag();
     T *Wfull = W[wcur].p;
     for (int c = 0; c < PIPE_C; ++c) {
@@ -79,12 +79,15 @@ template <typename T> void Solver<T>::pipe_consume_w(const nmfx_opts &o, bool la
         HIP_TRY(hipGetLastError());
         if (launch_wtx) wt_times_chunk(Wfull, X.p, c, done);
     }
-    enqueue_check(o, pipe_t);
+    // run_check = false: the flush comes from iterate() for the CURRENT iteration, which enqueues the objective of that
+    // iteration first and the stop check behind it (the check raises `done`, which turns every later launch into a no-op:
+    // checked here, a converging iteration would lose its own objective value)
+    if (run_check) enqueue_check(o, pipe_t);
     pipe_pending = false;
 }
 
 template <typename T> void Solver<T>::pipe_flush(const nmfx_opts &o) {
-    if (pipe_pending) pipe_consume_w(o, false);
+    if (pipe_pending) pipe_consume_w(o, false, /*run_check=*/false);
 }
 
 template <typename T> void Solver<T>::enqueue_multmse_pipelined(const nmfx_opts &o, long long t) {
@@ -94,7 +97,7 @@ template <typename T> void Solver<T>::enqueue_multmse_pipelined(const nmfx_opts 
         const T *Ho = H[hcur].p;
         T *Hn = H[hcur ^ 1].p;
         // W'X and W'W by row super-chunks: behind the previous iteration's all-gathers when one is in flight
-        if (was_pending) pipe_consume_w(o, true);
+        if (was_pending) pipe_consume_w(o, true, true);
         else for (int c = 0; c < PIPE_C; ++c) wt_times_chunk(W[wcur].p, X.p, c, done);
         reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, pipe_gram_pieces * PIPE_C, done);
         reduce_slabs_from("reduce_WtX", numH_p, slabs.p, h_stride, h_nslab, done);
@@ -103,7 +106,7 @@ template <typename T> void Solver<T>::enqueue_multmse_pipelined(const nmfx_opts 
         stats_h_finalize(last_tiles_r, done);
         hcur ^= 1;
     } else if (was_pending) {
-        pipe_consume_w(o, false);
+        pipe_consume_w(o, false, true);
     }
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;

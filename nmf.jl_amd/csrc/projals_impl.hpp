@@ -121,7 +121,7 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // CU).  Sharing its CU with a GEMM block the chain runs 4x slower (potrf 650 us, trtri 400 us), which still fits under the
     // 1.02 ms product: 2.75 -> 2.36 ms per iteration at 16384 x 16384, k = 256.  Replicated-W multi-GPU mode keeps the serial
     // order (its Gram travels inside the one packed all-reduce that follows the product).
-    const bool under = chol_slots > 0 && !use_bf16x3() && K % 128 == 0 && (nranks == 1 || rs);
+    const bool under = chol_slots > 0 && !use_bf16x3() && K % 128 == 0 && (!sharded() || rs);
     if (under) ensure_fstream();
     auto factor_under = [&](T *G, T lambda, const char *t1, const char *t2, bool with_potri) {
         HIP_TRY(hipEventRecord(ev_fork, stream));

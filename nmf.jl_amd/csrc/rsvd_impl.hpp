@@ -192,7 +192,7 @@ template <typename T> void Solver<T>::rsvd_begin(uint64_t seed, int64_t h_col_of
         EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
         gemm<KSTRIDED, KSTRIDED>("gemm_BBt", numH_p, K, K, numH_p, K, K, N, s_gh, true, eg, nullptr, (double)(K * N) * sizeof(T));
         reduce_slabs_from("reduce_BBt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, s_gh, nullptr);
-        if (nranks > 1) comm->all_reduce(gramH_p, (size_t)K * K, CT, false, stream);
+        if (sharded()) comm->all_reduce(gramH_p, (size_t)K * K, CT, false, stream);
     }
     HIP_TRY(hipMemcpy2DAsync(C_host, k * sizeof(T), gramH_p, K * sizeof(T), k * sizeof(T), k, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));

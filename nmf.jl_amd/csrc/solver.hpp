@@ -127,6 +127,7 @@ template <typename T> class Solver : public SolverBase {
         // `chol_slots` blocks short of two per CU, a high-priority side stream owns the half-empty CUs that leaves.
         // NMFX_CHOL_SLOTS=0 turns it off (factorisations between the products, as in round 1).
         if (const char *e = std::getenv("NMFX_CHOL_SLOTS")) chol_slots = std::max(0, std::min(128, std::atoi(e)));
+        if (const char *e = std::getenv("NMFX_FORCE_SHARDED")) force_sharded = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
         HIP_TRY(hipEventCreate(&ev_beg));
@@ -275,7 +276,7 @@ template <typename T> class Solver : public SolverBase {
         comm = c;
         rank = c->rank;
         nranks = c->nranks;
-        if (nranks > 1) {
+        if (sharded()) {
             // whole 128-row tiles per rank for the row-sharded W side
             int64_t m = 128 * (int64_t)nranks * PIPE_C, a = 256, b = m;   // x PIPE_C: whole tiles per rank and row super-chunk
             while (b) { const int64_t t = a % b; a = b; b = t; }
@@ -307,8 +308,9 @@ template <typename T> class Solver : public SolverBase {
     }
 
     // mode 0: off; 1: hipEvent pair around EVERY launch (each pair costs ~10 us of stream time: use for
-    // per-kernel breakdowns, not for throughput); 2: only the dominant GEMM launches (>= 1e10 flop), every 4th
-    // one -- the live roofline measurement of bench.py, < 0.5 % overhead on the timed region.
+    // per-kernel breakdowns, not for throughput); 2: only the dominant GEMM launches (the p*n*k products) and the
+    // collectives, every 8th one -- the live roofline measurement of bench.py, < 0.5 % overhead on the timed region;
+    // 3: the same launches, every 2nd one (short runs: the driver's 20-step line then rests on >= 10 samples per kernel).
     void profile_enable(int mode) override {
         profiling = mode;
         records.clear();
@@ -416,13 +418,19 @@ template <typename T> class Solver : public SolverBase {
     size_t slab_w_off = 0;    // W-side slab region
     Comm *comm = nullptr;
     int rank = 0, nranks = 1;
+    // A communicator of ONE rank normally short-cuts to the single-GPU code (no collective is issued).  NMFX_FORCE_SHARDED=1
+    // (read at construction) keeps the sharded code path -- reduce-scatter / all-gather / grouped all-reduces, the pipelined
+    // exchange -- also for nranks == 1, so that every collective of the multi-GPU step executes on a 1-GPU box, under RCCL, as
+    // an identity (tests/test_gpu_comm.py).
+    bool force_sharded = false;
+    bool sharded() const { return comm != nullptr && (nranks > 1 || force_sharded); }
     int comm_mode = 0;
     // row-sharded W side: this rank updates rows [row0, row0 + Pc) of W
     int64_t Pc = 0, row0 = 0;
     size_t ag_chunk_bytes = 0;
     DevBuf<T> rs_out;                       // reduce-scatter output: this rank's rows of the summed numerator (Pc x K, ld Pc)
     DevBuf<unsigned char> ag_send, ag_recv; // all-gather chunks: [ Pc x K piece of the new W | 2K doubles of column statistics ]
-    bool row_sharded() const { return nranks > 1 && comm_mode != NMFX_COMM_REPLICATED_W && Pc > 0 && Pc % 128 == 0; }
+    bool row_sharded() const { return sharded() && comm_mode != NMFX_COMM_REPLICATED_W && Pc > 0 && Pc % 128 == 0; }
     // Pipelined exchange (pipeline_impl.hpp; NMFX_COMM_PIPELINED, MultUpdate-MSE): the W side runs per row super-chunk, chunk
     // c's reduce-scatter on a second stream under chunk c+1's X*H' launch, its all-gather under the next iteration's W'X part.
     static constexpr int PIPE_C = 2;
@@ -459,7 +467,7 @@ template <typename T> class Solver : public SolverBase {
     int pipe_gram_pieces = 1;             // Gram tail pieces per chunk launch
     bool pipelined() const { return row_sharded() && comm_mode == NMFX_COMM_PIPELINED && Pcc > 0 && Pcc % 128 == 0 && fuse_gram && K % 128 == 0 && !use_bf16x3(); }
     void enqueue_multmse_pipelined(const nmfx_opts &o, long long t);
-    void pipe_consume_w(const nmfx_opts &o, bool launch_wtx);
+    void pipe_consume_w(const nmfx_opts &o, bool launch_wtx, bool run_check);
     void pipe_flush(const nmfx_opts &o);
     void wt_times_chunk(const T *Wp, const T *Bmat, int c, const int *done);
     void times_ht_chunk(const T *Amat, const T *Hp, int c, const int *done);
@@ -495,9 +503,12 @@ template <typename T> class Solver : public SolverBase {
 
     template <typename F> void timed(const char *name, double flops, double bytes, F &&launch) {
         if (!profiling) { launch(); return; }
-        // mode 2: only the products that carry the iteration's flops (the p*n*k ones, not the k x k x n Gram / update products),
-        // every 8th launch of each
-        if (profiling == 2 && (flops < (double)P * (double)N * (double)K || ((prof_seen[name]++) & 7) != 0)) { launch(); return; }
+        // mode 2 / 3: only the products that carry the iteration's flops (the p*n*k ones, not the k x k x n Gram / update products)
+        // and the collectives of the exchange step (names "comm_..."), every 8th (mode 2) / every 2nd (mode 3) launch of each
+        if (profiling >= 2) {
+            const bool wanted = flops >= (double)P * (double)N * (double)K || std::strncmp(name, "comm_", 5) == 0;
+            if (!wanted || ((prof_seen[name]++) & (profiling == 2 ? 7 : 1)) != 0) { launch(); return; }
+        }
         if (ev_used == (int)ev_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));
@@ -900,7 +911,7 @@ template <typename T> class Solver : public SolverBase {
     // kernel re-reads the whole other factor per 16-wide stripe, which stops paying once the problem is large enough to keep the
     // split-K products busy; very skewed shapes leave one side with too few stripes
     bool smallk_ok() const {
-        return sizeof(T) == 4 && K == 64 && nranks == 1 && smallk_enabled && !use_bf16x3() && P * N <= (int64_t)4096 * 4096 &&
+        return sizeof(T) == 4 && K == 64 && !sharded() && smallk_enabled && !use_bf16x3() && P * N <= (int64_t)4096 * 4096 &&
                std::max(P, N) <= 4 * std::min(P, N);
     }
     void enqueue_multmse_smallk(const nmfx_opts &o);
@@ -925,7 +936,7 @@ template <typename T> class Solver : public SolverBase {
                      T lambda, bool sharded_samples, const int *done);
     void allreduce_hstat(const int *done) {   // CD order: H is updated AFTER the packed W-side all-reduce
         (void)done;
-        if (nranks > 1) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
+        if (sharded()) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
     }
     void enqueue_check(const nmfx_opts &o, long long t) {
         const bool track = o.track_objective != 0;

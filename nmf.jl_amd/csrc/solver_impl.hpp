@@ -52,7 +52,7 @@ void Solver<T>::enqueue_objective(int alg, const nmfx_opts &o, double *dst, cons
             ++nextra;
         }
     }
-    if (nranks > 1) {
+    if (sharded()) {
         // the data term is a sum over column shards; regularisers: ||W||^2 is replicated, ||H||^2 is sharded.
         // Reduce the per-block partials to one value first, all-reduce it, then finish.
         hipLaunchKernelGGL(finish_objective_kernel<double>, dim3(1), dim3(256), 0, stream, obj_part.p, nblk, 1,
@@ -74,8 +74,8 @@ void Solver<T>::enqueue_objective(int alg, const nmfx_opts &o, double *dst, cons
 
 template <typename T> void Solver<T>::allreduce_w_side(bool with_hstat, const int *done) {
     (void)done;
-    if (nranks <= 1) return;
-    timed("allreduce_pack", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
+    if (!sharded()) return;
+    timed("comm_allreduce_pack", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
         comm->group_start();
         comm->all_reduce(pack.p, pack.count, CT, false, stream);
         if (with_hstat) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
@@ -87,7 +87,7 @@ template <typename T> void Solver<T>::allreduce_w_side(bool with_hstat, const in
 // blocks; the small tail of the packed buffer [ H_g H_g' | rowsum(H_g) ] and the H statistics are all-reduced in the same
 // group.  The rank's rows of the summed numerator land back in numW (standard layout, ld P) at [row0, row0 + Pc).
 template <typename T> void Solver<T>::scatter_w_numerator(bool with_hstat, const int *done, bool with_tail) {
-    timed("reduce_scatter_numW", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
+    timed("comm_reduce_scatter_numW", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
         comm->group_start();
         comm->reduce_scatter(numW_p, rs_out.p, (size_t)Pc * K, CT, stream);
         if (with_tail) comm->all_reduce(gramH_p, (size_t)K * K + (size_t)K, CT, false, stream);
@@ -117,7 +117,7 @@ template <typename T> void Solver<T>::stats_w_rows(const T *Wn, const T *Wo, con
 template <typename T> void Solver<T>::gather_w_rows(T *Wfull, bool with_stats, const int *done) {
     hipLaunchKernelGGL(rows_to_piece_kernel<T>, dim3(flat_grid(Pc * K)), dim3(256), 0, stream, reinterpret_cast<T *>(ag_send.p), Wfull,
                        P, K, Pc, row0, done);
-    timed("all_gather_W", 0.0, (double)(P * K) * sizeof(T), [&] {
+    timed("comm_all_gather_W", 0.0, (double)(P * K) * sizeof(T), [&] {
         comm->all_gather(ag_send.p, ag_recv.p, ag_chunk_bytes, CT_BYTE, stream);
     });
     hipLaunchKernelGGL(gathered_to_full_kernel<T>, dim3(flat_grid(P * K)), dim3(256), 0, stream, Wfull, ag_recv.p, nranks, ag_chunk_bytes,
@@ -165,7 +165,7 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
     }
     // :109 XH': single GPU -> slabs are consumed by the update GEMM's epilogue; replicated-W mode -> reduce into the packed
     // buffer first, because the all-reduce needs the rank-local sum
-    const bool w_slabs = (nranks == 1);
+    const bool w_slabs = !sharded();
     times_ht(X.p, Hp, true, done, /*keep_slabs=*/w_slabs);
     allreduce_w_side(o.update_H != 0, done);
     EpiMultUpdate<T, 0> e{w_num(), w_num_nslab(), w_stride, Wo, Wn, P, (T)o.lambda_w, (T)o.delta, nullptr, 0};   // :110-114
@@ -187,7 +187,7 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
     // gets the same floor here, so a zero column sum can never divide by zero
     const T lam_floor = std::sqrt(std::numeric_limits<T>::epsilon());
     const T lambda_h = std::max((T)o.lambda_h, lam_floor), lambda_w = std::max((T)o.lambda_w, lam_floor);
-    const bool fused = nranks == 1 && div_fused;
+    const bool fused = !sharded() && div_fused;
     if (o.update_H) {
         const T *Wp = W[wcur].p;
         const T *Ho = H[hcur].p;

@@ -1,7 +1,8 @@
 """Column-sharded multi-GPU plumbing (one process per GPU, torch.distributed for rendezvous only).
 
-The data path collective itself (one packed sum all-reduce per outer iteration) runs inside libnmfx.so on
-RCCL; this module only (a) decides which columns a rank owns and (b) ships rank 0's RCCL unique id to the
+The data-path exchange itself runs inside libnmfx.so on RCCL: by default a reduce-scatter of X_g H_g' by row blocks (grouped
+with the all-reduce of the small [H_g H_g' | rowsum(H_g) | H statistics] tail) and an all-gather of the updated row blocks of W
+per outer iteration (`replicated_w` keeps round 1's single packed all-reduce).  This module only (a) decides which columns a rank owns and (b) ships rank 0's RCCL unique id to the
 other ranks.  The reference has no distributed path."""
 from __future__ import annotations
 

@@ -96,6 +96,35 @@ def test_c3_multmse_one_iteration_pieces(built):
         assert np.all(np.diff(tr2[: res.niters + 1]) <= 1e-6 * tr2[0])
 
 
+@pytest.mark.parametrize("obj", ["mse", "div"])
+def test_c3_trajectory_vs_oracle(built, obj):
+    """north_star: "iteration-for-iteration objective value and final W, H" on the metric's OWN workload -- the CPU oracle
+    (the reference's operation sequence: 6 / 4 products of 2pnk per iteration through p x n temporaries, src/multupd.jl:83-116,
+    150-193; objective per iteration as with verbose = true, src/common.jl:76-82) runs three tracked iterations at
+    X = 16384 x 16384, k = 256, Float32 (~10 s of host time per iteration), the device the same three: every point of the
+    objective trajectory within 1e-5 relative, final factors within 1e-3 of max|.|."""
+    T = np.float32
+    X, W0, H0 = _c3_inputs()
+    p, n = X.shape
+    k = W0.shape[1]
+    lam = float(T(np.sqrt(np.finfo(T).eps))) if obj == "div" else 0.0
+    iters = 3
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("mult" + obj, X, Wc, Hc, orc.Opts(maxiter=iters, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+        o = nmfx.make_opts(T, maxiter=iters, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True)
+        res, trace = ctx.solve(0 if obj == "mse" else 1, o, Wg, Hg)
+    assert res.niters == ro.niters == iters
+    err = np.abs(np.asarray(trace[:iters + 1]) - np.asarray(ro.trace)) / np.abs(np.asarray(ro.trace))
+    print(f"C3 mult{obj}: relative objective error per point {err}")
+    assert np.all(err < 1e-5), err
+    assert np.max(np.abs(Wg - Wc)) <= 1e-3 * np.max(np.abs(Wc))
+    assert np.max(np.abs(Hg - Hc)) <= 1e-3 * np.max(np.abs(Hc))
+    assert not Wg[::97, 3].any() and not Hg[5, ::101].any() and not Wc[::97, 3].any() and not Hc[5, ::101].any()
+
+
 def test_c3_multdiv_properties(built):
     T = np.float32
     X, W0, H0 = _c3_inputs()

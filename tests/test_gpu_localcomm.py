@@ -195,6 +195,27 @@ def test_pipelined_stop_rule(built):
         assert np.max(np.abs(Ws - Wc)) <= 1e-7 * np.max(np.abs(Wc))
 
 
+@pytest.mark.parametrize("ce", [1, 3])
+def test_pipelined_tracked_solve_that_converges_keeps_its_last_objective(built, ce):
+    """Objective tracking + a tolerance that stops the solve, in the pipelined mode: the flush that precedes the
+    objective of iteration t must not run that iteration's stop check first -- the check raises `done`, and the objective launch
+    of the converging iteration would become a no-op (objvalue = NaN, last verbose row missing)."""
+    T = np.float64
+    p, n, k = 256, 384, 130
+    X, W0, H0 = planted(p, n, k, T, seed=3, k0=4)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("multmse", X, Wc, Hc, orc.Opts(maxiter=300, tol=3e-3, track_objective=True))
+    assert ro.converged and 3 < ro.niters < 300
+    kw = dict(maxiter=300, tol=3e-3, lambda_w=0.0, lambda_h=0.0, check_every=ce, track_objective=True)
+    Ws, Hs, rr, _ = run_sharded(T, X, W0, H0, "multmse", kw, 2, mode="pipelined")
+    for res, tr in rr:
+        assert res.converged and res.niters == ro.niters
+        assert np.isfinite(res.objvalue) and res.objvalue == tr[res.niters]
+        assert np.all(np.isfinite(tr[:res.niters + 1])) and np.all(np.isnan(tr[res.niters + 1:]))
+        assert rel_trace_err(tr[:res.niters + 1], np.array(ro.trace)) < 1e-9
+    assert abs(rr[0][0].objvalue - ro.objvalue) <= 1e-9 * abs(ro.objvalue)
+
+
 @pytest.mark.parametrize("T", [np.float64, np.float32])
 def test_sharded_front_end_rsvd_nndsvd(built, T):
     """The nnmf front end on a sharded X with 2 in-process ranks: randinit with the shard's

@@ -311,7 +311,7 @@ def cpu_baseline(p, n, k, T, Xt, W0, H0, ns):
     PURE iterations are timed: update_wh! + the preW/preH copies + stop_condition of nmf_skeleton! (src/common.jl:66-73),
     i.e. what one GPU 'step' does -- not prepare_state's W*H product, not the final objective pass.
     BLAS threads: the pool is pinned explicitly (threadpoolctl) and the timing is taken at the pool's cap and at half / a
-    quarter of it (skinny k = 256 products do not always scale to every core); the FASTEST setting is the baseline, and
+    quarter / an eighth of it (skinny k = 256 products do not always scale to every core); the FASTEST setting is the baseline, and
     `cores` reports the threads it actually used next to the host's core count."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nmf_oracle as orc
@@ -327,7 +327,7 @@ def cpu_baseline(p, n, k, T, Xt, W0, H0, ns):
         threadpool_limits = None
     cands = [cap] if (cap and threadpool_limits) else [None]
     if cap and threadpool_limits:
-        cands += [c for c in (cap // 2, cap // 4) if c >= 2]
+        cands += [c for c in (cap // 2, cap // 4, cap // 8) if c >= 2]
 
     def timed_iters(nthr, budget_s, max_iters):
         Ws, Hs = W0.copy(order="F"), np.asfortranarray(H0[:, :ns].copy())

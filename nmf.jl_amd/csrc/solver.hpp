@@ -22,6 +22,7 @@
 #include "comm.hpp"
 #include "gemm_mfma.hpp"
 #include "gemm_bf16x3.hpp"
+#include "gemm_stream.hpp"
 #include "kernels.hpp"
 #include "cd.hpp"
 
@@ -128,6 +129,7 @@ template <typename T> class Solver : public SolverBase {
         // NMFX_CHOL_SLOTS=0 turns it off (factorisations between the products, as in round 1).
         if (const char *e = std::getenv("NMFX_CHOL_SLOTS")) chol_slots = std::max(0, std::min(128, std::atoi(e)));
         if (const char *e = std::getenv("NMFX_FORCE_SHARDED")) force_sharded = std::atoi(e) != 0;
+        if (const char *e = std::getenv("NMFX_STREAM_WH")) stream_wh = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
         HIP_TRY(hipEventCreate(&ev_beg));
@@ -673,10 +675,35 @@ template <typename T> class Solver : public SolverBase {
         }
     }
     // the W*H products with a fused epilogue (ratio pass, objective): fp32 kernel, or the bf16x3 one when opted in
+    // f32, K a multiple of 128, an output of many tiles per block slot: the persistent cross-tile pipeline of gemm_stream.hpp
+    // (tile i's epilogue runs under tile i + 1's MFMAs).  NMFX_STREAM_WH=0 keeps the block-per-tile kernel.
+    bool stream_wh = true;
+    static SEpiRatio<float> to_stream(const EpiRatio<float> &e) { return SEpiRatio<float>{e.X, e.Q, e.ld, e.delta}; }
+    template <int KL> static SEpiObjective<float, KL> to_stream(const EpiObjective<float, KL> &e) { return SEpiObjective<float, KL>{e.X, e.ld, e.partial, 0.0}; }
     template <typename Epi>
     void gemm_wh(const char *name, const T *Hp, const T *Wp, const Epi &epi, const int *done, double bytes) {
-        if (use_bf16x3() && P % 128 == 0 && N % 128 == 0) launch_bf16x3<0, 1>(name, Hp, K, N, Wp, P, P, K, 1, true, epi, done, bytes);
-        else gemm<KCONTIG, KSTRIDED>(name, Hp, K, N, Wp, P, P, K, 1, true, epi, done, bytes);
+        if (use_bf16x3() && P % 128 == 0 && N % 128 == 0) { launch_bf16x3<0, 1>(name, Hp, K, N, Wp, P, P, K, 1, true, epi, done, bytes); return; }
+        if constexpr (sizeof(T) == 4) {
+            const int64_t tiles = (N / 128) * (P / 128);
+            const int grid = 2 * num_cu;
+            if (stream_wh && K % 128 == 0 && (grid & 7) == 0 && tiles >= 4 * (int64_t)grid && tiles < (int64_t)1 << 30) {
+                StreamArgs g;
+                g.A = reinterpret_cast<const float *>(Hp); g.lda = K;
+                g.B = reinterpret_cast<const float *>(Wp); g.ldb = P;
+                g.tiles_r = (int)(N / 128); g.tiles_c = (int)(P / 128);
+                g.nkt = (int)(K / 32);
+                g.group = (g.tiles_r % 8 == 0 && g.tiles_c % 8 == 0) ? 8 : 1;
+                g.done = done;
+                auto se = to_stream(epi);
+                timed(name, 2.0 * (double)N * (double)P * (double)K, bytes, [&] {
+                    hipLaunchKernelGGL((gemm_wh_stream_kernel<decltype(se)>), dim3((unsigned)grid), dim3(256), 0, stream, g, se);
+                    HIP_TRY(hipGetLastError());
+                });
+                last_tiles_r = g.tiles_r; last_blocks = grid;
+                return;
+            }
+        }
+        gemm<KCONTIG, KSTRIDED>(name, Hp, K, N, Wp, P, P, K, 1, true, epi, done, bytes);
     }
     // A product whose (tile, split) items would fill every block slot of the chip (two 128 x 128 blocks per CU, all resident for
     // the whole launch) while another stream has a workgroup to place: launch `chol_slots` blocks short and deal the missing items

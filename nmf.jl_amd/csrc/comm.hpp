@@ -17,6 +17,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstring>
 #include <cstdint>
 #include <mutex>
 #include <string>
@@ -98,7 +99,10 @@ struct SimComm : Comm {
     }
     void all_gather(const void *send, void *recv, size_t sendcount, int ct, hipStream_t s) override {
         const size_t b = sendcount * ct_size(ct);
-        for (int q = 0; q < nranks; ++q) (void)hipMemcpyAsync(reinterpret_cast<char *>(recv) + (size_t)q * b, send, b, hipMemcpyDeviceToDevice, s);
+        for (int q = 0; q < nranks; ++q) {
+            char *dst = reinterpret_cast<char *>(recv) + (size_t)q * b;
+            if (dst != send) (void)hipMemcpyAsync(dst, send, b, hipMemcpyDeviceToDevice, s);   // in-place all-gather: the own chunk is already there
+        }
     }
 };
 

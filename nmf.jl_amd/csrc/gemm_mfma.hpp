@@ -652,6 +652,40 @@ template <typename T, int STATS> struct EpiMultUpdate {
     }
 };
 
+// The same multiplicative update for the ROW-SHARDED W side of the multi-GPU step: numerator, old factor and
+// output each have their own leading dimension -- the numerator is read straight from the reduce-scatter's output (Pc x K piece,
+// ld Pc), the old factor from the rank's rows of W (ld P), the new rows are written straight into the rank's chunk of the
+// all-gather buffer (ld Pc) -- so no pack / unpack launch surrounds the update.  Same arithmetic, same bits.
+template <typename T> struct EpiMultUpdateRows {
+    const T *num;
+    int64_t ldn;       // numerator AND output (both Pc x K pieces)
+    const T *old;
+    int64_t ldo;
+    T *out;
+    T lambda, delta;
+    rsrc_t rnum, rold, rout;
+    LaneAddr<T> ln, lo;
+    __device__ __forceinline__ void setup(int, const TileCtx &t) {
+        rnum = tile_rsrc(num, ldn, t);
+        rout = tile_rsrc(out, ldn, t);
+        rold = tile_rsrc(old, ldo, t);
+        ln.init(t, ldn);
+        lo.init(t, ldo);
+    }
+    __device__ __forceinline__ void begin() {}
+    struct Pre { T nu, ov; };
+    static constexpr bool EARLY = true, HEAVY = true;
+    __device__ __forceinline__ Pre prefetch(int ro, int co) const {
+        return Pre{buf_ld<T>(rnum, ln.lb, ln.soff(ro, co)), buf_ld<T>(rold, lo.lb, lo.soff(ro, co))};
+    }
+    __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &pre) {
+        T t = pre.nu - lambda;
+        t = (t > (T)0) ? t : ((t != t) ? t : (T)0);
+        buf_st(rout, ln.lb, ln.soff(ro, co), pre.ov * (t / (v + delta)));
+    }
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
+};
+
 // out = max(acc, 0)   (projectnn!, src/utils.jl:34-41; NaN passes through)
 template <typename T> struct EpiClampStore {
     T *out;

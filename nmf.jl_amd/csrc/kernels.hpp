@@ -173,7 +173,7 @@ __global__ void finalize_partials_kernel(const double *partial, int nchunks, int
 // wstat/hstat: [j*2] = dev, [j*2+1] = sum (hstat may be null when update_H is false).
 // The reference accumulates in T; the comparison is done in T on the rounded sums.
 template <typename T>
-__global__ void check_kernel(Ctrl *ctrl, const double *wstat, const double *hstat, int k, T tol, long long t, double *dev_out) {
+__device__ __forceinline__ void check_body(Ctrl *ctrl, const double *wstat, const double *hstat, int k, T tol, long long t, double *dev_out) {
     if (ctrl->done) return;
     __shared__ int first_bad;
     __shared__ T wmax[4];
@@ -220,6 +220,10 @@ __global__ void check_kernel(Ctrl *ctrl, const double *wstat, const double *hsta
         ctrl->niters = t;
         if (jf >= k) { ctrl->converged = 1; ctrl->done = 1; }
     }
+}
+template <typename T>
+__global__ void check_kernel(Ctrl *ctrl, const double *wstat, const double *hstat, int k, T tol, long long t, double *dev_out) {
+    check_body<T>(ctrl, wstat, hstat, k, tol, t, dev_out);
 }
 
 // objective finalisation (evaluate_objv): s = sum of block partials (ascending);
@@ -384,6 +388,108 @@ __global__ void gathered_to_full_kernel(T *full, const unsigned char *recv, int 
                 s += reinterpret_cast<const double *>(recv + (size_t)g * chunk_bytes + (size_t)Pc * K * sizeof(T))[j];
             tail_sum[j] = s;
         }
+}
+
+// Everything between the X_g H_g' launch and the exchange of the row-sharded MultUpdate-MSE step in ONE launch (three launches of
+// 6-17 us each at the 8-rank shard shape of the headline problem, where an iteration is 0.4 ms):
+//   blocks [0, nb1)         : split-K combine of the numerator slabs into the blocked send buffer (reduce_slabs_blocked_kernel)
+//   blocks [nb1, nb1 + nb2) : the fused Gram's tail pieces summed (reduce_many_slabs_kernel: 4 slab-lanes per element, fixed order)
+//   the rest                : stop_condition's H statistics finalised from the update GEMM's per-tile partials
+//                             (finalize_partials_kernel: a wave per output)
+template <typename T>
+__global__ __launch_bounds__(256) void w_side_combine_kernel(T *dst_blk, const T *slabs, int64_t P, int64_t K, int64_t Pc, int nslab, int64_t stride,
+                                                             T *gram, const T *gsrc, int64_t gcount, int gslabs, int64_t gstride,
+                                                             const double *hpart, int hchunks, int hcount, double *hstat, unsigned nb1,
+                                                             unsigned nb2, const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ T sm[4][64];
+    if (blockIdx.x < nb1) {
+        // 256 consecutive rows of one column per block (P is a multiple of 256): 32-bit index arithmetic, no 64-bit division
+        const unsigned rb = (unsigned)(P / 256), a = blockIdx.x / rb, i = (blockIdx.x % rb) * 256u + threadIdx.x;
+        const unsigned blk = i / (unsigned)Pc, il = i - blk * (unsigned)Pc;
+        const int64_t o = (int64_t)i + (int64_t)a * P;
+        T s = slabs[o];
+        for (int q = 1; q < nslab; ++q) s += slabs[(int64_t)q * stride + o];
+        dst_blk[((int64_t)blk * K + a) * Pc + il] = s;
+    } else if (blockIdx.x < nb1 + nb2) {
+        const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const int64_t i = (int64_t)(blockIdx.x - nb1) * 64 + e;
+        T acc = (T)0;
+        if (i < gcount) {
+            int q = sl;
+            for (; q + 28 < gslabs; q += 32) {
+                T v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = gsrc[(int64_t)(q + 4 * u) * gstride + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; q < gslabs; q += 4) acc += gsrc[(int64_t)q * gstride + i];
+        }
+        sm[sl][e] = acc;
+        __syncthreads();
+        if (sl == 0 && i < gcount) gram[i] = ((sm[0][e] + sm[1][e]) + sm[2][e]) + sm[3][e];
+    } else {
+        const int e = (int)(blockIdx.x - nb1 - nb2) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+        if (e >= hcount) return;
+        const int lane = threadIdx.x & 63;
+        double s = 0.0;
+        for (int c = lane; c < hchunks; c += 64) s += hpart[(int64_t)c * hcount + e];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) hstat[e] = s;
+    }
+}
+
+// The tail of the row-sharded W side: the all-gather's receive buffer (G pieces of Pc x K, ld Pc) is unpacked into the full W
+// (ld P) and stop_condition's column sums (src/common.jl:95-99) are taken over ALL rows against the old W on the way -- every rank
+// computes the same sums from the same bits, so no statistics travel with the all-gather.  grid = (G * cpp, K): cpp chunks per
+// piece, a block stays inside one rank's piece; partial[(chunk*K + j)*2 + {0,1}].  Followed by stats_check_kernel (one block): the
+// per-chunk partials added in chunk order and, unless the caller still has an objective evaluation to enqueue in front of it
+// (do_check = 0), the stop rule itself.  Two launches instead of col_stats + finalize + rows_to_piece + gathered_to_full + check.
+// (One launch with a last-block ticket was measured: 4096 device-scope atomics on one address cost 130 us on this chip.)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_stats_kernel(T *Wfull, const T *Wold, const unsigned char *recv, size_t chunk_bytes, int64_t P,
+                                                           int64_t Pc, int cpp, int K, double *partial, const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ double sm[8];
+    const int j = blockIdx.y, chunk = blockIdx.x;
+    const int g = chunk / cpp, ci = chunk % cpp;
+    const int64_t per = (Pc + cpp - 1) / cpp;
+    const int64_t beg = ci * per, end = (beg + per < Pc) ? beg + per : Pc;
+    const T *piece = reinterpret_cast<const T *>(recv + (size_t)g * chunk_bytes) + (int64_t)j * Pc;
+    const T *oldc = Wold + (int64_t)g * Pc + (int64_t)j * P;
+    T *newc = Wfull + (int64_t)g * Pc + (int64_t)j * P;
+    double dev = 0.0, sum = 0.0;
+    for (int64_t il = beg + threadIdx.x; il < end; il += blockDim.x) {
+        const T a = piece[il];
+        const T b = oldc[il];
+        newc[il] = a;
+        const T d = a - b, s = a + b;
+        dev += (double)(T)(d * d);
+        sum += (double)(T)(s * s);
+    }
+    for (int off = 32; off > 0; off >>= 1) { dev += __shfl_down(dev, off, 64); sum += __shfl_down(sum, off, 64); }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[w] = dev; sm[4 + w] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double d = 0.0, s = 0.0;
+        for (int q = 0; q < nw; ++q) { d += sm[q]; s += sm[4 + q]; }
+        partial[((int64_t)chunk * K + j) * 2] = d;
+        partial[((int64_t)chunk * K + j) * 2 + 1] = s;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void stats_check_kernel(const double *partial, int nchunks, int K, double *wstat, Ctrl *ctrl, const double *hstat,
+                                                          int k, T tol, long long t, int do_check, const int *done) {
+    NMFX_DONE_GUARD(done);
+    for (int e = threadIdx.x; e < 2 * K; e += blockDim.x) {
+        double s = 0.0;
+        for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * 2 * K + e];
+        wstat[e] = s;
+    }
+    __syncthreads();
+    if (do_check) check_body<T>(ctrl, wstat, hstat, k, tol, t, nullptr);
 }
 
 // dst[c + r*ldd] = sum_p src[p*stride + c + r*cols] (p ascending): the tail pieces of a short grid (GemmArgs::tail_main) summed into the

@@ -129,6 +129,7 @@ template <typename T> class Solver : public SolverBase {
         // NMFX_CHOL_SLOTS=0 turns it off (factorisations between the products, as in round 1).
         if (const char *e = std::getenv("NMFX_CHOL_SLOTS")) chol_slots = std::max(0, std::min(128, std::atoi(e)));
         if (const char *e = std::getenv("NMFX_FORCE_SHARDED")) force_sharded = std::atoi(e) != 0;
+        if (const char *e = std::getenv("NMFX_RS_FUSED")) rs_fused_enabled = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_STREAM_WH")) stream_wh = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
@@ -432,6 +433,14 @@ template <typename T> class Solver : public SolverBase {
     size_t ag_chunk_bytes = 0;
     DevBuf<T> rs_out;                       // reduce-scatter output: this rank's rows of the summed numerator (Pc x K, ld Pc)
     DevBuf<unsigned char> ag_send, ag_recv; // all-gather chunks: [ Pc x K piece of the new W | 2K doubles of column statistics ]
+    // MultUpdate-MSE, row-sharded: the launches between the big products and the collectives fused (solver_impl.hpp)
+    bool rs_fused_enabled = true;         // NMFX_RS_FUSED=0: the unfused sequence (pack / unpack / statistics as separate launches)
+    bool w_defer_combine = false;         // times_ht: leave the split-K slabs and the Gram pieces to the caller's combine launch
+    bool h_reduce_pair = false;           // wt_times: numerator and Gram combined by ONE launch
+    int w_pieces = 1;                     // Gram tail pieces of the last fused X*H' launch
+    int h_stat_chunks = 1;                // r-tiles of the last H update (chunks of its statistics partials)
+    bool check_fused = false;             // the stop check of this iteration already ran inside stats_check_kernel
+    bool rs_fused() const { return rs_fused_enabled && row_sharded() && fuse_gram && K % 128 == 0 && !use_bf16x3(); }
     bool row_sharded() const { return sharded() && comm_mode != NMFX_COMM_REPLICATED_W && Pc > 0 && Pc % 128 == 0; }
     // Pipelined exchange (pipeline_impl.hpp; NMFX_COMM_PIPELINED, MultUpdate-MSE): the W side runs per row super-chunk, chunk
     // c's reduce-scatter on a second stream under chunk c+1's X*H' launch, its all-gather under the next iteration's W'X part.
@@ -764,6 +773,12 @@ template <typename T> class Solver : public SolverBase {
             sg.A2 = Wp; sg.lda2 = P; sg.r_split = N; sg.tail_tiles = (int)(K / 128);
             gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                    (double)(P * N + 2 * P * K) * sizeof(T), sg, 2.0 * K * K * P);
+            if (h_reduce_pair && (!keep_slabs || h_nslab > 2)) {   // both combines in one launch
+                reduce_pair("reduce_WtX_WtW", numH_p, reg, h_stride, h_nslab, h_stride, gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces,
+                            (int64_t)K * K, done);
+                h_in_slabs = false;
+                return;
+            }
             reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
             if (!keep_slabs || h_nslab > 2) {
                 reduce_slabs_from("reduce_WtX", numH_p, reg, h_stride, h_nslab, done);
@@ -838,6 +853,7 @@ template <typename T> class Solver : public SolverBase {
             sg.B2 = Hp; sg.ldb2 = K; sg.c_split = P; sg.tail_tiles = (int)(K / 128);
             gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
                                      (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
+            if (w_defer_combine) { w_pieces = pieces; w_in_slabs = false; return; }   // the caller's combine launch sums both
             reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
             finish_w_slabs(keep_slabs, done);
             return;
@@ -929,6 +945,7 @@ template <typename T> class Solver : public SolverBase {
 
     void enqueue_objective(int alg, const nmfx_opts &o, double *dst, const int *done);
     void enqueue_multmse(const nmfx_opts &o, long long t);
+    void multmse_w_rows_fused(const nmfx_opts &o, long long t);
     // k <= 64, Float32, one GPU: the 4-launch path of smallk.hpp (smallk_impl.hpp)
     bool smallk_enabled = true;          // NMFX_SMALLK=0 keeps the general path
     bool smallk_attr_set = false;
@@ -967,9 +984,13 @@ template <typename T> class Solver : public SolverBase {
     }
     void enqueue_check(const nmfx_opts &o, long long t) {
         const bool track = o.track_objective != 0;
-        hipLaunchKernelGGL(check_kernel<T>, dim3(1), dim3(256), 0, stream, ctrl, wstat.p,
-                           o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, track ? dev_trace.p : (double *)nullptr);
-        HIP_TRY(hipGetLastError());
+        if (check_fused) {
+            check_fused = false;   // stats_check_kernel ran the stop rule of iteration t (never while tracking)
+        } else {
+            hipLaunchKernelGGL(check_kernel<T>, dim3(1), dim3(256), 0, stream, ctrl, wstat.p,
+                               o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, track ? dev_trace.p : (double *)nullptr);
+            HIP_TRY(hipGetLastError());
+        }
         if (track) {   // verbose-style tracking also time-stamps every iteration (common.jl:77: elapsed = time() - start)
             while (iter_events.size() <= (size_t)t) {
                 hipEvent_t e;

@@ -141,15 +141,20 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
         // :98 W'X (and W'W, same launch) stay as split-K slabs: the Gram slabs get a tiny reduction, the update GEMM sums
         // the numerator slabs in its epilogue (ascending slab order, like reduce_slabs_kernel), and it also
         // produces the stop_condition statistics of H -- three launches for the whole H phase.
+        const bool fusedrs = rs_fused();
+        h_reduce_pair = fusedrs;
         wt_times(Wp, X.p, true, done, /*keep_slabs=*/true);
+        h_reduce_pair = false;
         EpiMultUpdate<T, 1> e{h_num(), h_num_nslab(), h_stride, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};  // :99-103
         gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (3.0 + h_num_nslab()) * K * N * sizeof(T));
-        stats_h_finalize(last_tiles_r, done);
+        h_stat_chunks = last_tiles_r;
+        if (!fusedrs) stats_h_finalize(last_tiles_r, done);   // fused row-sharded step: finalised by the W side's combine launch
         hcur ^= 1;
     }
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
+    if (rs_fused()) { multmse_w_rows_fused(o, t); return; }
     if (row_sharded()) {
         // sharded: X_g H_g' partial sums -> reduce-scatter by row blocks -> this rank updates ITS Pc rows -> all-gather
         w_blocked = true;
@@ -171,6 +176,53 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
     EpiMultUpdate<T, 0> e{w_num(), w_num_nslab(), w_stride, Wo, Wn, P, (T)o.lambda_w, (T)o.delta, nullptr, 0};   // :110-114
     gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo, P, P, K, 1, false, e, done, 3.0 * P * K * sizeof(T));
     stats_w(Wn, Wo, done);
+    wcur ^= 1;
+}
+
+// The row-sharded W side of MultUpdate-MSE with everything around the two collectives fused (8 launches per iteration instead of
+// 17 at the 8-rank shard shape, where an iteration is 0.4 ms and every small launch is 6-17 us):
+//   X_g H_g' (+ H_g H_g' tail pieces)  ->  ONE combine launch (numerator slabs into the blocked send buffer, Gram pieces, H statistics)
+//   -> reduce-scatter + the small all-reduces  ->  update GEMM on the rank's rows: numerator straight from the reduce-scatter's
+//   output, new rows straight into the rank's chunk of the all-gather buffer (EpiMultUpdateRows)  ->  IN-PLACE all-gather
+//   ->  one launch that unpacks W and takes stop_condition's column sums over all rows (gather_stats_kernel), one block that adds them
+//   up and runs the stop rule (stats_check_kernel).
+template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, long long t) {
+    const int *done = done_flag();
+    const T *Hp = H[hcur].p;
+    const T *Wo = W[wcur].p;
+    T *Wn = W[wcur ^ 1].p;
+    w_blocked = true; w_defer_combine = true;
+    times_ht(X.p, Hp, true, done);
+    w_blocked = false; w_defer_combine = false;
+    const unsigned nb1 = (unsigned)(P / 256 * K), nb2 = (unsigned)((K * K + 63) / 64), nb3 = o.update_H ? (unsigned)((2 * K + 3) / 4) : 0u;
+    timed("combine_W", 0.0, ((double)P * K * (w_nslab + 1) + (double)K * K * (w_pieces + 1)) * sizeof(T), [&] {
+        hipLaunchKernelGGL(w_side_combine_kernel<T>, dim3(nb1 + nb2 + nb3), dim3(256), 0, stream, numW_p, slabs.p + slab_w_off, P, K, Pc, w_nslab,
+                           w_stride, gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, w_pieces, (int64_t)K * K, stat_part.p, h_stat_chunks,
+                           (int)(2 * K), hstat.p, nb1, nb2, done);
+        HIP_TRY(hipGetLastError());
+    });
+    timed("comm_reduce_scatter_numW", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
+        comm->group_start();
+        comm->reduce_scatter(numW_p, rs_out.p, (size_t)Pc * K, CT, stream);
+        comm->all_reduce(gramH_p, (size_t)K * K, CT, false, stream);
+        if (o.update_H) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
+        comm->group_end();
+    });
+    const size_t chunk = (size_t)Pc * K * sizeof(T);
+    T *mine = reinterpret_cast<T *>(ag_recv.p + (size_t)rank * chunk);
+    EpiMultUpdateRows<T> e{rs_out.p, Pc, Wo + row0, P, mine, (T)o.lambda_w, (T)o.delta};                  // multupd.jl:110-114
+    gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo + row0, P, Pc, K, 1, false, e, done, 3.0 * Pc * K * sizeof(T));
+    timed("comm_all_gather_W", 0.0, (double)(P * K) * sizeof(T), [&] { comm->all_gather(mine, ag_recv.p, chunk, CT_BYTE, stream); });
+    const bool fuse_check = o.track_objective == 0;
+    const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(64 / nranks, Pc / 1024));   // chunks per piece
+    timed("gather_W_stats", 0.0, 3.0 * P * K * sizeof(T), [&] {
+        hipLaunchKernelGGL(gather_stats_kernel<T>, dim3((unsigned)(nranks * cpp), (unsigned)K), dim3(256), 0, stream, Wn, Wo, ag_recv.p, chunk, P, Pc, cpp, (int)K,
+                           stat_part.p, done);
+        hipLaunchKernelGGL(stats_check_kernel<T>, dim3(1), dim3(256), 0, stream, stat_part.p, nranks * cpp, (int)K, wstat.p, ctrl,
+                           o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done);
+        HIP_TRY(hipGetLastError());
+    });
+    check_fused = fuse_check;
     wcur ^= 1;
 }
 
@@ -308,6 +360,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     if (o.precision != NMFX_PREC_FP32 && o.precision != NMFX_PREC_BF16X3) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for precision."};
     precision = o.precision;
     pipe_pending = false;
+    check_fused = false;
     smallk_grams_valid = false;
     div_sw_valid = div_sh_valid = false;
     rsvd_ready = 0;   // the iteration overwrites the buffers a pending rsvd keeps its Q / B in

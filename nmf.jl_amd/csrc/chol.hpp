@@ -43,6 +43,11 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 template <typename T>
 __global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int k, Ctrl *ctrl, int posdef_status) {
     if (ctrl != nullptr && ctrl->done) return;
+    // ProjectedALS runs this workgroup on a CU it shares with a block of the big product (projals_impl.hpp): its waves are the
+    // YOUNGER ones on their SIMDs and lose every issue arbitration against the GEMM's waves (4x slower than alone).  The
+    // factorisation is a latency chain that needs few issue slots, the GEMM a throughput kernel that has plenty: raise the wave
+    // priority (priority outranks age, MI355X_MICROARCH.md "Two waves per SIMD").
+    __builtin_amdgcn_s_setprio(3);
     using M = Mfma<T>;
     constexpr int NB = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int
 template <typename T>
 __global__ __launch_bounds__(64) void trtri_diag_kernel(const T *U, T *Uinv, int64_t ld, int k, const int *done) {
     NMFX_DONE_GUARD(done);
+    __builtin_amdgcn_s_setprio(3);
     constexpr int NB = 32;
     const int jb = blockIdx.x * NB, lane = threadIdx.x;
     const int nb = (k - jb < NB) ? (k - jb) : NB;
@@ -222,24 +228,27 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const T *U, T *Uinv, int
         if (lane < nb && r <= lane) Uinv[(jb + r) + (int64_t)(jb + lane) * ld] = v[r];
 }
 
-// grid = ceil(k/32) workgroups (block column b) of 4 waves.  LDS: finished tiles Y[c] (c = 0..b, row-major 32x32 each),
-// 4 partial-sum tiles.  Dynamic LDS = (nblk + 4) * 1024 elements of T.
+// grid = ceil(k/32) workgroups (block column b) of 4 waves.  LDS: the `nfit` most recently finished tiles Y[c] of the column
+// (slot b - c, row-major 32x32 each; the diagonal tile is slot 0) + 4 partial-sum tiles: dynamic LDS = (min(nblk, nfit) + 4) * 1024
+// elements of T.  Tiles further down the chain than `nfit` are read back from Uinv in global memory (written by this workgroup, L2
+// hits): no limit on k from the LDS size (a fully LDS-resident column needs 160 KiB at k = 512 in f64).
 template <typename T>
-__global__ __launch_bounds__(256) void trtri_offdiag_kernel(const T *U, T *Uinv, int64_t ld, int k, const int *done) {
+__global__ __launch_bounds__(256) void trtri_offdiag_kernel(const T *U, T *Uinv, int64_t ld, int k, int nfit, const int *done) {
     NMFX_DONE_GUARD(done);
+    __builtin_amdgcn_s_setprio(3);
     using M = Mfma<T>;
     constexpr int NB = 32, MT = M::MT, KS = M::KS, SUB = NB / MT;   // SUB x SUB MFMA tiles per 32 x 32 block
     extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
-    T *Y = reinterpret_cast<T *>(chol_smem);          // Y[c*1024 + l*32 + j] = Uinv(32c + l, 32b + j)
+    T *Y = reinterpret_cast<T *>(chol_smem);          // Y[(b-c)*1024 + l*32 + j] = Uinv(32c + l, 32b + j), b - c < nfit
     const int nblk = (k + NB - 1) / NB;
-    T *Ps = Y + (size_t)nblk * NB * NB;               // 4 partial tiles, same row-major layout
+    T *Ps = Y + (size_t)((nblk < nfit) ? nblk : nfit) * NB * NB;   // 4 partial tiles, same row-major layout
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane % MT, ks = lane / MT;
     // Y[b] = diagonal block (already in Uinv), zero-padded
     for (int e = tid; e < NB * NB; e += 256) {
         const int l = e / NB, j = e % NB;
         const int gr = b * NB + l, gc = b * NB + j;
-        Y[(size_t)b * NB * NB + e] = (gr < k && gc < k && l <= j) ? Uinv[gr + (int64_t)gc * ld] : (T)0;
+        Y[e] = (gr < k && gc < k && l <= j) ? Uinv[gr + (int64_t)gc * ld] : (T)0;
     }
     __syncthreads();
     for (int a = b - 1; a >= 0; --a) {
@@ -252,7 +261,8 @@ __global__ __launch_bounds__(256) void trtri_offdiag_kernel(const T *U, T *Uinv,
 #pragma unroll
                 for (int r = 0; r < M::NACC; ++r) acc[si][sj][r] = (T)0;
         for (int c = a + 1 + wave; c <= b; c += 4) {
-            const T *Yc = Y + (size_t)c * NB * NB;
+            const bool in_lds = (b - c) < nfit;
+            const T *Yc = Y + (size_t)(in_lds ? (b - c) : 0) * NB * NB;
 #pragma unroll
             for (int kk = 0; kk < NB / KS; ++kk) {
                 const int l = kk * KS + ks;
@@ -263,7 +273,13 @@ __global__ __launch_bounds__(256) void trtri_offdiag_kernel(const T *U, T *Uinv,
                     af[si] = (gr < k && gc < k) ? U[gr + (int64_t)gc * ld] : (T)0;
                 }
 #pragma unroll
-                for (int sj = 0; sj < SUB; ++sj) bf[sj] = Yc[l * NB + sj * MT + li];
+                for (int sj = 0; sj < SUB; ++sj) {
+                    if (in_lds) bf[sj] = Yc[l * NB + sj * MT + li];
+                    else {   // finished tile c of this column, from global memory: Uinv(32c + l, 32b + j); zero outside the matrix
+                        const int gr = c * NB + l, gc = b * NB + sj * MT + li;
+                        bf[sj] = (gr < k && gc < k) ? *reinterpret_cast<const volatile T *>(Uinv + gr + (int64_t)gc * ld) : (T)0;
+                    }
+                }
 #pragma unroll
                 for (int si = 0; si < SUB; ++si)
 #pragma unroll
@@ -313,7 +329,8 @@ __global__ __launch_bounds__(256) void trtri_offdiag_kernel(const T *U, T *Uinv,
 #pragma unroll
                     for (int sj = 0; sj < SUB; ++sj) acc2[si][sj] = M::mma(af[si], bf[sj], acc2[si][sj]);
             }
-            T *Ya = Y + (size_t)a * NB * NB;
+            const bool keep = (b - a) < nfit;
+            T *Ya = Y + (size_t)(keep ? (b - a) : 0) * NB * NB;
 #pragma unroll
             for (int si = 0; si < SUB; ++si)
 #pragma unroll
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(256) void trtri_offdiag_kernel(const T *U, T *Uinv,
                         else rr = (lane >> 4) + 4 * reg;
                         const int i = si * MT + rr, j = sj * MT + li;
                         const T val = -acc2[si][sj][reg];
-                        Ya[i * NB + j] = val;
+                        if (keep) Ya[i * NB + j] = val;
                         const int gr = a * NB + i, gc = b * NB + j;
                         if (gr < k && gc < k) Uinv[gr + (int64_t)gc * ld] = val;
                     }

@@ -504,6 +504,53 @@ __global__ void reduce_pieces_kernel(T *dst, int64_t ldd, const T *src, int64_t 
     }
 }
 
+// Split-K combine of a product that was launched a few blocks SHORT (GemmArgs::tail_main): the last slab's share of a small
+// rectangle of the output arrived as `npieces` tail pieces instead.  ONE launch instead of reduce_pieces_kernel (pieces -> last slab)
+// + reduce_slabs_kernel (slabs -> dst), and the same bits: dst = slab_0 + ... + slab_{n-2} + L, where L is the last slab's value
+// or, inside the rectangle, piece_0 + piece_1 + ... (ascending; 8 loads in flight instead of a chain of dependent ones, which
+// had made the stand-alone pieces pass the slowest small launch of a ProjectedALS iteration: 24 us for 0.5 MB).
+//   mode 0: dst is flat (count elements), the rectangle is the contiguous range [off, off + plen): piece index e - off
+//   mode 1: dst is ld x cols column-major (ld a multiple of 256), the rectangle is rows [r0, r0 + prow) of every column, pieces
+//           are compact (ld = prow): piece index (i - r0) + a*prow
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_slabs_tail_kernel(T *dst, const T *src, int64_t count, int nslab, int64_t stride, const T *pieces,
+                                                                int npieces, int64_t pstride, int mode, int64_t off, int64_t plen, int64_t ld,
+                                                                int64_t r0, int64_t prow, const int *done) {
+    NMFX_DONE_GUARD(done);
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t pidx = -1;
+    if (mode == 0) {
+        if (e >= count) return;
+        if (e >= off && e < off + plen) pidx = e - off;
+    } else {
+        // column index fastest over the blocks: the blocks that carry the pieces (the last row blocks of EVERY column) are then
+        // consecutive block ids, i.e. dealt to all 8 XCDs (row index fastest put them all on two XCDs: 48 us instead of 24)
+        const unsigned cols = (unsigned)(count / ld), a = blockIdx.x % cols, i = (blockIdx.x / cols) * 256u + threadIdx.x;
+        e = (int64_t)i + (int64_t)a * ld;
+        if ((int64_t)i >= r0 && (int64_t)i < r0 + prow) pidx = ((int64_t)i - r0) + (int64_t)a * prow;
+    }
+    T lastv;
+    if (pidx >= 0) {
+        T acc = pieces[pidx];
+        int q = 1;
+        for (; q + 8 <= npieces; q += 8) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pieces[(int64_t)(q + u) * pstride + pidx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; q < npieces; ++q) acc += pieces[(int64_t)q * pstride + pidx];
+        lastv = acc;
+    } else {
+        lastv = src[(int64_t)(nslab - 1) * stride + e];
+    }
+    if (nslab == 1) { dst[e] = lastv; return; }
+    T s = src[e];
+    for (int k = 1; k < nslab - 1; ++k) s += src[(int64_t)k * stride + e];
+    dst[e] = s + lastv;
+}
+
 // ---- multdiv, single GPU: everything that follows a numerator product in ONE pass over the factor (src/multupd.jl:176-179, 188-191
 // + stop_condition's sums, src/common.jl:95-104): split-K slabs summed (ascending, in T, like reduce_slabs_kernel), the scaling
 // of div_update_kernel, the statistics of row_stats_kernel / col_stats_kernel and the OTHER side's next divisor (sum over the

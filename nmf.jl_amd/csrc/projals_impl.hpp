@@ -16,8 +16,11 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
     const size_t kk = (size_t)K * K;
     // potrf: 32 x 32 diagonal block + 32 x kp row panel in LDS (kp = k rounded up to 32)
     const size_t lds32 = potrf_lds_bytes();
-    const size_t lds_tri = (size_t)((k + 31) / 32 + 4) * 1024 * sizeof(T);   // finished tiles of a block column + 4 partial tiles
-    if (lds_tri > 160 * 1024) throw StatusError{NMFX_ERR_UNSUPPORTED, "projals: k too large for the blocked triangular inverse"};
+    // trtri: up to `nfit` finished tiles of a block column + 4 partial tiles in LDS (96 KiB at most, so that the workgroup still fits
+    // beside a GEMM block of the co-resident product); further tiles are read back from global memory (chol.hpp)
+    const int nblk_t = (int)((k + 31) / 32);
+    const int nfit = std::max(1, (int)((96 * 1024) / (1024 * sizeof(T))) - 4);
+    const size_t lds_tri = (size_t)(std::min(nblk_t, nfit) + 4) * 1024 * sizeof(T);
     if (lds32 > 160 * 1024) throw StatusError{NMFX_ERR_UNSUPPORTED, "projals: k too large for the single-workgroup Cholesky panel (k <= 1248 f32 / 608 f64)"};
     timed(tag_potrf, (double)k * k * k / 3.0, 0.0, [&] {
         if (lambda != (T)0)   // adddiag! skips lambda == 0 (src/utils.jl:18)
@@ -33,7 +36,7 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tri));
         const unsigned nblk = (unsigned)((k + 31) / 32);
         hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3(nblk), dim3(64), 0, stream, A, Uinv, K, (int)k, done);
-        hipLaunchKernelGGL((trtri_offdiag_kernel<T>), dim3(nblk), dim3(256), lds_tri, stream, A, Uinv, K, (int)k, done);
+        hipLaunchKernelGGL((trtri_offdiag_kernel<T>), dim3(nblk), dim3(256), lds_tri, stream, A, Uinv, K, (int)k, nfit, done);
         HIP_TRY(hipGetLastError());
     });
 }

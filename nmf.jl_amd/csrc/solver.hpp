@@ -798,6 +798,16 @@ template <typename T> class Solver : public SolverBase {
             Seg sg;
             sg.tail_main = shg.leftover; sg.tail_per = shg.per;
             gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done, (double)(P * N + P * K) * sizeof(T), sg);
+            if (!keep_slabs || h_nslab > 2) {   // pieces + slabs in one launch
+                timed("reduce_WtX", 0.0, (double)K * N * (h_nslab + 1) * sizeof(T), [&] {
+                    hipLaunchKernelGGL(reduce_slabs_tail_kernel<T>, dim3((unsigned)((K * N + 255) / 256)), dim3(256), 0, stream, numH_p, reg, (int64_t)K * N,
+                                       h_nslab, h_stride, slabs.p + gram_slab_off, shg.pieces, lines * 128 * K, 0, c0 * K, lines * 128 * K, (int64_t)0,
+                                       (int64_t)0, (int64_t)0, done);
+                    HIP_TRY(hipGetLastError());
+                });
+                h_in_slabs = false;
+                return;
+            }
             reduce_pieces("reduce_WtX_pieces", reg + (int64_t)(s_h - 1) * h_stride + c0 * K, lines * 128 * K, slabs.p + gram_slab_off, 1, lines * 128 * K,
                           shg.pieces, done);
         } else
@@ -868,6 +878,15 @@ template <typename T> class Solver : public SolverBase {
             Seg sg;
             sg.tail_main = shg.leftover; sg.tail_per = shg.per;
             gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done, (double)(P * N + K * N) * sizeof(T), sg);
+            if (!w_blocked && (!keep_slabs || w_nslab > 2)) {   // pieces + slabs in one launch
+                timed("reduce_XHt", 0.0, (double)P * K * (w_nslab + 1) * sizeof(T), [&] {
+                    hipLaunchKernelGGL(reduce_slabs_tail_kernel<T>, dim3((unsigned)(P / 256 * K)), dim3(256), 0, stream, numW_p, reg, (int64_t)P * K, w_nslab,
+                                       w_stride, slabs.p + gram_slab_off, shg.pieces, rows * K, 1, (int64_t)0, (int64_t)0, P, r0, rows, done);
+                    HIP_TRY(hipGetLastError());
+                });
+                w_in_slabs = false;
+                return;
+            }
             reduce_pieces("reduce_XHt_pieces", reg + (int64_t)(s_w - 1) * w_stride + r0, P, slabs.p + gram_slab_off, K, rows, shg.pieces, done);
         } else
         gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,

@@ -51,6 +51,36 @@ def test_projals_trajectory(built, T, shape):
     assert np.all(Wg >= 0) and np.all(Hg >= 0)
 
 
+@pytest.mark.parametrize("T,k", [(np.float64, 520), (np.float32, 1160)])
+def test_projals_k_beyond_one_lds_column(built, T, k):
+    """The reference's pdsolve! / pdrsolve! (src/utils.jl:63-84) have no size limit; the blocked triangular inverse used to refuse
+    k > 512 (Float64) / k > 1152 (Float32) -- a block column of finished tiles no longer fitted the LDS (round 2:
+    `1200x1100 k=513 float64 projals: k too large`).  Now the tiles beyond the LDS budget are read back from global memory."""
+    p, n = k + 40, k + 90
+    # (f32: a regularisation that keeps the Grams well conditioned -- with lambda = 0.5 the two CPU precisions already disagree by 5 %)
+    lam, k0 = (0.5, 12) if T == np.float64 else (20.0, 40)
+    X, W0, H0 = planted(p, n, k, T, seed=5, normalize=False, zeroh=True, k0=k0)
+    iters = 3
+    alg = nmfx.ProjectedALS(T, maxiter=iters, tol=1e-30, lambda_w=lam, lambda_h=lam)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg, track_objective=True)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=iters, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+    assert r.niters == ro.niters == iters
+    tol = 1e-7 if T == np.float64 else 1e-3    # f32: 1160-term fp32 accumulations in the explicit-inverse products (measured 3.7e-4)
+    assert rel_trace_err(r.trace, ro.trace) < tol
+    assert np.max(np.abs(Wg - Wc)) <= 50 * tol * np.max(np.abs(Wc))
+    assert np.max(np.abs(Hg - Hc)) <= 50 * tol * np.max(np.abs(Hc))
+    # and the exported utilities at the same size (test/utils.jl:48-63 identities)
+    rng = np.random.default_rng(3)
+    A = rng.random((k, k)).astype(T)
+    A = np.asfortranarray(A @ A.T + k * np.eye(k, dtype=T))
+    Bm = np.asfortranarray(rng.random((k, 7)).astype(T))
+    with nmfx.Context(T, k, 7, k) as ctx:
+        Xs = ctx.pdsolve(A, Bm)
+    assert np.max(np.abs(A.astype(np.float64) @ Xs - Bm)) <= (1e-9 if T == np.float64 else 2e-3) * np.max(np.abs(Bm))
+
+
 @pytest.mark.parametrize("T", [np.float64, np.float32])
 def test_projals_default_options_and_stop(built, T):
     """Default lambda = cbrt(eps(T)) (src/projals.jl:30-31), H0 = 0 as nnmf passes it (src/interf.jl:39,43)."""

@@ -236,7 +236,7 @@ __device__ __forceinline__ double greedy_div(double g, double den, double) { ret
 
 template <typename T> __device__ __forceinline__ void greedy_sd(T w, T g, T prr, T den, double rden, T &s, T &d) {
     T t = op_sub(w, greedy_div(g, den, rden));
-    t = (t > (T)0) ? t : ((t != t) ? t : (T)0);
+    t = (t <= (T)0) ? (T)0 : t;   // max(zero(T), t): a NaN fails the comparison and passes through like Julia's max (one compare instead of two)
     s = op_sub(t, w);
     d = op_sub(op_mul(-g, s), op_mul(op_mul((T)0.5, prr), op_mul(s, s)));
 }
@@ -272,6 +272,22 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ void max_dpp_step(d
     const double ov = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
     v = (ov > v) ? ov : v;
 }
+// Float32: the maximum and the DPP lane shift in ONE instruction (v_max_f32_dpp; lanes without a source lane are disabled by the DPP
+// bound check and keep their value, which is what the -inf identity of the generic form achieves with a move, a compare and a
+// select).  The compiler does not form it from the generic code; the s_nop covers the VALU-write -> DPP-read hazard, which its
+// hazard recogniser cannot see inside an asm statement.  Same value as the generic form for non-NaN inputs (signed zeros compare
+// equal everywhere the result is used).
+__device__ __forceinline__ float wave_max_uniform(float v) {
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return lane63(v);
+}
 template <typename T> __device__ __forceinline__ T wave_max_uniform(T v) {
     max_dpp_step<0x111, 0xf>(v);
     max_dpp_step<0x112, 0xf>(v);
@@ -303,12 +319,13 @@ template <typename T, int KMAX> struct GreedyRow {
     // arg-max of D with the first index on ties: the VALUE by a DPP max reduction (2 operations per step instead of the 7 of a
     // (value, index) reduction -- this sits on every greedy step's dependency chain), then the index from wave ballots: slots are
     // visited in ascending m and a slot's lowest set lane is its smallest component index c = lane + 64 m
-    __device__ __forceinline__ void argmax(int k, int km, int lane, T &best, int &q) const {
+    // FULL: k == 64 * KMAX -- every (lane, slot) is a live component, no validity masks
+    template <bool FULL = false> __device__ __forceinline__ void argmax(int k, int km, int lane, T &best, int &q) const {
         best = -INFINITY;
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
             const int c = lane + 64 * m;
-            const bool take = (m < km) && (c < k) && (d[m] > best);
+            const bool take = (FULL || ((m < km) && (c < k))) && (d[m] > best);
             best = take ? d[m] : best;
         }
         best = wave_max_uniform(best);
@@ -316,7 +333,7 @@ template <typename T, int KMAX> struct GreedyRow {
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
             const int c = lane + 64 * m;
-            const unsigned long long hit = __ballot((m < km) && (c < k) && (d[m] == best));
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64((FULL || ((m < km) && (c < k))) && (d[m] == best));
             if (hit != 0ull && q == 0x7fffffff) q = 64 * m + (int)__builtin_ctzll(hit);
         }
     }
@@ -365,9 +382,9 @@ template <typename T> __global__ void greedy_pinit_reduce_kernel(const T *part, 
 }
 
 // The sweep of one sample row by one wave; `fetch(q, m)` returns P(q, lane + 64 m) (q wave-uniform).
-template <typename T, int KMAX, typename Fetch>
-__device__ __forceinline__ void greedy_sweep_row(SampleView<const T> Wold, SampleView<T> Wout, SampleView<const T> G, const T *__restrict__ P, int64_t ldp,
-                                                 int64_t i, int k, T lambda, T epsT, const T *pinit, long long *steps_total, int lane, Fetch fetch) {
+template <typename T, int KMAX, bool FULL, typename Fetch>
+__device__ __forceinline__ long long greedy_sweep_row(SampleView<const T> Wold, SampleView<T> Wout, SampleView<const T> G, const T *__restrict__ P, int64_t ldp,
+                                                      int64_t i, int k, T lambda, T epsT, const T *pinit, int lane, Fetch fetch) {
     const int km = (k + 63) / 64;
     GreedyRow<T, KMAX> row;
     row.load(Wold, G, P, ldp, i, k, km, lane, lambda, epsT);
@@ -376,7 +393,7 @@ __device__ __forceinline__ void greedy_sweep_row(SampleView<const T> Wold, Sampl
     for (int m = 0; m < KMAX; ++m) wnew[m] = (T)0;
     const T thresh = op_mul((T)0.001, pinit[0]);   // nu * p_init
     T dq; int q;
-    row.argmax(k, km, lane, dq, q);
+    row.template argmax<FULL>(k, km, lane, dq, q);
     const long long max_steps = (long long)k * k;
     long long step = 0;
     for (; step < max_steps; ++step) {
@@ -387,18 +404,31 @@ __device__ __forceinline__ void greedy_sweep_row(SampleView<const T> Wold, Sampl
 #pragma unroll
         for (int m = 1; m < KMAX; ++m) sq_owner = (m == qm) ? row.s[m] : sq_owner;
         const T sq = lane_read(sq_owner, ql);
+        if constexpr (FULL) {
+            // all KMAX loads of the row P(q, :) in flight at once, then the arithmetic (the per-slot `m < km` test of the general
+            // form below is a branch per slot, each with its own load -> wait -> compute round trip)
+            T pq[KMAX];
 #pragma unroll
-        for (int m = 0; m < KMAX; ++m) {
-            wnew[m] = (m == qm && lane == ql) ? op_add(wnew[m], sq) : wnew[m];
-            if (m < km) {                             // uniform; lanes c in [k, K) of a live slot read P's zero padding: G stays put
-                const T pq = fetch(q, m);
-                row.g[m] = op_add(row.g[m], op_mul(sq, pq));
+            for (int m = 0; m < KMAX; ++m) pq[m] = fetch(q, m);
+#pragma unroll
+            for (int m = 0; m < KMAX; ++m) {
+                wnew[m] = (m == qm && lane == ql) ? op_add(wnew[m], sq) : wnew[m];
+                row.g[m] = op_add(row.g[m], op_mul(sq, pq[m]));
                 greedy_sd(row.w[m], row.g[m], row.prr[m], row.den[m], row.rden[m], row.s[m], row.d[m]);
             }
+        } else {
+#pragma unroll
+            for (int m = 0; m < KMAX; ++m) {
+                wnew[m] = (m == qm && lane == ql) ? op_add(wnew[m], sq) : wnew[m];
+                if (m < km) {                             // uniform; lanes c in [k, K) of a live slot read P's zero padding: G stays put
+                    const T pq = fetch(q, m);
+                    row.g[m] = op_add(row.g[m], op_mul(sq, pq));
+                    greedy_sd(row.w[m], row.g[m], row.prr[m], row.den[m], row.rden[m], row.s[m], row.d[m]);
+                }
+            }
         }
-        row.argmax(k, km, lane, dq, q);
+        row.template argmax<FULL>(k, km, lane, dq, q);
     }
-    if (steps_total != nullptr && lane == 0 && step > 0) atomicAdd((unsigned long long *)steps_total, (unsigned long long)step);
 #pragma unroll
     for (int m = 0; m < KMAX; ++m) {
         const int c = lane + 64 * m;
@@ -408,6 +438,7 @@ __device__ __forceinline__ void greedy_sweep_row(SampleView<const T> Wold, Sampl
             Wout.at(i, c) = v;
         }
     }
+    return step;
 }
 
 template <typename T, int KMAX>
@@ -415,11 +446,23 @@ __global__ __launch_bounds__(256) void greedy_sweep_kernel(SampleView<const T> W
                                                            const T *__restrict__ P, int64_t ldp, int64_t nsamples, int k, T lambda,
                                                            T epsT, const T *pinit, long long *steps_total, const int *done) {
     NMFX_DONE_GUARD(done);
+    __shared__ long long nsteps[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
-    if (i >= nsamples) return;
-    greedy_sweep_row<T, KMAX>(Wold, Wout, G, P, ldp, i, k, lambda, epsT, pinit, steps_total, lane,
-                              [&](int q, int m) { return P[(int64_t)q * ldp + lane + 64 * m]; });
+    long long steps = 0;
+    if (i < nsamples) {
+        auto fetch = [&](int q, int m) { return P[(int64_t)q * ldp + lane + 64 * m]; };
+        if (k == 64 * KMAX) steps = greedy_sweep_row<T, KMAX, true>(Wold, Wout, G, P, ldp, i, k, lambda, epsT, pinit, lane, fetch);
+        else steps = greedy_sweep_row<T, KMAX, false>(Wold, Wout, G, P, ldp, i, k, lambda, epsT, pinit, lane, fetch);
+    }
+    // executed greedy steps (nmfx_result.inner_iters): one atomic per block, not per row (16384 atomics on one address are
+    // serialised at ~30 ns each on this chip)
+    if (lane == 0) nsteps[wave] = steps;
+    __syncthreads();
+    if (threadIdx.x == 0 && steps_total != nullptr) {
+        const long long tot = nsteps[0] + nsteps[1] + nsteps[2] + nsteps[3];
+        if (tot > 0) atomicAdd((unsigned long long *)steps_total, (unsigned long long)tot);
+    }
 }
 
 // (Measured and dropped: the same sweep with the packed upper triangle of P -- 131.6 KB for K = 256 in Float32 -- resident in LDS,

@@ -240,7 +240,7 @@ typedef struct nmfx_local_group nmfx_local_group;
 int nmfx_comm_get_unique_id(void *out_bytes /* NMFX_UNIQUE_ID_BYTES */);
 int nmfx_comm_init(nmfx_ctx *ctx, const void *unique_id_bytes, int rank, int nranks);
 int nmfx_local_group_create(nmfx_local_group **out, int nranks);   /* nranks <= 16 */
-void nmfx_local_group_destroy(nmfx_local_group *group);            /* after every attached context is destroyed */
+void nmfx_local_group_destroy(nmfx_local_group *group);            /* contexts still attached keep the group alive: freed when the last one is destroyed */
 int nmfx_comm_init_local(nmfx_ctx *ctx, nmfx_local_group *group, int rank);
 int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode);
 /* Measurement aid (no reference counterpart, results are NOT a factorisation): "rank r of n" without peers -- collectives move

@@ -46,26 +46,40 @@ void Solver<T>::cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<co
     }
 }
 
-// The component orders of a CoordinateDescent(shuffle = true) solve, all of them up front (2 * maxiter calls x k components):
-// call c = 2*(t-1) + side sweeps in the order that sorts the keys Philox4x32-10((i, c, 4, 0), key = cd_shuffle)[0], i < k
-// (include/nmfx.h; NumPy twin: tests/philox_ref.py::cd_permutation).
+// The component orders of a CoordinateDescent(shuffle = true) solve: call c = 2*(t-1) + side sweeps in the order that sorts the keys
+// Philox4x32-10((i, c, 4, 0), key = cd_shuffle)[0], i < k (include/nmfx.h; NumPy twin: tests/philox_ref.py::cd_permutation).
+// Generated lazily, a window of CD_PERM_WINDOW iterations at a time (2 * window * k ints on the device): a solve with a huge
+// maxiter and a tolerance that stops it after a few iterations pays for one window, not for 2 * maxiter * k orders up front.
+// The upload is stream-ordered behind the sweeps that still read the previous window.
 template <typename T> void Solver<T>::prepare_cd_permutations(const nmfx_opts &o) {
-    const uint64_t key = (uint64_t)(int64_t)o.cd_shuffle;   // sign-extended 32-bit field
-    const size_t calls = (size_t)2 * (size_t)o.maxiter;
-    std::vector<int> host(calls * (size_t)k);
-    std::vector<std::pair<uint32_t, int>> keys((size_t)k);
-    for (size_t c = 0; c < calls; ++c) {
-        for (int i = 0; i < (int)k; ++i) {
-            uint32_t w[4];
-            philox4x32_10((uint32_t)i, (uint32_t)c, 4u, 0u, (uint32_t)key, (uint32_t)(key >> 32), w);
-            keys[(size_t)i] = {w[0], i};
+    (void)o;
+    cd_perm_w0 = -1;   // no window resident: the first iteration generates [0, CD_PERM_WINDOW)
+}
+template <typename T> const int *Solver<T>::cd_permutation_window(const nmfx_opts &o, long long t) {
+    const long long it = t - 1;
+    if (cd_perm_w0 < 0 || it < cd_perm_w0 || it >= cd_perm_w0 + CD_PERM_WINDOW) {
+        const uint64_t key = (uint64_t)(int64_t)o.cd_shuffle;   // sign-extended 32-bit field
+        const long long w0 = it, w1 = std::min<long long>((long long)o.maxiter, w0 + CD_PERM_WINDOW);
+        const size_t calls = (size_t)2 * (size_t)(w1 - w0);
+        cd_perm_host.resize(calls * (size_t)k);
+        std::vector<std::pair<uint32_t, int>> keys((size_t)k);
+        for (size_t cc = 0; cc < calls; ++cc) {
+            const uint64_t c = (uint64_t)2 * (uint64_t)w0 + cc;
+            if (c >> 32) throw StatusError{NMFX_ERR_UNSUPPORTED, "cd: shuffle = true supports at most 2^31 iterations (the call index is a 32-bit Philox counter word)"};
+            for (int i = 0; i < (int)k; ++i) {
+                uint32_t w[4];
+                philox4x32_10((uint32_t)i, (uint32_t)c, 4u, 0u, (uint32_t)key, (uint32_t)(key >> 32), w);
+                keys[(size_t)i] = {w[0], i};
+            }
+            std::sort(keys.begin(), keys.end());
+            for (int i = 0; i < (int)k; ++i) cd_perm_host[cc * (size_t)k + (size_t)i] = keys[(size_t)i].second;
         }
-        std::sort(keys.begin(), keys.end());
-        for (int i = 0; i < (int)k; ++i) host[c * (size_t)k + (size_t)i] = keys[(size_t)i].second;
+        cd_perm.ensure((size_t)2 * CD_PERM_WINDOW * (size_t)k);
+        HIP_TRY(hipMemcpyAsync(cd_perm.p, cd_perm_host.data(), cd_perm_host.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));   // pageable source: the copy must have left the host vector before it is refilled
+        cd_perm_w0 = w0;
     }
-    cd_perm.ensure(host.size());
-    HIP_TRY(hipMemcpyAsync(cd_perm.p, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    return cd_perm.p + (size_t)(2 * (it - cd_perm_w0)) * (size_t)k;
 }
 
 // cd_sweep in the component order `perm` (nullptr: 1..k): rename in, sweep, rename out (cd.hpp)
@@ -90,8 +104,8 @@ void Solver<T>::cd_sweep_ordered(SampleView<const T> Zo, SampleView<T> Zn, Sampl
 
 template <typename T> void Solver<T>::enqueue_cd(const nmfx_opts &o, long long t) {
     const int *done = done_flag();
-    const int *perm_w = o.cd_shuffle ? cd_perm.p + (size_t)(2 * (t - 1)) * (size_t)k : nullptr;
-    const int *perm_h = o.cd_shuffle ? cd_perm.p + (size_t)(2 * (t - 1) + 1) * (size_t)k : nullptr;
+    const int *perm_w = o.cd_shuffle ? cd_permutation_window(o, t) : nullptr;
+    const int *perm_h = o.cd_shuffle ? perm_w + (size_t)k : nullptr;
     {   // ---- W (coorddesc.jl:166): HHt = H*Ht, XHt = X*Ht (:109-115)
         const T *Hp = H[hcur].p;
         const T *Wo = W[wcur].p;

@@ -143,6 +143,26 @@ struct LocalGroup {
     hipEvent_t ready[LOCAL_MAX_RANKS] = {}, done[LOCAL_MAX_RANKS] = {};
     int device[LOCAL_MAX_RANKS] = {};
     std::atomic<int> attached{0};
+    bool orphaned = false;   // nmfx_local_group_destroy was called while contexts were still attached: the last one to detach frees the group
+    static std::mutex &lifetime_mu() { static std::mutex m; return m; }
+    // owner's release (nmfx_local_group_destroy): immediate when no context is attached, deferred to the last detach otherwise
+    static void release(LocalGroup *g) {
+        bool now;
+        {
+            std::lock_guard<std::mutex> lk(lifetime_mu());
+            g->orphaned = true;
+            now = g->attached.load() == 0;
+        }
+        if (now) delete g;
+    }
+    static void detach(LocalGroup *g) {
+        bool now;
+        {
+            std::lock_guard<std::mutex> lk(lifetime_mu());
+            now = (g->attached.fetch_sub(1) == 1) && g->orphaned;
+        }
+        if (now) delete g;
+    }
     explicit LocalGroup(int n_) : n(n_) {}
     ~LocalGroup() {
         for (int i = 0; i < LOCAL_MAX_RANKS; ++i) {
@@ -178,11 +198,13 @@ struct LocalComm : Comm {
     LocalComm(LocalGroup *g_, int rank_, int device_) : g(g_), dev(device_) {
         rank = rank_;
         nranks = g->n;
+        // a rank that attaches again (a context re-using the slot) replaces the slot's events instead of leaking them
+        if (g->ready[rank]) { (void)hipEventDestroy(g->ready[rank]); g->ready[rank] = nullptr; }
+        if (g->done[rank]) { (void)hipEventDestroy(g->done[rank]); g->done[rank] = nullptr; }
         if (hipEventCreateWithFlags(&g->ready[rank], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming) != hipSuccess)
             throw CommError{"hipEventCreate failed"};
         g->device[rank] = device_;
-        g->attached.fetch_add(1);
         g->barrier();   // every rank has published its device
         for (int q = 0; q < nranks; ++q)
             if (g->device[q] != dev) {
@@ -190,9 +212,11 @@ struct LocalComm : Comm {
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) throw CommError{"hipDeviceEnablePeerAccess failed"};
                 (void)hipGetLastError();
             }
+        g->attached.fetch_add(1);   // last: a constructor that throws has no destructor to detach again
     }
     ~LocalComm() override {
         if (scratch) (void)hipFree(scratch);
+        LocalGroup::detach(g);
     }
     const char *transport() const override { return "local"; }
 

@@ -152,7 +152,9 @@ int nmfx_local_group_create(nmfx_local_group **out, int nranks) {
     return NMFX_OK;
 }
 
-void nmfx_local_group_destroy(nmfx_local_group *group) { delete reinterpret_cast<LocalGroup *>(group); }
+void nmfx_local_group_destroy(nmfx_local_group *group) {
+    if (group) LocalGroup::release(reinterpret_cast<LocalGroup *>(group));   // deferred while contexts are still attached
+}
 
 int nmfx_comm_init_local(nmfx_ctx *ctx, nmfx_local_group *group, int rank) {
     LocalGroup *g = reinterpret_cast<LocalGroup *>(group);

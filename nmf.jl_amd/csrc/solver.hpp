@@ -991,7 +991,11 @@ template <typename T> class Solver : public SolverBase {
     void enqueue_greedycd(const nmfx_opts &o, long long t);
     template <typename F> void with_kmax(F &&f);
     void prepare_cd_permutations(const nmfx_opts &o);
-    DevBuf<int> cd_perm;   // CoordinateDescent(shuffle = true): the component orders of every call of the solve
+    const int *cd_permutation_window(const nmfx_opts &o, long long t);
+    static constexpr long long CD_PERM_WINDOW = 256;
+    DevBuf<int> cd_perm;   // CoordinateDescent(shuffle = true): the component orders of a window of iterations
+    std::vector<int> cd_perm_host;
+    long long cd_perm_w0 = -1;
     void cd_sweep_ordered(SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> Num, const T *Pm, int64_t nsamples, T l1,
                           const int *perm, int64_t offset, const int *done);
     void cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> Num, const T *Pm, int64_t nsamples, T l1, const int *done);

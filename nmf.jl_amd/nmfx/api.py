@@ -466,9 +466,22 @@ class LocalGroup:
         self.h, self.nranks = h, nranks
 
     def close(self):
+        """Releases the group; if contexts are still attached the library frees it when the last of them closes."""
         if getattr(self, "h", None):
             self.lib.nmfx_local_group_destroy(self.h)
             self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def comm_unique_id() -> bytes:
@@ -767,7 +780,11 @@ def _nnmf_device(X, k, init, alg, maxiter, tol, replicates, W0, H0, update_H, ve
             if init == "random":
                 ctx.randinit(seed, normalize=True, zeroh=not initH)
             elif init == "spa":                                          # src/interf.jl:50-51
-                ctx.spa_init()
+                _, unsolved = ctx.spa_init()
+                if unsolved > 0:                                         # like NMFX.jl's spa!: the reference's fnnls always returns the minimiser
+                    import warnings
+                    warnings.warn(f"spa: the active-set least-squares solve of {unsolved} column(s) of H stopped at its iteration cap or "
+                                  "on a Cholesky breakdown; those columns hold a feasible but not optimal H", RuntimeWarning, stacklevel=2)
             else:                                                        # src/interf.jl:44-49
                 if initdata is None:
                     ctx.rsvd(seed, download=False)                       # rsvd(X, k), src/initialization.jl:83

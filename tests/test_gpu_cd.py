@@ -176,6 +176,30 @@ def test_cd_shuffle_matches_oracle(built, T, shape, update_H):
     assert not np.array_equal(W, W2)
 
 
+def test_cd_shuffle_orders_beyond_one_window(built):
+    """The component orders are generated a window of 256 iterations at a time (all 2 * maxiter * k orders used
+    to be built before the first iteration): a solve that crosses a window boundary still follows the oracle's orders, and a huge
+    maxiter with a tolerance that stops the solve early costs one window."""
+    import philox_ref
+    T = np.float64
+    p, n, k = 40, 56, 4
+    X, W0, H0 = planted(p, n, k, T, seed=12)
+    seed, iters = 91, 300
+    inst = nmfx.CoordinateDescent(T, maxiter=iters, tol=1e-30, alpha=1e-3, l1ratio=0.5, shuffle=True, shuffle_seed=seed)
+    W, H = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(inst, X, W, H)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    o = orc.Opts(maxiter=iters, tol=1e-30, l1_w=inst.l1_w, l2_w=inst.l2_w, l1_h=inst.l1_h, l2_h=inst.l2_h,
+                 perm_source=lambda c: philox_ref.cd_permutation(k, seed, c))
+    ro = orc.solve("cd", X, Wc, Hc, o)
+    assert r.niters == ro.niters == iters
+    assert abs(r.objvalue - ro.objvalue) <= 1e-9 * abs(ro.objvalue)
+    assert np.max(np.abs(W - Wc)) <= 1e-7 * np.max(np.abs(Wc)) and np.max(np.abs(H - Hc)) <= 1e-7 * np.max(np.abs(Hc))
+    W2, H2 = W0.copy(order="F"), H0.copy(order="F")
+    r2 = nmfx.solve(nmfx.CoordinateDescent(T, maxiter=2_000_000_000, tol=1e-3, alpha=1e-3, l1ratio=0.5, shuffle=True, shuffle_seed=seed), X, W2, H2)
+    assert r2.converged and r2.niters < 2000
+
+
 def test_cd_shuffle_reference_kat(built):
     """test/coorddesc.jl:10-14 on the GPU path: alpha = 1e-4, l1ratio = 0.5, shuffle = true reconstructs X to 1e-2."""
     for T in (np.float64, np.float32):

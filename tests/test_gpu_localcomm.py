@@ -269,6 +269,43 @@ def test_sharded_front_end_rsvd_nndsvd(built, T):
     assert np.array_equal(out[0][4], out[1][4])
 
 
+def test_group_released_before_its_contexts(built):
+    """nmfx_local_group_destroy while contexts are still attached: the group stays alive until the last attached
+    context is destroyed -- the contexts keep working, nothing is freed under them."""
+    T = np.float64
+    p, n, k, G = 128, 96, 4, 2
+    X, W0, H0 = planted(p, n, k, T, seed=2)
+    group = nmfx.LocalGroup(G)
+    out, errs = [None] * G, []
+    released = threading.Event()
+
+    def worker(r):
+        try:
+            c0, c1 = nmfx.dist.shard_range(n, r, G)
+            with nmfx.Context(T, p, c1 - c0, k) as ctx:
+                ctx.comm_init_local(group, r)
+                ctx.set_X(np.asfortranarray(X[:, c0:c1]))
+                released.wait(60)                                   # the owner has released the group by now
+                W, H = W0.copy(order="F"), np.asfortranarray(H0[:, c0:c1].copy())
+                res, _ = ctx.solve(ALG["multmse"], nmfx.make_opts(T, maxiter=5, tol=1e-30), W, H)
+                out[r] = (W, res)
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    import time
+    time.sleep(1.0)                                                 # both ranks are attached (comm_init_local is collective)
+    group.close()
+    released.set()
+    for t in th:
+        t.join(120)
+    assert not errs, errs
+    assert out[0] is not None and out[1] is not None and out[0][1].niters == 5
+    assert np.array_equal(out[0][0], out[1][0])
+
+
 def test_sharded_cd_shuffle(built):
     """CoordinateDescent(shuffle = true) on the row-sharded path: every rank derives the same component orders from the key."""
     import philox_ref

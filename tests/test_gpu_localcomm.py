@@ -278,12 +278,14 @@ def test_group_released_before_its_contexts(built):
     group = nmfx.LocalGroup(G)
     out, errs = [None] * G, []
     released = threading.Event()
+    attached = [threading.Event() for _ in range(G)]
 
     def worker(r):
         try:
             c0, c1 = nmfx.dist.shard_range(n, r, G)
             with nmfx.Context(T, p, c1 - c0, k) as ctx:
                 ctx.comm_init_local(group, r)
+                attached[r].set()
                 ctx.set_X(np.asfortranarray(X[:, c0:c1]))
                 released.wait(60)                                   # the owner has released the group by now
                 W, H = W0.copy(order="F"), np.asfortranarray(H0[:, c0:c1].copy())
@@ -295,8 +297,8 @@ def test_group_released_before_its_contexts(built):
     th = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
     for t in th:
         t.start()
-    import time
-    time.sleep(1.0)                                                 # both ranks are attached (comm_init_local is collective)
+    for ev in attached:
+        assert ev.wait(120)                                         # both ranks are attached
     group.close()
     released.set()
     for t in th:

@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="do not bracket launches with hipEvents (no roofline object)")
     ap.add_argument("--all-events", action="store_true", help="hipEvent pair around every launch (per-kernel table; slows the loop ~4%%)")
     ap.add_argument("--cpu-sample-cols", type=int, default=2048)
+    ap.add_argument("--check-every", type=int, default=1 << 30,
+                    help="iterations between the host's polls of the device stop flag (default: never inside the timed region; the "
+                         "API default is 4 -- small problems pay a host round trip per poll)")
     ap.add_argument("--sim-ranks", type=int, default=0,
                     help="measurement aid (1 GPU): time rank 0's COMPUTE of an N-rank run -- X, H are the rank's column shard, the "
                          "collectives move their bytes device-locally (results are not a factorisation; never a headline number)")
@@ -145,7 +148,7 @@ def main():
     tiny = float(np.finfo(T).tiny)      # stop rule can never fire: exactly K iterations are executed
 
     def opts(iters):
-        return nmfx.make_opts(T, maxiter=iters, tol=tiny, lambda_w=lam, lambda_h=lam, check_every=1 << 30,
+        return nmfx.make_opts(T, maxiter=iters, tol=tiny, lambda_w=lam, lambda_h=lam, check_every=a.check_every,
                               maxsubiter=a.maxsubiter, precision=a.precision)
 
     def barrier():
@@ -239,7 +242,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"X={p}x{n} k={k} {a.dtype} alg=:{a.alg} (planted-rank dense X, seed {SEED}), "
                                    f"column-sharded over {world} GPU(s)", "p": p, "n": n, "k": k,
-                       "parallelism": f"colshard{world}" + (f"+{a.comm_mode}" if world > 1 else ""), "precision": a.precision},
+                       "parallelism": f"colshard{world}" + (f"+{a.comm_mode}" if world > 1 else ""), "precision": a.precision,
+                       "check_every": (a.check_every if a.check_every < (1 << 30) else "never (stop rule evaluated on the device only)")},
             "gflops_algorithmic": round(f_alg * a.steps / dt / 1e9, 1),
             "frac_of_mfma_peak": round(f_alg * a.steps / dt / 1e12 / (((2500.0 / 3.0) if a.precision == "bf16x3" else
                                                                         (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6)) * world), 4),

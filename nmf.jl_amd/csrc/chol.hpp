@@ -40,8 +40,11 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 // broadcasts);  (2) the 32 x m row panel is staged through LDS with coalesced loads and solved one column per
 // thread;  (3) the trailing update A22 -= R'R runs on the matrix cores (MFMA 32x32x2 f32 / 16x16x4 f64) with
 // both operands read from the LDS panel -- the same [k][row] image the GEMM template calls KSTRIDED.
-template <typename T>
-__global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int k, Ctrl *ctrl, int posdef_status) {
+// GPANEL: the row panel lives in a global scratch buffer (`gpanel`, 32 x kps elements, L2-resident) instead of LDS -- the fallback for
+// k beyond what one workgroup's LDS holds (k > 1248 in Float32, 608 in Float64): slower (every panel access is a global round trip,
+// ordered inside the workgroup by the barriers), but the reference's potrf! has no size limit either.
+template <typename T, bool GPANEL = false>
+__global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int k, Ctrl *ctrl, int posdef_status, T *gpanel = nullptr) {
     if (ctrl != nullptr && ctrl->done) return;
     // ProjectedALS runs this workgroup on a CU it shares with a block of the big product (projals_impl.hpp): its waves are the
     // YOUNGER ones on their SIMDs and lose every issue arbitration against the GEMM's waves (4x slower than alone).  The
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int
     const int kp0 = (k + 31) / 32 * 32;
     const int kp = (kp0 > 64) ? kp0 - 32 : 32;          // row stride of the panel image (>= the widest panel, m <= k - 32)
     T *U11 = reinterpret_cast<T *>(chol_smem);          // U11[i*NB + l] = U(jb+l, jb+i)  (transposed copy), l <= i
-    T *Rp = U11 + NB * NB;                              // Rp[l*kp + c]  = U(jb+l, jb+nb+c), zero for c >= m
+    T *Rp = GPANEL ? gpanel : U11 + NB * NB;            // Rp[l*kp + c]  = U(jb+l, jb+nb+c), zero for c >= m
     int *failp = reinterpret_cast<int *>(U11 + 1);      // (i = 0, l = 1) lies in the never-touched half of the transposed block
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
     if (tid == 0) *failp = 0;

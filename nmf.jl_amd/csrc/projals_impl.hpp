@@ -21,13 +21,20 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
     const int nblk_t = (int)((k + 31) / 32);
     const int nfit = std::max(1, (int)((96 * 1024) / (1024 * sizeof(T))) - 4);
     const size_t lds_tri = (size_t)(std::min(nblk_t, nfit) + 4) * 1024 * sizeof(T);
-    if (lds32 > 160 * 1024) throw StatusError{NMFX_ERR_UNSUPPORTED, "projals: k too large for the single-workgroup Cholesky panel (k <= 1248 f32 / 608 f64)"};
+    const bool gpanel = lds32 > 160 * 1024;   // the row panel no longer fits one workgroup's LDS: keep it in a global scratch buffer
+    if (gpanel) potrf_panel.ensure(lds32 / sizeof(T));
     timed(tag_potrf, (double)k * k * k / 3.0, 0.0, [&] {
         if (lambda != (T)0)   // adddiag! skips lambda == 0 (src/utils.jl:18)
             hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, A, K, (int)k, lambda, done);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_upper_kernel<T>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
-        hipLaunchKernelGGL((potrf_upper_kernel<T>), dim3(1), dim3(potrf_nt), lds32, stream, A, K, (int)k, ctrl, (int)NMFX_ERR_NOT_POSDEF);
+        if (gpanel) {
+            hipLaunchKernelGGL((potrf_upper_kernel<T, true>), dim3(1), dim3(potrf_nt), (size_t)(32 * 32 + 64) * sizeof(T), stream, A, K, (int)k, ctrl,
+                               (int)NMFX_ERR_NOT_POSDEF, potrf_panel.p);
+        } else {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_upper_kernel<T, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+            hipLaunchKernelGGL((potrf_upper_kernel<T, false>), dim3(1), dim3(potrf_nt), lds32, stream, A, K, (int)k, ctrl, (int)NMFX_ERR_NOT_POSDEF,
+                               (T *)nullptr);
+        }
         HIP_TRY(hipGetLastError());
     });
     timed(tag_trtri, (double)k * k * k / 3.0, 0.0, [&] {

@@ -396,6 +396,7 @@ template <typename T> class Solver : public SolverBase {
     DevBuf<T> X, Q, W[2], H[2], hside, slabs, svec, pack;
     T *numH_p = nullptr, *gramW_p = nullptr;
     T *numW_p = nullptr, *gramH_p = nullptr, *sH_p = nullptr;
+    DevBuf<T> potrf_panel;   // potrf's row panel when it does not fit the LDS (k > 1248 f32 / 608 f64)
     DevBuf<T> work[8];   // algorithm-specific scratch (projals factor/inverse, alspgrad G/Zn/Zp/D/GD)
     DevBuf<double> stat_part, wstat, hstat, obj_part, obj_extra, obj_final, trace_dev;
     Ctrl *ctrl = nullptr, *ctrl_host = nullptr;

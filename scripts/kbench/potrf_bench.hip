@@ -32,7 +32,7 @@ template <typename T> int run(int k) {
     for (int rep = 0; rep < 5; ++rep) {
         CK(hipMemcpy(dU, A.data(), A.size() * sizeof(T), hipMemcpyHostToDevice));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((potrf_upper_kernel<T>), dim3(1), dim3(1024), lds, 0, dU, (int64_t)K, k, ctrl, 3);
+        hipLaunchKernelGGL((potrf_upper_kernel<T>), dim3(1), dim3(1024), lds, 0, dU, (int64_t)K, k, ctrl, 3, (T *)nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best_p = std::min(best_p, ms);
         CK(hipMemset(dInv, 0, A.size() * sizeof(T)));

@@ -51,11 +51,12 @@ def test_projals_trajectory(built, T, shape):
     assert np.all(Wg >= 0) and np.all(Hg >= 0)
 
 
-@pytest.mark.parametrize("T,k", [(np.float64, 520), (np.float32, 1160)])
+@pytest.mark.parametrize("T,k", [(np.float64, 520), (np.float32, 1160), (np.float64, 640), (np.float32, 1300)])
 def test_projals_k_beyond_one_lds_column(built, T, k):
     """The reference's pdsolve! / pdrsolve! (src/utils.jl:63-84) have no size limit; the blocked triangular inverse used to refuse
     k > 512 (Float64) / k > 1152 (Float32) -- a block column of finished tiles no longer fitted the LDS (round 2:
-    `1200x1100 k=513 float64 projals: k too large`).  Now the tiles beyond the LDS budget are read back from global memory."""
+    `1200x1100 k=513 float64 projals: k too large`).  Now the tiles beyond the LDS budget are read back from global memory, and
+    beyond k = 608 (Float64) / 1248 (Float32) the factorisation's row panel moves to a global scratch buffer as well."""
     p, n = k + 40, k + 90
     # (f32: a regularisation that keeps the Grams well conditioned -- with lambda = 0.5 the two CPU precisions already disagree by 5 %)
     lam, k0 = (0.5, 12) if T == np.float64 else (20.0, 40)

@@ -495,4 +495,135 @@ __global__ void finish_sumabs_kernel(const double *partial, int n, T lambda, dou
     extra[slot] = (double)(T)(lambda * (T)s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k > 1024: the components of a sample row no longer fit the register file.  Same sweeps, one wave (= one workgroup) per
+// sample row, the row's component vectors in LDS (component r at slot r: lane r % 64 reads it, conflict-free).  Every
+// expression, the per-lane accumulation order (slots ascending) and the butterfly / DPP reductions are those of the
+// register kernels above, so for a k both forms can run the results are bit-identical (tests/test_gpu_cd.py forces this
+// form at small k with NMFX_CD_LDS=1).  The reference's loops (src/coorddesc.jl:133-156, src/greedycd.jl:134-158) have no
+// size limit; this form's is the 160 KiB of LDS: k <= 20480 (cd, f32), ~4400 (greedycd, f32), ~2800 (greedycd, f64).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void cd_sweep_lds_kernel(SampleView<const T> Wold, SampleView<T> Wnew, SampleView<const T> Z,
+                                                          const T *__restrict__ P, int64_t ldp, int64_t nsamples, int k, T l1, const int *done) {
+    NMFX_DONE_GUARD(done);
+    extern __shared__ __attribute__((aligned(16))) unsigned char cd_lds_raw[];
+    const int lane = threadIdx.x, kp = (k + 63) / 64 * 64;
+    T *w = reinterpret_cast<T *>(cd_lds_raw), *z = w + kp;
+    const int64_t i = blockIdx.x;
+    for (int c = lane; c < kp; c += 64) {
+        w[c] = (c < k) ? Wold.at(i, c) : (T)0;
+        z[c] = (c < k) ? (T)(Z.at(i, c) - l1) : (T)0;
+    }
+    __syncthreads();
+    for (int t = 0; t < k; ++t) {
+        T part = (T)0;
+        for (int c = lane; c < kp; c += 64) part += ((c < k) ? P[(int64_t)t * ldp + c] : (T)0) * w[c];
+        const T hess = P[(int64_t)t * ldp + t];
+        const T grad = wave_sum(part) - z[t];
+        T nw = w[t] - grad / hess;
+        nw = (nw > (T)0) ? nw : ((nw != nw) ? nw : (T)0);
+        __syncthreads();                       // every lane has read w[t]
+        if (hess != (T)0 && lane == 0) w[t] = nw;
+        __syncthreads();
+    }
+    for (int c = lane; c < k; c += 64) Wnew.at(i, c) = w[c];
+}
+
+// the row's state in LDS: w, g, s, d, prr, den, wnew (T) and rden (double), kp elements each
+template <typename T> struct GreedyLds {
+    T *w, *g, *s, *d, *prr, *den, *wn;
+    double *rden;
+    __device__ __forceinline__ GreedyLds(unsigned char *raw, int kp) {
+        rden = reinterpret_cast<double *>(raw);
+        w = reinterpret_cast<T *>(rden + kp);
+        g = w + kp; s = g + kp; d = s + kp; prr = d + kp; den = prr + kp; wn = den + kp;
+    }
+    static size_t bytes(int kp) { return (size_t)kp * (sizeof(double) + 7 * sizeof(T)); }
+};
+// (best, q) = max / arg-max of D over the row (first index on ties), both wave-uniform; D(c) from `dget(c)`
+template <typename T, typename F> __device__ __forceinline__ void greedy_argmax_lds(F dget, int k, int kp, int lane, T &best, int &q) {
+    best = -INFINITY;
+    for (int c = lane; c < kp; c += 64) {
+        const T dv = dget(c);
+        const bool take = (c < k) && (dv > best);
+        best = take ? dv : best;
+    }
+    best = wave_max_uniform(best);
+    q = 0x7fffffff;
+    for (int c0 = 0; c0 < kp; c0 += 64) {
+        const int c = c0 + lane;
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64((c < k) && (dget(c) == best));
+        if (hit != 0ull) { q = c0 + (int)__builtin_ctzll(hit); break; }
+    }
+}
+template <typename T> __device__ __forceinline__ void greedy_load_lds(GreedyLds<T> &r, const SampleView<const T> &W, const SampleView<const T> &G,
+                                                                    const T *P, int64_t ldp, int64_t i, int k, int kp, int lane, T lambda, T epsT) {
+    for (int c = lane; c < kp; c += 64) {
+        const bool ok = c < k;
+        const T wv = ok ? W.at(i, c) : (T)0;
+        T gv = ok ? G.at(i, c) : (T)0;
+        if (ok && lambda > (T)0) gv = op_add(gv, lambda);
+        const T pv = ok ? P[(int64_t)c * ldp + c] : (T)1;
+        const T dn = op_add(epsT, pv);
+        const double rd = 1.0 / (double)dn;
+        T sv, dv;
+        greedy_sd(wv, gv, pv, dn, rd, sv, dv);
+        r.w[c] = wv; r.g[c] = gv; r.prr[c] = pv; r.den[c] = dn; r.rden[c] = rd; r.s[c] = sv; r.d[c] = dv; r.wn[c] = (T)0;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(64) void greedy_pinit_lds_kernel(SampleView<const T> W, SampleView<const T> G, const T *__restrict__ P, int64_t ldp,
+                                                              int64_t nsamples, int k, T lambda, T epsT, T *part, const int *done) {
+    NMFX_DONE_GUARD(done);
+    extern __shared__ __attribute__((aligned(16))) unsigned char cd_lds_raw[];
+    const int lane = threadIdx.x, kp = (k + 63) / 64 * 64;
+    GreedyLds<T> r(cd_lds_raw, kp);
+    greedy_load_lds(r, W, G, P, ldp, (int64_t)blockIdx.x, k, kp, lane, lambda, epsT);
+    __syncthreads();
+    T best; int q;
+    greedy_argmax_lds<T>([&](int c) { return r.d[c]; }, k, kp, lane, best, q);
+    if (lane == 0) part[blockIdx.x] = (best > (T)-1) ? best : (T)-1;
+}
+template <typename T>
+__global__ __launch_bounds__(64) void greedy_sweep_lds_kernel(SampleView<const T> Wold, SampleView<T> Wout, SampleView<const T> G,
+                                                              const T *__restrict__ P, int64_t ldp, int64_t nsamples, int k, T lambda, T epsT,
+                                                              const T *pinit, long long *steps_total, const int *done) {
+    NMFX_DONE_GUARD(done);
+    extern __shared__ __attribute__((aligned(16))) unsigned char cd_lds_raw[];
+    const int lane = threadIdx.x, kp = (k + 63) / 64 * 64;
+    const int64_t i = blockIdx.x;
+    GreedyLds<T> r(cd_lds_raw, kp);
+    greedy_load_lds(r, Wold, G, P, ldp, i, k, kp, lane, lambda, epsT);
+    __syncthreads();
+    const T thresh = op_mul((T)0.001, pinit[0]);
+    T dq; int q;
+    greedy_argmax_lds<T>([&](int c) { return r.d[c]; }, k, kp, lane, dq, q);
+    const long long max_steps = (long long)k * k;
+    long long step = 0;
+    for (; step < max_steps; ++step) {
+        if (dq < thresh) break;
+        const T sq = r.s[q];                      // broadcast read
+        __syncthreads();
+        if (lane == 0) r.wn[q] = op_add(r.wn[q], sq);
+        for (int c = lane; c < kp; c += 64) {     // lanes c in [k, kp) read P's zero padding: G stays put (K >= kp: P is K x K zero-padded)
+            const T pq = P[(int64_t)q * ldp + c];
+            const T gv = op_add(r.g[c], op_mul(sq, pq));
+            r.g[c] = gv;
+            T sv, dv;
+            greedy_sd(r.w[c], gv, r.prr[c], r.den[c], r.rden[c], sv, dv);
+            r.s[c] = sv; r.d[c] = dv;
+        }
+        __syncthreads();
+        greedy_argmax_lds<T>([&](int c) { return r.d[c]; }, k, kp, lane, dq, q);
+    }
+    if (lane == 0 && steps_total != nullptr && step > 0) atomicAdd((unsigned long long *)steps_total, (unsigned long long)step);
+    __syncthreads();
+    for (int c = lane; c < k; c += 64) {
+        T v = op_add(r.w[c], r.wn[c]);
+        v = (v < (T)0) ? (T)0 : v;
+        Wout.at(i, c) = v;
+    }
+}
+
 }  // namespace nmfx

@@ -15,7 +15,12 @@ template <typename T> template <typename F> void Solver<T>::with_kmax(F &&f) {
     else if (k <= 256) f(std::integral_constant<int, 4>{});
     else if (k <= 512) f(std::integral_constant<int, 8>{});
     else if (k <= 1024) f(std::integral_constant<int, 16>{});
-    else throw StatusError{NMFX_ERR_UNSUPPORTED, "cd / greedycd: k > 1024 is not supported (components of a sample row live in registers)"};
+    else throw StatusError{NMFX_ERR_UNSUPPORTED, "internal: with_kmax beyond the register forms (k > 1024 runs the LDS forms)"};
+}
+// k > 1024 (or NMFX_CD_LDS=1): the LDS forms of the sweeps (cd.hpp), one wave per sample row
+template <typename T> bool Solver<T>::cd_use_lds() const { return k > 1024 || cd_force_lds; }
+static inline void cd_lds_check(size_t bytes) {
+    if (bytes > 160 * 1024) throw StatusError{NMFX_ERR_UNSUPPORTED, "cd / greedycd: k too large (a sample row's component vectors no longer fit 160 KiB of LDS)"};
 }
 
 // ---------------------------------------------------------------------------
@@ -24,6 +29,15 @@ template <typename T> template <typename F> void Solver<T>::with_kmax(F &&f) {
 template <typename T>
 void Solver<T>::cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<const T> Num, const T *Pm, int64_t nsamples, T l1,
                          const int *done) {
+    if (cd_use_lds()) {
+        const int kp = (int)((k + 63) / 64 * 64);
+        const size_t lds = (size_t)2 * kp * sizeof(T);
+        cd_lds_check(lds);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&cd_sweep_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (nsamples > 0)
+            hipLaunchKernelGGL((cd_sweep_lds_kernel<T>), dim3((unsigned)nsamples), dim3(64), lds, stream, Zo, Zn, Num, Pm, K, nsamples, (int)k, l1, done);
+        return;
+    }
     const int kpl = (int)(K / 16);                       // K is 64 or a multiple of 128: kpl is a multiple of 4
     const int reg_budget = (sizeof(T) == 4) ? 32 : 16;   // components per lane kept in registers (w, z, a: 3 arrays)
     if (kpl <= reg_budget) {
@@ -163,6 +177,27 @@ void Solver<T>::greedy_side(const char *tag, SampleView<const T> Zo, SampleView<
     const unsigned blocks = (unsigned)std::max<int64_t>(1, (nsamples + 3) / 4);   // >= 1: a rank without samples still takes part in the p_init all-reduce
     work[3].ensure((size_t)blocks + 8);
     T *part = work[3].p, *pinit = work[3].p + blocks;
+    if (cd_use_lds()) {
+        const int kp = (int)((k + 63) / 64 * 64);
+        const size_t lds = GreedyLds<T>::bytes(kp);
+        cd_lds_check(lds);
+        work[3].ensure((size_t)std::max<int64_t>(1, nsamples) + 8);
+        T *part1 = work[3].p, *pinit1 = work[3].p + std::max<int64_t>(1, nsamples);
+        timed(tag, 0.0, 4.0 * (double)nsamples * K * sizeof(T), [&] {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_pinit_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_sweep_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (nsamples > 0)
+                hipLaunchKernelGGL((greedy_pinit_lds_kernel<T>), dim3((unsigned)nsamples), dim3(64), lds, stream, Zo, G, Pm, K, nsamples, (int)k, lambda, epsT,
+                                   part1, done);
+            hipLaunchKernelGGL(greedy_pinit_reduce_kernel<T>, dim3(1), dim3(256), 0, stream, part1, (int)nsamples, pinit1, done);
+            if (sharded_samples && sharded()) comm->all_reduce(pinit1, 1, CT, true, stream);
+            if (nsamples > 0)
+                hipLaunchKernelGGL((greedy_sweep_lds_kernel<T>), dim3((unsigned)nsamples), dim3(64), lds, stream, Zo, Zn, G, Pm, K, nsamples, (int)k, lambda,
+                                   epsT, pinit1, &ctrl->inner_iters, done);
+            HIP_TRY(hipGetLastError());
+        });
+        return;
+    }
     timed(tag, 0.0, 4.0 * (double)nsamples * K * sizeof(T), [&] {
         with_kmax([&](auto KM) {
             constexpr int KMAX = decltype(KM)::value;

@@ -140,8 +140,11 @@ def test_nnmf_default_algorithm(built):
 
 
 def test_k_limit(built):
-    X, W0, H0 = uniform(1100, 1100, 1030, np.float32, seed=1)
-    with pytest.raises(nmfx.NMFXError, match="k > 1024"):
+    """k > 1024 runs the LDS forms of the sweeps (test_sweeps_beyond_1024_components); what is refused is a sample row whose
+    component vectors exceed 160 KiB of LDS (GreedyCD: k > ~4400 in Float32)."""
+    k = 4608
+    X, W0, H0 = uniform(k + 8, k + 8, k, np.float32, seed=1)
+    with pytest.raises(nmfx.NMFXError, match="k too large"):
         nmfx.solve(nmfx.GreedyCD(np.float32, maxiter=2), X, W0, H0)
 
 
@@ -174,6 +177,73 @@ def test_cd_shuffle_matches_oracle(built, T, shape, update_H):
     W2, H2 = W0.copy(order="F"), H0.copy(order="F")
     nmfx.solve(nmfx.CoordinateDescent(T, maxiter=6, tol=1e-30, alpha=1e-3, l1ratio=0.5, update_H=update_H), X, W2, H2)
     assert not np.array_equal(W, W2)
+
+
+def _solve_with_env(env, inst, X, W0, H0):
+    import os
+    old = os.environ.get("NMFX_CD_LDS")
+    if env:
+        os.environ["NMFX_CD_LDS"] = "1"
+    try:
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        with nmfx.Context(inst.T, X.shape[0], X.shape[1], W0.shape[1]) as ctx:      # the knob is read when the context is created
+            ctx.set_X(X)
+            r = nmfx.solve(inst, X, W, H, ctx=ctx, track_objective=True)
+    finally:
+        if old is None:
+            os.environ.pop("NMFX_CD_LDS", None)
+        else:
+            os.environ["NMFX_CD_LDS"] = old
+    return W, H, r
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("alg", ["cd", "greedycd"])
+@pytest.mark.parametrize("shape", [(90, 120, 70), (140, 100, 130), (64, 64, 64), (640, 660, 600)])
+def test_lds_forms_of_the_sweeps_are_bit_identical(built, T, alg, shape):
+    """k > 1024 runs the sweeps with the sample row's component vectors in LDS (one wave per row) instead of registers.  Same
+    expressions, same accumulation order as the 64-lanes-per-row register kernels: forced at small k (NMFX_CD_LDS=1) the two forms
+    must agree bit for bit -- factors, objective trajectory and (greedycd) the executed step count.  (CoordinateDescent at small k
+    normally runs its 16-lanes-per-row kernel, whose dot products are summed in another order: there the comparison is to rounding.)"""
+    p, n, k = shape
+    X, W0, H0 = uniform(p, n, k, T, seed=3 + k)
+    iters = 5 if k < 500 else 2
+    inst = _cd(T, maxiter=iters, tol=1e-30, alpha=1e-3, l1ratio=0.5, regularization="both") if alg == "cd" else \
+        nmfx.GreedyCD(T, maxiter=iters, tol=1e-30, lambda_w=1e-3, lambda_h=2e-3)
+    Wr, Hr, rr = _solve_with_env(False, inst, X, W0, H0)
+    Wl, Hl, rl = _solve_with_env(True, inst, X, W0, H0)
+    K = 64 if k <= 64 else (k + 127) // 128 * 128
+    same_kernel_order = alg == "greedycd" or K // 16 > (32 if T == np.float32 else 16)     # cd: beyond cd_sweep16_kernel's register budget
+    if same_kernel_order:
+        assert np.array_equal(Wr, Wl) and np.array_equal(Hr, Hl) and np.array_equal(rr.trace, rl.trace)
+    else:
+        tol = 1e-11 if T == np.float64 else 1e-4
+        assert rel_trace_err(rl.trace, rr.trace) < tol
+        assert np.max(np.abs(Wr - Wl)) <= 100 * tol * max(1.0, np.max(np.abs(Wr))) and np.max(np.abs(Hr - Hl)) <= 100 * tol * max(1.0, np.max(np.abs(Hr)))
+    if alg == "greedycd":
+        assert rr.info["inner_iters"] == rl.info["inner_iters"] > 0
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_sweeps_beyond_1024_components(built, T):
+    """The reference's sweeps have no size limit (src/coorddesc.jl:133-156, src/greedycd.jl:134-158); round 2 refused k > 1024.
+    CoordinateDescent against the C oracle at k = 1100, GreedyCD through its properties (exact coordinate minimisation never
+    increases the objective; non-negative, finite factors; the greedy steps are counted)."""
+    p, n, k = 1150, 1210, 1100
+    X, W0, H0 = planted(p, n, k, T, seed=8, k0=20)
+    alg = _cd(T, maxiter=2, tol=1e-30)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    r = nmfx.solve(alg, X, Wg, Hg, track_objective=True)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = co.solve("cd", X, Wc, Hc, orc.Opts(maxiter=2, tol=1e-30, track_objective=True))
+    tol = 1e-9 if T == np.float64 else 2e-3
+    assert r.niters == ro.niters == 2 and rel_trace_err(r.trace, ro.trace) < tol
+    assert np.max(np.abs(Wg - Wc)) <= 200 * tol * max(1.0, np.max(np.abs(Wc)))
+    W2, H2 = W0.copy(order="F"), H0.copy(order="F")
+    r2 = nmfx.solve(nmfx.GreedyCD(T, maxiter=2, tol=1e-30), X, W2, H2, track_objective=True)
+    assert r2.niters == 2 and np.all(np.diff(r2.trace) <= 1e-6 * r2.trace[0])
+    assert np.all(W2 >= 0) and np.all(H2 >= 0) and np.isfinite(W2).all() and np.isfinite(H2).all()
+    assert r2.info["inner_iters"] > 0
 
 
 def test_cd_shuffle_orders_beyond_one_window(built):

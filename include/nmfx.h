@@ -77,8 +77,9 @@ typedef struct {
                                  verbose=true does (src/common.jl:56,79); fills objv_trace */
     int32_t maxsubiter;       /* ALSPGrad.maxsubiter (200) */
     int32_t traceiter;        /* back-tracking cap (20) */
-    int32_t check_every;      /* host polls the device-side stop flag every this many outer iterations
-                                 (>=1; results do not depend on it: iterations past the stop are no-ops) */
+    int32_t check_every;      /* host polls the device-side stop flag every this many outer iterations; <= 0: adaptive
+                                 (a window of 4 that doubles, up to 256, while a window takes < 1 ms of wall time).
+                                 Results do not depend on it: iterations past the stop are no-ops */
     double tol;               /* stop_condition eps (src/common.jl:92-111) */
     double lambda_w, lambda_h;
     double delta;

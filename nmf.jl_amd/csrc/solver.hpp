@@ -13,6 +13,7 @@
 #include <cstring>
 #include <limits>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <string>
 #include <type_traits>

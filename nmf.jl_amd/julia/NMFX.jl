@@ -105,7 +105,7 @@ end
 
 opts(T; maxiter, tol, update_H, lambda_w=0.0, lambda_h=0.0, maxsubiter=200, tolg=eps(T)^(1/4),
      l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision=0, cd_shuffle=0) =
-    COpts(maxiter, update_H, 0, maxsubiter, 20, 4, tol, lambda_w, lambda_h, sqrt(eps(T)), tolg, T(0.2), T(0.01),
+    COpts(maxiter, update_H, 0, maxsubiter, 20, 0, tol, lambda_w, lambda_h, sqrt(eps(T)), tolg, T(0.2), T(0.01),
           l1_w, l2_w, l1_h, l2_h, precision, cd_shuffle)
 
 # ---- solve! methods: same signatures as src/multupd.jl:45, src/projals.jl:37, src/alspgrad.jl:381, with a

@@ -232,7 +232,7 @@ class Result:
 
 
 def make_opts(T, maxiter=100, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.0, delta=None, maxsubiter=200,
-              traceiter=20, tolg=None, beta=0.2, sigma=0.01, track_objective=False, check_every=4,
+              traceiter=20, tolg=None, beta=0.2, sigma=0.01, track_objective=False, check_every=0,
               l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision="fp32", cd_shuffle=0) -> L.Opts:
     T = np.dtype(T).type
     return L.Opts(int(maxiter), int(bool(update_H)), int(bool(track_objective)), int(maxsubiter), int(traceiter),
@@ -500,7 +500,7 @@ def _result(T, W, H, res, trace):
                        final_tolg=res.final_tolg))
 
 
-def solve(alg, X, W, H, ctx: Context | None = None, track_objective=False, check_every=4, precision="fp32") -> Result:
+def solve(alg, X, W, H, ctx: Context | None = None, track_objective=False, check_every=0, precision="fp32") -> Result:
     """NMF.solve!(alg, X, W, H): W and H (Fortran-ordered, dtype of X) are updated in place."""
     p, n, k = nmf_checksize(X, W, H)
     T = alg.T

@@ -70,3 +70,21 @@ def test_verbose_table_columns(built, alg, update_H, capsys):
     assert lines[0].split() == ["Iter", "Elapsed", "time", "objv", "objv.change", "(W", "&", "H).relchange"]
     assert len(lines) == r.niters + 2 and len(lines[1].split()) == 3 and all(len(l.split()) == 5 for l in lines[2:])
     assert lines[0].startswith("Iter     Elapsed time     objv             objv.change      (W & H).relchange")
+
+
+@pytest.mark.parametrize("alg", ["multmse", "multdiv", "projals", "cd", "greedycd"])
+def test_result_does_not_depend_on_the_poll_interval(built, alg):
+    """nmfx_opts.check_every: the host polls the device stop flag every N iterations, or (<= 0, the default) with a window that
+    grows from 4 while a window takes under a millisecond.  Iterations enqueued past the stop are no-ops, so niters, the factors and
+    the objective must be the same for every choice -- including a converging solve whose stop falls inside a long window."""
+    T = np.float64
+    X, W0, H0 = planted(60, 84, 4, T, seed=23, normalize=(alg != "projals"), zeroh=(alg == "projals"))
+    outs = []
+    for ce in (0, 1, 3, 64, 1 << 20):
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        r = nmfx.solve(_inst(alg, T, maxiter=3000, tol=2e-4), X, W, H, check_every=ce)
+        outs.append((r.niters, r.converged, r.objvalue, W, H))
+    assert outs[0][1] and 8 < outs[0][0] < 3000
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and o[1] == outs[0][1] and o[2] == outs[0][2]
+        assert np.array_equal(o[3], outs[0][3]) and np.array_equal(o[4], outs[0][4])

@@ -62,9 +62,14 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
         }
     };
     // H <- Hn / H <- Hp of the step that broke the loop (no-op while the loop is still running or unchanged)
-    auto apply = [&]() {
-        hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(512), dim3(256), 0, stream, Z, G, rows, cols, ldz, pg_state);
-        hipLaunchKernelGGL(pg_clear_apply_kernel, dim3(1), dim3(1), 0, stream, pg_state);
+    auto apply = [&](bool with_clear) {
+        {
+            // ~2048 blocks: row chunks of >= 1024 rows, the rest of the parallelism from the columns
+            const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, rows / 1024));
+            const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cols, 2048 / gx));
+            hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, Z, G, rows, cols, ldz, pg_state);
+        }
+        if (with_clear) hipLaunchKernelGGL(pg_clear_apply_kernel, dim3(1), dim3(1), 0, stream, pg_state);
         HIP_TRY(hipGetLastError());
     };
     auto fetch = [&]() {
@@ -92,7 +97,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
                 hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, tolg);
             }
             for (int sidx = 0; sidx < SPEC; ++sidx) step();
-            apply();
+            apply(false);   // pg_endcheck_kernel clears the request
             hipLaunchKernelGGL(pg_endcheck_kernel, dim3(1), dim3(1), 0, stream, pg_state);
         }
         fetch();
@@ -101,7 +106,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
             while (!pg_host->idle && pg_host->it < traceiter) {
                 const int more = std::min(4, traceiter - pg_host->it);
                 for (int sidx = 0; sidx < more; ++sidx) step();
-                apply();
+                apply(true);
                 fetch();
             }
             hipLaunchKernelGGL(pg_resume_kernel, dim3(1), dim3(1), 0, stream, pg_state);

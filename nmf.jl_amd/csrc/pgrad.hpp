@@ -152,7 +152,9 @@ template <typename T> __global__ void pg_begin_kernel(PgState *st, const double 
 
 // end of the steps enqueued for one inner iteration: a line search that is still running hands over to the host
 // (every inner iteration enqueued behind this one becomes a no-op until the host has finished the search)
+// (also clears the `apply` request that pg_apply_kernel has just served: one single-thread launch instead of two per inner iteration)
 __global__ void pg_endcheck_kernel(PgState *st) {
+    st->apply = 0;
     if (!st->idle) { st->halt = 1; st->gate = 1; }
 }
 // the host finished a halted line search: speculation may continue
@@ -214,12 +216,17 @@ __global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local
 
 // Z <- max(Z - alpha_apply*G, 0) if the decision asked for it (H <- Hn / H <- Hp of the reference); Z, G are rows x cols
 // column-major blocks with leading dimension ld (a row block of W when the W side is row-sharded)
+// grid = (row chunks, column groups): a block walks a contiguous row range of its columns -- no per-element index division (the flat
+// form spent more time in two 64-bit divisions per element than in the 3 x 134 MB it moves on the W side of a C5 shard)
 template <typename T> __global__ void pg_apply_kernel(T *Z, const T *G, int64_t rows, int64_t cols, int64_t ld, PgState *st) {
     if (!st->apply) return;
     const T a = (T)st->alpha_apply;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < rows * cols; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = e % rows + (e / rows) * ld;
-        Z[i] = pg_trial(Z[i], G[i], a);
+    const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    for (int64_t c = blockIdx.y; c < cols; c += gridDim.y) {
+        T *z = Z + c * ld;
+        const T *g = G + c * ld;
+        for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) z[r] = pg_trial(z[r], g[r], a);
     }
 }
 __global__ void pg_clear_apply_kernel(PgState *st) { st->apply = 0; }

@@ -552,14 +552,23 @@ template <typename T> struct EpiStore {
     T *dst;
     T *C2 = nullptr;
     int64_t ld2 = 0, stride2 = 0, r_off = 0, c_off = 0;
+    // piece_rows > 0: the main output is BLOCKED along c -- piece g = c / piece_rows is a contiguous (piece_rows x R) column-major
+    // matrix at C + g * piece_stride (the reduce-scatter send buffer of the row-sharded W side: piece g = the rows rank g owns);
+    // wave tiles never straddle pieces (piece_rows is a multiple of 128)
+    int64_t piece_rows = 0, piece_stride = 0;
     rsrc_t rd;
     LaneAddr<T> la;
     struct Pre {};
     static constexpr bool EARLY = false, HEAVY = false;
     __device__ __forceinline__ void setup(int split, const TileCtx &t) {
         int64_t ldc;
-        if (split >= 0) { dst = C + (int64_t)split * slab_stride; ldc = ld; }
-        else { dst = C2 + (int64_t)(-1 - split) * stride2 - (c_off + r_off * ld2); ldc = ld2; }
+        if (split >= 0) {
+            dst = C + (int64_t)split * slab_stride; ldc = ld;
+            if (piece_rows > 0) {
+                const int64_t g = t.cw0 / piece_rows;
+                dst += g * piece_stride - g * piece_rows;      // element (r, c) at dst + c + r * ld with ld = piece_rows
+            }
+        } else { dst = C2 + (int64_t)(-1 - split) * stride2 - (c_off + r_off * ld2); ldc = ld2; }
         rd = tile_rsrc(dst, ldc, t);
         la.init(t, ldc);
     }

@@ -460,13 +460,31 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(T *Wfull, const T *Wo
     const T *oldc = Wold + (int64_t)g * Pc + (int64_t)j * P;
     T *newc = Wfull + (int64_t)g * Pc + (int64_t)j * P;
     double dev = 0.0, sum = 0.0;
-    for (int64_t il = beg + threadIdx.x; il < end; il += blockDim.x) {
-        const T a = piece[il];
-        const T b = oldc[il];
-        newc[il] = a;
-        const T d = a - b, s = a + b;
-        dev += (double)(T)(d * d);
-        sum += (double)(T)(s * s);
+    // 16-byte accesses (Pc and P are multiples of 128 rows, the chunk bounds multiples of 4 whenever Pc / cpp is): a thread's
+    // VEC consecutive rows per trip
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    if (((beg | end) & (VEC - 1)) == 0) {
+        for (int64_t il = beg + (int64_t)threadIdx.x * VEC; il < end; il += (int64_t)blockDim.x * VEC) {
+            const vec_t a = *reinterpret_cast<const vec_t *>(piece + il);
+            const vec_t b = *reinterpret_cast<const vec_t *>(oldc + il);
+            *reinterpret_cast<vec_t *>(newc + il) = a;
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                const T d = a[u] - b[u], s = a[u] + b[u];
+                dev += (double)(T)(d * d);
+                sum += (double)(T)(s * s);
+            }
+        }
+    } else {
+        for (int64_t il = beg + threadIdx.x; il < end; il += blockDim.x) {
+            const T a = piece[il];
+            const T b = oldc[il];
+            newc[il] = a;
+            const T d = a - b, s = a + b;
+            dev += (double)(T)(d * d);
+            sum += (double)(T)(s * s);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) { dev += __shfl_down(dev, off, 64); sum += __shfl_down(sum, off, 64); }
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;

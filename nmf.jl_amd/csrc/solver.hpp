@@ -438,6 +438,9 @@ template <typename T> class Solver : public SolverBase {
     DevBuf<unsigned char> ag_send, ag_recv; // all-gather chunks: [ Pc x K piece of the new W | 2K doubles of column statistics ]
     // MultUpdate-MSE, row-sharded: the launches between the big products and the collectives fused (solver_impl.hpp)
     bool rs_fused_enabled = true;         // NMFX_RS_FUSED=0: the unfused sequence (pack / unpack / statistics as separate launches)
+    bool force_quarter_tiles = false;     // set around a gemm() call: 64 x 64 tiles whatever the shape
+    bool w_direct = false;                // times_ht stored the product straight into the blocked send buffer (no slabs)
+    bool gramw_sharded_valid = false;     // gramW_p holds the all-reduced W'W of the current W (row-sharded fused step)
     bool w_defer_combine = false;         // times_ht: leave the split-K slabs and the Gram pieces to the caller's combine launch
     bool h_reduce_pair = false;           // wt_times: numerator and Gram combined by ONE launch
     int w_pieces = 1;                     // Gram tail pieces of the last fused X*H' launch
@@ -583,7 +586,12 @@ template <typename T> class Solver : public SolverBase {
             // blocks per CU: those run prologue, 16 k-tiles and epilogue in lockstep; four quarter-size blocks per CU overlap one
             // block's epilogue with another's k-loop (update products at 16384 x 256 x 256: 45 -> 38 us)
             const int64_t half_blocks = std::max(R / 64 * (C / 128), R / 128 * (C / 64));
-            if (small_k && R % 64 == 0 && C % 64 == 0 && (half_blocks < 2 * (int64_t)num_cu || (Epi::HEAVY && half_blocks == 2 * (int64_t)num_cu))) {
+            if (force_quarter_tiles && R % 64 == 0 && C % 64 == 0 && seg.tail_tiles == 0) {
+                // a small split-K product that would put only a few dozen 128 x 128 blocks on the chip (the own-rows Gram of the
+                // row-sharded W side): 4x the blocks on quarter-size tiles
+                g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 64);
+                launch_gemm_cfg<LA, LB, 64, 64, 2, 2, AUX>(g, epi);
+            } else if (small_k && R % 64 == 0 && C % 64 == 0 && (half_blocks < 2 * (int64_t)num_cu || (Epi::HEAVY && half_blocks == 2 * (int64_t)num_cu))) {
                 // even the half-size tiles leave CUs idle (e.g. the 4096 x 512 projected-gradient products of a C5 shard:
                 // 256 blocks): quarter-size tiles, 4 waves of 32 x 32
                 g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 64);
@@ -855,17 +863,26 @@ template <typename T> class Solver : public SolverBase {
             return;
         }
         if (with_gram && fuse_gram && K % 128 == 0) {
-            w_nslab = s_w; w_stride = (int64_t)P * K;
+            // row-sharded fused step at a short local contraction: ONE split, the product stored straight into the blocked send
+            // buffer (EpiStore::piece_rows) -- no slabs to write and to combine (measured at the 8-rank shard shape of the headline
+            // problem, scripts/kbench/gemm_bench.hip: 153 us unsplit on 256 blocks against 150 us 2-way split on 512)
+            // (only where it pays: a local contraction of 1024 .. 4096 -- 4 or more ranks at the headline shape -- and enough tiles to
+            // give every CU one; longer contractions keep the 2-way split that puts two blocks on a CU)
+            const bool direct = w_defer_combine && w_blocked && N / BK >= 32 && N / BK <= 128 && (K / 128) * (P / 128) >= num_cu;
+            const int sw = direct ? 1 : s_w;
+            w_nslab = sw; w_stride = (int64_t)P * K;
             const int tiles = (int)((K / 128) * (P / 128));
             const int tt = (int)((K / 128) * (K / 128));
-            const int per = tail_piece(tiles * s_w, tt, (int)(N / BK));
+            const int per = tail_piece(tiles * sw, tt, (int)(N / BK));
             const int pieces = (int)((N / BK + per - 1) / per);
-            EpiStore<T> e{reg, P, w_stride, nullptr};
+            EpiStore<T> e{direct ? numW_p : reg, direct ? Pc : P, w_stride, nullptr};
+            if (direct) { e.piece_rows = Pc; e.piece_stride = (int64_t)K * Pc; }
             e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = (int64_t)K * K; e.r_off = 0; e.c_off = P;
             Seg sg;
             sg.B2 = Hp; sg.ldb2 = K; sg.c_split = P; sg.tail_tiles = (int)(K / 128);
-            gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
+            gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, sw, false, e, done,
                                      (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
+            w_direct = direct;
             if (w_defer_combine) { w_pieces = pieces; w_in_slabs = false; return; }   // the caller's combine launch sums both
             reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
             finish_w_slabs(keep_slabs, done);

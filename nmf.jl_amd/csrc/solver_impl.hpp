@@ -142,8 +142,11 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
         // the numerator slabs in its epilogue (ascending slab order, like reduce_slabs_kernel), and it also
         // produces the stop_condition statistics of H -- three launches for the whole H phase.
         const bool fusedrs = rs_fused();
+        // row-sharded fused step: from the second iteration on W'W arrives all-reduced from the ranks' own row blocks (computed
+        // behind the W update, multmse_w_rows_fused) instead of being recomputed over all P rows on every rank inside this launch
+        const bool have_gram = fusedrs && gramw_sharded_valid;
         h_reduce_pair = fusedrs;
-        wt_times(Wp, X.p, true, done, /*keep_slabs=*/true);
+        wt_times(Wp, X.p, !have_gram, done, /*keep_slabs=*/true);
         h_reduce_pair = false;
         EpiMultUpdate<T, 1> e{h_num(), h_num_nslab(), h_stride, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};  // :99-103
         gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (3.0 + h_num_nslab()) * K * N * sizeof(T));
@@ -194,7 +197,7 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
     w_blocked = true; w_defer_combine = true;
     times_ht(X.p, Hp, true, done);
     w_blocked = false; w_defer_combine = false;
-    const unsigned nb1 = (unsigned)(P / 256 * K), nb2 = (unsigned)((K * K + 63) / 64), nb3 = o.update_H ? (unsigned)((2 * K + 3) / 4) : 0u;
+    const unsigned nb1 = w_direct ? 0u : (unsigned)(P / 256 * K), nb2 = (unsigned)((K * K + 63) / 64), nb3 = o.update_H ? (unsigned)((2 * K + 3) / 4) : 0u;
     timed("combine_W", 0.0, ((double)P * K * (w_nslab + 1) + (double)K * K * (w_pieces + 1)) * sizeof(T), [&] {
         hipLaunchKernelGGL(w_side_combine_kernel<T>, dim3(nb1 + nb2 + nb3), dim3(256), 0, stream, numW_p, slabs.p + slab_w_off, P, K, Pc, w_nslab,
                            w_stride, gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, w_pieces, (int64_t)K * K, stat_part.p, h_stat_chunks,
@@ -212,7 +215,23 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
     T *mine = reinterpret_cast<T *>(ag_recv.p + (size_t)rank * chunk);
     EpiMultUpdateRows<T> e{rs_out.p, Pc, Wo + row0, P, mine, (T)o.lambda_w, (T)o.delta};                  // multupd.jl:110-114
     gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo + row0, P, Pc, K, 1, false, e, done, 3.0 * Pc * K * sizeof(T));
-    timed("comm_all_gather_W", 0.0, (double)(P * K) * sizeof(T), [&] { comm->all_gather(mine, ag_recv.p, chunk, CT_BYTE, stream); });
+    if (o.update_H) {
+        // W'W for the next H update from the rank's OWN new rows (2 Pc k^2 instead of 2 p k^2 on every rank), summed over the ranks
+        // by a k x k all-reduce that travels in the same group as the all-gather
+        const int sg = pick_splits((int)((K / 64) * (K / 64)), Pc);
+        EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
+        force_quarter_tiles = true;
+        gemm<KCONTIG, KCONTIG>("gemm_WtW_rows", mine, Pc, K, mine, Pc, K, Pc, sg, true, eg, done, (double)(Pc * K) * sizeof(T));
+        force_quarter_tiles = false;
+        reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, sg, done);
+    }
+    timed("comm_all_gather_W", 0.0, (double)(P * K) * sizeof(T), [&] {
+        comm->group_start();
+        comm->all_gather(mine, ag_recv.p, chunk, CT_BYTE, stream);
+        if (o.update_H) comm->all_reduce(gramW_p, (size_t)K * K, CT, false, stream);
+        comm->group_end();
+    });
+    gramw_sharded_valid = o.update_H != 0;
     const bool fuse_check = o.track_objective == 0;
     const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(64 / nranks, Pc / 1024));   // chunks per piece
     timed("gather_W_stats", 0.0, 3.0 * P * K * sizeof(T), [&] {
@@ -361,6 +380,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     precision = o.precision;
     pipe_pending = false;
     check_fused = false;
+    gramw_sharded_valid = false;
     smallk_grams_valid = false;
     div_sw_valid = div_sh_valid = false;
     rsvd_ready = 0;   // the iteration overwrites the buffers a pending rsvd keeps its Q / B in

@@ -91,6 +91,11 @@ int main(int argc, char **argv) {
     run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT big (XHt) 128x128", 256, 16384, 16384, 2, false, reps);
     run<float, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN shard/8 128x128", 2048, 256, 16384, 16, true, reps);
     run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT shard/8 128x128", 256, 16384, 2048, 2, false, reps);
+    run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT shard/8 128x128 no split", 256, 16384, 2048, 1, false, reps);
+    run<float, KSTRIDED, KSTRIDED, 64, 128, 1, 4>("NT shard/8 64x128 no split", 256, 16384, 2048, 1, false, reps);
+    run<float, KSTRIDED, KSTRIDED, 128, 64, 4, 1>("NT shard/8 128x64 no split", 256, 16384, 2048, 1, false, reps);
+    run<float, KCONTIG, KCONTIG, 128, 64, 4, 1>("TN shard/8 128x64 8 splits", 2048, 256, 16384, 8, true, reps);
+    run<float, KCONTIG, KCONTIG, 64, 128, 1, 4>("TN shard/8 64x128 8 splits", 2048, 256, 16384, 8, true, reps);
     run<float, KCONTIG, KCONTIG, 256, 64, 4, 1>("TN C2 (k=64) 256x64", 4096, 64, 4096, 8, true, reps);
     run<float, KSTRIDED, KSTRIDED, 64, 256, 1, 4>("NT C2 (k=64) 64x256", 64, 4096, 4096, 8, false, reps);
     run<double, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN f64 128x128", 8192, 256, 8192, 4, true, reps);

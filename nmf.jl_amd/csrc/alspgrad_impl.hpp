@@ -19,6 +19,10 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     const int64_t rows = left ? K : Rw, cols = left ? N : K, ldz = left ? K : P;
     work[3].ensure((size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K));
     T *G = work[3].p + (wrows ? row0 : 0);
+    // Gram*D of the last two trial points (EpiPgStep): the accepted one turns G into the next inner iteration's gradient
+    work[4].ensure((size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K));
+    work[5].ensure((size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K));
+    T *GD0 = work[4].p + (wrows ? row0 : 0), *GD1 = work[5].p + (wrows ? row0 : 0);
     pg_part.ensure((size_t)3 * 65536);
     if (!pg_state) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pg_state), sizeof(PgState)));
@@ -40,8 +44,8 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
         return last_blocks;
     };
     // one back-tracking step: Gram * D(alpha) with D formed in the operand loader, scalars reduced in the epilogue
-    auto step = [&]() {
-        EpiPgStep<T> e{Z, G, left ? K : P, pg_state, pg_part.p, (T)0, (T)0, 0, 0.0, 0.0, 0.0};
+    auto step = [&](bool last_enqueued) {
+        EpiPgStep<T> e{Z, G, GD0, GD1, left ? K : P, pg_state, pg_part.p, (T)0, (T)0, 0, 0.0, 0.0, 0.0};
         Seg sg;
         sg.alpha_ptr = &pg_state->alpha;
         int nblk;
@@ -56,22 +60,31 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
         if (reduce_scalars) {
             hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 3, 0, 1);
             comm->all_reduce(pg_state->red, 3, CT_F64, false, stream);
-            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, beta, sigma, epsT, traceiter);
+            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, beta, sigma, epsT, traceiter, last_enqueued ? 1 : 0);
         } else {
-            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, beta, sigma, epsT, traceiter);
+            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, beta, sigma, epsT, traceiter, last_enqueued ? 1 : 0);
         }
     };
+    // ~2048 blocks: row chunks of >= 1024 rows, the rest of the parallelism from the columns
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, rows / 1024));
+    const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cols, 2048 / gx));
     // H <- Hn / H <- Hp of the step that broke the loop (no-op while the loop is still running or unchanged)
     auto apply = [&](bool with_clear) {
-        {
-            // ~2048 blocks: row chunks of >= 1024 rows, the rest of the parallelism from the columns
-            const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, rows / 1024));
-            const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cols, 2048 / gx));
-            hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, Z, G, rows, cols, ldz, pg_state);
-        }
+        hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, Z, G, rows, cols, ldz, pg_state);
         if (with_clear) hipLaunchKernelGGL(pg_clear_apply_kernel, dim3(1), dim3(1), 0, stream, pg_state);
         HIP_TRY(hipGetLastError());
     };
+    // the same accept fused with the gradient of the point it leads to: G += Gram*D(accepted), projgradnorm^2 partials
+    auto advance = [&]() {
+        timed("pg_advance", 0.0, 5.0 * rows * cols * sizeof(T), [&] {
+            hipLaunchKernelGGL(pg_advance_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, Z, G, GD0, GD1, rows, cols, ldz, pg_state, pg_part.p);
+            HIP_TRY(hipGetLastError());
+        });
+        return (int)(gx * gy);
+    };
+    // A full product G = Gram*Z - B every REFRESH inner iterations bounds the rounding drift of the running sum
+    // (the first iteration of a sub-solve always: Gram and B are new)
+    const int REFRESH = (sizeof(T) == 4) ? 16 : 64;
     auto fetch = [&]() {
         HIP_TRY(hipMemcpyAsync(pg_host, pg_state, sizeof(PgState), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -88,7 +101,13 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     while (!converged && t < maxiter) {
         const int batch = (int)std::min<long long>(AHEAD, (long long)maxiter - t);
         for (int b = 0; b < batch; ++b) {
-            const int nblk = grad();
+            int nblk;
+            if ((t + b) % REFRESH == 0) {
+                if (t + b > 0) apply(false);   // pg_begin_kernel clears the request
+                nblk = grad();
+            } else {
+                nblk = advance();
+            }
             if (reduce_scalars) {
                 hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 1, 3, 2);
                 comm->all_reduce(pg_state->red + 3, 1, CT_F64, false, stream);
@@ -96,17 +115,14 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
             } else {
                 hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, tolg);
             }
-            for (int sidx = 0; sidx < SPEC; ++sidx) step();
-            apply(false);   // pg_endcheck_kernel clears the request
-            hipLaunchKernelGGL(pg_endcheck_kernel, dim3(1), dim3(1), 0, stream, pg_state);
+            for (int sidx = 0; sidx < SPEC; ++sidx) step(sidx == SPEC - 1);
         }
         fetch();
         while (pg_host->halt && !pg_host->nonfinite) {
             // finish the halted search: the remaining steps, a few at a time
             while (!pg_host->idle && pg_host->it < traceiter) {
                 const int more = std::min(4, traceiter - pg_host->it);
-                for (int sidx = 0; sidx < more; ++sidx) step();
-                apply(true);
+                for (int sidx = 0; sidx < more; ++sidx) step(false);
                 fetch();
             }
             hipLaunchKernelGGL(pg_resume_kernel, dim3(1), dim3(1), 0, stream, pg_state);
@@ -117,6 +133,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
         t = pg_host->t_inner;
         converged = pg_host->converged != 0;
     }
+    apply(true);                                                           // the accept of the last executed search, if any
     if (inner_total) *inner_total += t;
     pg_backtracks += pg_host ? pg_host->backtracks : 0;
     return t;

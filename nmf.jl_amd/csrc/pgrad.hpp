@@ -32,6 +32,7 @@ struct PgState {
     long long backtracks;
     int halt;            // the line search of the current inner iteration needs more steps than were enqueued: the host takes over
     int t_inner;         // executed inner iterations of this sub-solve (the converged one included, like the reference's t)
+    int gd_sel;          // which of the two Gram*D buffers belongs to the accepted trial point (valid with apply = 1)
 };
 
 template <typename T> __device__ __forceinline__ T pg_trial(T z, T g, T alpha) {
@@ -73,10 +74,13 @@ template <typename T> struct EpiGradNorm {
 
 // One back-tracking step: acc = (Gram * D(alpha))(r, c).  Per block: partial[3*bid + {0,1,2}] =
 //   <G, D>, <Gram D, D>, ||Zprev - Zn||^2   with Zprev = Zn(alpha_prev) if a previous trial exists, else Z
-// (src/alspgrad.jl:150-152 and the isapprox of :170).  Nothing is stored.
+// (src/alspgrad.jl:150-152 and the isapprox of :170).  The product itself goes to GD[it & 1] (it = steps done so far in
+// this search): the accepted trial point is this step's or the previous one's, and G(Z + D) = G(Z) + Gram*D, so the next
+// inner iteration's gradient is an element-wise update (pg_advance_kernel) instead of another k x k product.
 template <typename T> struct EpiPgStep {
     const T *Z;
     const T *G;
+    T *GD0, *GD1;
     int64_t ld;
     const PgState *st;
     double *partial;
@@ -85,9 +89,13 @@ template <typename T> struct EpiPgStep {
     double s1, s2, s3;
     struct Pre { T z, g; };
     static constexpr bool EARLY = true, HEAVY = true;
-    rsrc_t rz, rg;
+    rsrc_t rz, rg, rgd;
     LaneAddr<T> la;
-    __device__ __forceinline__ void setup(int, const TileCtx &t) { rz = tile_rsrc(Z, ld, t); rg = tile_rsrc(G, ld, t); la.init(t, ld); }
+    __device__ __forceinline__ void setup(int, const TileCtx &t) {
+        rz = tile_rsrc(Z, ld, t); rg = tile_rsrc(G, ld, t);
+        rgd = tile_rsrc((st->it & 1) ? GD1 : GD0, ld, t);
+        la.init(t, ld);
+    }
     __device__ __forceinline__ void begin() {
         alpha = (T)st->alpha;
         alpha_prev = (T)st->alpha_prev;
@@ -98,7 +106,8 @@ template <typename T> struct EpiPgStep {
         const uint32_t so = la.soff(ro, co);
         return Pre{buf_ld<T>(rz, la.lb, so), buf_ld<T>(rg, la.lb, so)};
     }
-    __device__ __forceinline__ void apply(int, int, T v, int, const Pre &pre) {
+    __device__ __forceinline__ void apply(int ro, int co, T v, int, const Pre &pre) {
+        buf_st(rgd, la.lb, la.soff(ro, co), v);
         const T zn = pg_trial(pre.z, pre.g, alpha);
         const T d = zn - pre.z;
         const T zprev = zp_valid ? pg_trial(pre.z, pre.g, alpha_prev) : pre.z;
@@ -127,6 +136,18 @@ __device__ __forceinline__ double pg_block_sum(const double *partial, int n, int
     return t;
 }
 
+// the three sums of a back-tracking step at once: wave w < 3 of the block sums slot w (same per-slot order for every launch)
+__device__ __forceinline__ void pg_block_sum3(const double *partial, int n, double *out3) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (w < 3) {
+        double v = 0.0;
+        for (int i = lane; i < n; i += 64) v += partial[(int64_t)i * 3 + w];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) out3[w] = v;
+    }
+    __syncthreads();
+}
+
 // start of an inner iteration (src/alspgrad.jl:129-137): red[3] = projgradnorm^2 from the gradient GEMM's partials
 // (n_local = 0 when the caller already reduced / all-reduced them into red[3]); converged if < tolg, else arm back-tracking.
 template <typename T> __global__ void pg_begin_kernel(PgState *st, const double *partial, int n_local, T tolg) {
@@ -150,13 +171,6 @@ template <typename T> __global__ void pg_begin_kernel(PgState *st, const double 
     }
 }
 
-// end of the steps enqueued for one inner iteration: a line search that is still running hands over to the host
-// (every inner iteration enqueued behind this one becomes a no-op until the host has finished the search)
-// (also clears the `apply` request that pg_apply_kernel has just served: one single-thread launch instead of two per inner iteration)
-__global__ void pg_endcheck_kernel(PgState *st) {
-    st->apply = 0;
-    if (!st->idle) { st->halt = 1; st->gate = 1; }
-}
 // the host finished a halted line search: speculation may continue
 __global__ void pg_resume_kernel(PgState *st) {
     st->halt = 0;
@@ -177,32 +191,28 @@ __global__ void pg_reduce_kernel(PgState *st, const double *partial, int n, int 
 
 // The branch logic of one back-tracking step (src/alspgrad.jl:155-177); n_local > 0: sum the step's partials first.
 template <typename T>
-__global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local, T beta, T sigma, T epsT, int traceiter) {
+__global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local, T beta, T sigma, T epsT, int traceiter, int last_enqueued) {
     if (st->idle) return;
-    __shared__ double sm[4];
-    if (n_local > 0) {
-        for (int sl = 0; sl < 3; ++sl) {
-            const double s = pg_block_sum(partial, n_local, 3, sl, sm);
-            if (threadIdx.x == 0) st->red[sl] = s;
-            __syncthreads();
-        }
-    }
+    __shared__ double r3[3];
+    if (n_local > 0) pg_block_sum3(partial, n_local, r3);
     if (threadIdx.x != 0) return;
+    if (n_local > 0) { st->red[0] = r3[0]; st->red[1] = r3[1]; st->red[2] = r3[2]; }
     T alpha = (T)st->alpha;
     if (!isfinite(alpha)) { st->nonfinite = 1; st->idle = 1; st->gate = 1; return; }   // :140 (the step's sums are garbage then)
     const T dv1 = (T)st->red[0], dv2 = (T)st->red[1];
     const bool suff_decr = (((T)1 - sigma) * dv1 + (T)0.5 * dv2) < (T)0;
+    const int slot = st->it & 1;                                          // where this step's Gram*D went
     st->it += 1;
     st->backtracks += 1;
     bool brk = false;
     if (st->it == 1) st->decr_alpha = suff_decr ? 0 : 1;                  // :157-160 (Hp <- H is implicit: zp_valid = 0)
     if (st->decr_alpha) {
-        if (suff_decr) { st->apply = 1; st->alpha_apply = (double)alpha; brk = true; }   // :163-165 H <- Hn
+        if (suff_decr) { st->apply = 1; st->alpha_apply = (double)alpha; st->gd_sel = slot; brk = true; }   // :163-165 H <- Hn
         else alpha = alpha * beta;                                        // :167
     } else {
         const T nrm = sqrt((T)st->red[2]);                                // isapprox(Hp, Hn, atol=eps(T)) <=> ||Hp-Hn|| <= eps
         if (!suff_decr || nrm <= epsT) {                                  // :170-172 H <- Hp
-            if (st->zp_valid) { st->apply = 1; st->alpha_apply = st->alpha_prev; }
+            if (st->zp_valid) { st->apply = 1; st->alpha_apply = st->alpha_prev; st->gd_sel = slot ^ 1; }
             brk = true;
         } else {                                                          // :174-175 alpha /= beta; Hp <- Hn
             st->alpha_prev = (double)alpha;
@@ -212,6 +222,10 @@ __global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local
     }
     st->alpha = (double)alpha;
     if (brk || st->it >= traceiter) st->idle = 1;                         // loop exhausted: Z unchanged (quirk i)
+    // last step enqueued for this inner iteration and the search is still running: it hands over to the host (every inner
+    // iteration enqueued behind this one becomes a no-op until the host has finished the search).  A pending `apply`
+    // request stays: the next inner iteration's pg_advance_kernel / pg_apply_kernel serves it.
+    else if (last_enqueued) { st->halt = 1; st->gate = 1; }
 }
 
 // Z <- max(Z - alpha_apply*G, 0) if the decision asked for it (H <- Hn / H <- Hp of the reference); Z, G are rows x cols
@@ -230,5 +244,37 @@ template <typename T> __global__ void pg_apply_kernel(T *Z, const T *G, int64_t 
     }
 }
 __global__ void pg_clear_apply_kernel(PgState *st) { st->apply = 0; }
+
+// Start of an inner iteration after the first: serve the pending accept (Z <- Zn(alpha_apply), G <- G + Gram*D of that trial
+// point, which its step left in GD[gd_sel]) and reduce projgradnorm^2 of the new (Z, G) -- one pass over Z, G, GD instead of
+// pg_apply_kernel + the k x k product G = Gram*Z - B (src/alspgrad.jl:124-130).  Without a pending accept (20 steps exhausted:
+// Z unchanged) only the norm is recomputed.  Same grid shape as pg_apply_kernel; partial[] gets one value per block.
+template <typename T>
+__global__ void pg_advance_kernel(T *Z, T *G, const T *GD0, const T *GD1, int64_t rows, int64_t cols, int64_t ld, const PgState *st, double *partial) {
+    if (st->gate) return;
+    const bool ap = st->apply != 0;
+    const T a = (T)st->alpha_apply;
+    const T *GD = st->gd_sel ? GD1 : GD0;
+    const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    double sum = 0.0;
+    for (int64_t c = blockIdx.y; c < cols; c += gridDim.y) {
+        T *z = Z + c * ld;
+        T *g = G + c * ld;
+        const T *gd = GD + c * ld;
+        for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+            T zv = z[r], gv = g[r];
+            if (ap) {
+                zv = pg_trial(zv, gv, a);
+                gv = gv + gd[r];
+                z[r] = zv;
+                g[r] = gv;
+            }
+            if (gv < (T)0 || zv > (T)0) sum += (double)(T)(gv * gv);
+        }
+    }
+    __shared__ double sm[8];
+    block_sum_store(sum, sm, (int)threadIdx.x, (int)blockDim.x, partial + (int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+}
 
 }  // namespace nmfx

@@ -27,7 +27,9 @@ def uniform(p, n, k, T, seed=1):
     return X, np.asfortranarray(W0.astype(T)), np.asfortranarray(H0.astype(T))
 
 
-def rel_trace_err(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+def rel_trace_err(a, b, floor=0.0):
+    """largest relative difference of two objective traces; values below `floor` (the objective's own resolution: an exact fit
+    leaves (a few eps * ||X||)^2 or 0 depending on the last bit of the factors) count as equal"""
+    a = np.maximum(np.asarray(a, dtype=np.float64), floor)
+    b = np.maximum(np.asarray(b, dtype=np.float64), floor)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))

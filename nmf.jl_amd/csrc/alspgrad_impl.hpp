@@ -70,7 +70,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cols, 2048 / gx));
     // H <- Hn / H <- Hp of the step that broke the loop (no-op while the loop is still running or unchanged)
     auto apply = [&](bool with_clear) {
-        hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, Z, G, rows, cols, ldz, pg_state);
+        hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, Z, G, rows, cols, ldz, pg_state, with_clear ? 0 : 1);
         if (with_clear) hipLaunchKernelGGL(pg_clear_apply_kernel, dim3(1), dim3(1), 0, stream, pg_state);
         HIP_TRY(hipGetLastError());
     };
@@ -95,7 +95,27 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     // enqueued behind it until the host has finished that search step by step.  One host round trip per AHEAD inner iterations
     // instead of one per iteration (it cost ~15 % of the C5 shard's time); the executed sequence, hence every counter and
     // every bit of Z, is the same.
-    const int SPEC = std::min(4, traceiter), AHEAD = 8;
+    // SPEC follows the searches seen so far (PgState::hist): the smallest count that all but ~3 % of them fit in -- a launch
+    // behind a finished search is a ~4.5 us no-op (x 2 with its decision kernel), a halt costs the rest of the batch as no-ops plus
+    // a host round trip (~170 us).  At the C5 shard shape every search takes 2 or 3 steps except 1-2 per sub-solve that take 5+:
+    // 3 instead of a fixed 4 saves 400 no-op pairs per outer iteration.  Scheduling only: the executed sequence does not change.
+    const int AHEAD = 8;
+    int SPEC = std::min(pg_spec_hint[left ? 0 : 1], traceiter);
+    int forced = 0;                                                        // NMFX_PG_SPEC=n pins it (tests: every value gives the same bits)
+    if (const char *e = std::getenv("NMFX_PG_SPEC")) forced = std::atoi(e);
+    if (forced > 0) SPEC = std::min(forced, traceiter);
+    auto retune = [&]() {
+        if (forced > 0) return;
+        long long total = 0;
+        for (int i = 0; i < 8; ++i) total += pg_host->hist[i];
+        if (total < 8) return;
+        for (int sp = 2; sp <= 4; ++sp) {
+            long long longer = 0;
+            for (int i = sp; i < 8; ++i) longer += pg_host->hist[i];
+            if (longer * 32 <= total || sp == 4) { SPEC = std::min(sp, traceiter); break; }
+        }
+        pg_spec_hint[left ? 0 : 1] = SPEC;
+    };
     long long t = 0;
     bool converged = false;
     while (!converged && t < maxiter) {
@@ -132,8 +152,14 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
         if (pg_host->nonfinite) throw StatusError{NMFX_ERR_ALPHA_NONFINITE, "alpha is not finite"};
         t = pg_host->t_inner;
         converged = pg_host->converged != 0;
+        retune();
     }
     apply(true);                                                           // the accept of the last executed search, if any
+    if (const char *e = std::getenv("NMFX_PG_HIST"); e && e[0] == '1' && pg_host) {
+        std::fprintf(stderr, "[nmfx] pg_subsolve(%s): %lld inner iterations, searches by steps:", left ? "H" : "W", t);
+        for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %d", pg_host->hist[i]);
+        std::fprintf(stderr, "\n");
+    }
     if (inner_total) *inner_total += t;
     pg_backtracks += pg_host ? pg_host->backtracks : 0;
     return t;

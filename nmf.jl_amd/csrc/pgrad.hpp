@@ -33,6 +33,7 @@ struct PgState {
     int halt;            // the line search of the current inner iteration needs more steps than were enqueued: the host takes over
     int t_inner;         // executed inner iterations of this sub-solve (the converged one included, like the reference's t)
     int gd_sel;          // which of the two Gram*D buffers belongs to the accepted trial point (valid with apply = 1)
+    int hist[8];         // finished line searches by number of steps (last bin: 8 or more); NMFX_PG_HIST=1 prints it per sub-solve
 };
 
 template <typename T> __device__ __forceinline__ T pg_trial(T z, T g, T alpha) {
@@ -221,7 +222,7 @@ __global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local
         }
     }
     st->alpha = (double)alpha;
-    if (brk || st->it >= traceiter) st->idle = 1;                         // loop exhausted: Z unchanged (quirk i)
+    if (brk || st->it >= traceiter) { st->idle = 1; st->hist[st->it < 8 ? st->it - 1 : 7] += 1; }   // loop exhausted: Z unchanged (quirk i)
     // last step enqueued for this inner iteration and the search is still running: it hands over to the host (every inner
     // iteration enqueued behind this one becomes a no-op until the host has finished the search).  A pending `apply`
     // request stays: the next inner iteration's pg_advance_kernel / pg_apply_kernel serves it.
@@ -232,8 +233,10 @@ __global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local
 // column-major blocks with leading dimension ld (a row block of W when the W side is row-sharded)
 // grid = (row chunks, column groups): a block walks a contiguous row range of its columns -- no per-element index division (the flat
 // form spent more time in two 64-bit divisions per element than in the 3 x 134 MB it moves on the W side of a C5 shard)
-template <typename T> __global__ void pg_apply_kernel(T *Z, const T *G, int64_t rows, int64_t cols, int64_t ld, PgState *st) {
-    if (!st->apply) return;
+// respect_gate: the launch belongs to an inner iteration enqueued ahead of the host (a no-op behind a converged or halted one: the
+// request it would serve then belongs to the iteration the host enqueues again after the halt)
+template <typename T> __global__ void pg_apply_kernel(T *Z, const T *G, int64_t rows, int64_t cols, int64_t ld, const PgState *st, int respect_gate) {
+    if (!st->apply || (respect_gate && st->gate)) return;
     const T a = (T)st->alpha_apply;
     const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = (r0 + per < rows) ? r0 + per : rows;

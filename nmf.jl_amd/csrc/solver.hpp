@@ -1080,6 +1080,7 @@ template <typename T> class Solver : public SolverBase {
     long long pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int maxiter, int traceiter, T tolg, T beta, T sigma,
                           long long *inner_total);
     struct PgState *pg_state = nullptr, *pg_host = nullptr;
+    int pg_spec_hint[2] = {3, 3};   // speculative line-search steps per enqueued inner iteration (H side, W side), alspgrad_impl.hpp
     DevBuf<double> pg_part;
     long long pg_backtracks = 0;
 };

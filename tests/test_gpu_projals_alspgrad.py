@@ -143,6 +143,24 @@ def test_alspgrad_trajectory(built, T, shape):
         assert np.max(np.abs(Wg - Wc)) <= 1e-6 * np.max(np.abs(Wc))
 
 
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_alspgrad_speculation_depth_is_scheduling_only(built, T, monkeypatch):
+    """The sub-solve is enqueued ahead of the host with SPEC speculative line-search steps per inner iteration (adaptive: 2..4);
+    a search that needs more halts the iterations queued behind it and they are enqueued again.  Whatever the depth -- 1 halts on
+    every search that takes two steps, i.e. on nearly every inner iteration, with the full-product gradient refreshes (every 64 /
+    16 inner iterations) landing inside halted stretches -- the executed sequence is the same: identical bits, identical counters."""
+    X, W0, H0 = planted(140, 300, 9, T, seed=77)
+    outs = []
+    for spec in ("0", "1", "2", "3", "4"):
+        monkeypatch.setenv("NMFX_PG_SPEC", spec)                   # 0: adaptive
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        r = nmfx.solve(nmfx.ALSPGrad(T, maxiter=6, tol=1e-30), X, W, H, track_objective=True)
+        outs.append((W, H, r.info["inner_iters"], r.info["backtracks"], np.asarray(r.trace)))
+    for W, H, it, bt, tr in outs[1:]:
+        assert it == outs[0][2] and bt == outs[0][3]
+        assert np.array_equal(W, outs[0][0]) and np.array_equal(H, outs[0][1]) and np.array_equal(tr, outs[0][4])
+
+
 @pytest.mark.parametrize("alg_name", ["projals", "alspgrad"])
 @pytest.mark.parametrize("T", [np.float64, np.float32])
 def test_update_H_false(built, alg_name, T):

@@ -57,13 +57,10 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
             gemm<KSTRIDED, KSTRIDED, 2>("gemm_pg_step", Gram, K, K, Z, P, Rw, K, 1, false, e, idle, 4.0 * Rw * K * sizeof(T), sg);
         }
         nblk = last_blocks;
-        if (reduce_scalars) {
-            hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 3, 0, 1);
-            comm->all_reduce(pg_state->red, 3, CT_F64, false, stream);
-            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, beta, sigma, epsT, traceiter, last_enqueued ? 1 : 0);
-        } else {
-            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, beta, sigma, epsT, traceiter, last_enqueued ? 1 : 0);
-        }
+        // sharded: the per-block partials themselves are all-reduced (a few KB: the same latency-bound collective as 3 doubles, and
+        // no local reduction launch in front of it); every rank then sums the same numbers in the same order
+        if (reduce_scalars) comm->all_reduce(pg_part.p, (size_t)3 * nblk, CT_F64, false, stream);
+        hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, beta, sigma, epsT, traceiter, last_enqueued ? 1 : 0);
     };
     // ~2048 blocks: row chunks of >= 1024 rows, the rest of the parallelism from the columns
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, rows / 1024));
@@ -128,13 +125,8 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
             } else {
                 nblk = advance();
             }
-            if (reduce_scalars) {
-                hipLaunchKernelGGL(pg_reduce_kernel, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, 1, 3, 2);
-                comm->all_reduce(pg_state->red + 3, 1, CT_F64, false, stream);
-                hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, tolg);
-            } else {
-                hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, tolg);
-            }
+            if (reduce_scalars) comm->all_reduce(pg_part.p, (size_t)nblk, CT_F64, false, stream);
+            hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, tolg);
             for (int sidx = 0; sidx < SPEC; ++sidx) step(sidx == SPEC - 1);
         }
         fetch();

@@ -150,7 +150,7 @@ __device__ __forceinline__ void pg_block_sum3(const double *partial, int n, doub
 }
 
 // start of an inner iteration (src/alspgrad.jl:129-137): red[3] = projgradnorm^2 from the gradient GEMM's partials
-// (n_local = 0 when the caller already reduced / all-reduced them into red[3]); converged if < tolg, else arm back-tracking.
+// (sharded: all-reduced across the ranks first, block by block); converged if < tolg, else arm back-tracking.
 template <typename T> __global__ void pg_begin_kernel(PgState *st, const double *partial, int n_local, T tolg) {
     if (st->gate) return;
     __shared__ double sm[4];
@@ -176,18 +176,6 @@ template <typename T> __global__ void pg_begin_kernel(PgState *st, const double 
 __global__ void pg_resume_kernel(PgState *st) {
     st->halt = 0;
     st->gate = st->converged ? 1 : 0;
-}
-
-// only the reduction part (sharded H: the partial sums are all-reduced before the decision)
-__global__ void pg_reduce_kernel(PgState *st, const double *partial, int n, int nslots, int slot0, int guard_idle) {
-    if (guard_idle == 1 && st->idle) return;
-    if (guard_idle == 2 && st->gate) return;
-    __shared__ double sm[4];
-    for (int sl = 0; sl < nslots; ++sl) {
-        const double s = pg_block_sum(partial, n, nslots, sl, sm);
-        if (threadIdx.x == 0) st->red[slot0 + sl] = s;
-        __syncthreads();
-    }
 }
 
 // The branch logic of one back-tracking step (src/alspgrad.jl:155-177); n_local > 0: sum the step's partials first.

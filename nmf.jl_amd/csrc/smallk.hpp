@@ -36,9 +36,14 @@ typedef float smallk_v4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ smallk_v4 smallk_mfma(float a, float b, smallk_v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 constexpr int SMALLK_THREADS = 512;
+// ST = contraction rows (H side) / columns (W side) per stage = per workgroup barrier: 128 (16 MFMAs per wave between barriers;
+// 64 left the two waves of a SIMD waiting at a barrier for about as long as they computed)
+constexpr int SMALLK_ST = 128;
 // LDS floats: staged operands (2 stages) | Gram | old-factor stripe | half-combine | new-factor stripe
-constexpr int SMALLK_H_LDS = 2 * 64 * 68 + 2 * 16 * 68 + 64 * 80 + 16 * 68 + 4 * 64 * 4 + 16 * 80;
-constexpr int SMALLK_W_LDS = 2 * 64 * 80 + 2 * 64 * 16 + 64 * 80 + 64 * 16 + 4 * 64 * 4 + 16 * 80;
+template <int ST> constexpr int smallk_h_lds() { return 2 * 64 * (ST + 4) + 2 * 16 * (ST + 4) + 64 * 80 + 16 * 68 + 4 * 64 * 4 + 16 * 80; }
+template <int ST> constexpr int smallk_w_lds() { return 2 * ST * 80 + 2 * ST * 16 + 64 * 80 + 64 * 16 + 4 * 64 * 4 + 16 * 80; }
+constexpr int SMALLK_H_LDS = smallk_h_lds<SMALLK_ST>();
+constexpr int SMALLK_W_LDS = smallk_w_lds<SMALLK_ST>();
 
 // multiplicative update of one element (EpiMultUpdate::apply, gemm_mfma.hpp): max(zero(T), num - lambda) with Julia's NaN rule
 __device__ __forceinline__ float smallk_update(float ov, float nu, float dn, float lambda, float delta) {
@@ -72,36 +77,55 @@ __device__ __forceinline__ void smallk_stripe_gram(const float *S, float *slab, 
 // loads, 256 contiguous bytes per 16 threads), double-buffered, one barrier per stage; two register sets keep the global loads
 // two stages ahead.  Wave (w, half): output tile w (components 16w ..), contraction rows 32 half .. of every stage; every
 // fragment read is a conflict-free ds_read_b32 (row strides 68 / 80 / 16 floats put the 64 lanes on 64 different banks).
+template <int ST>
 __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X, int64_t ldx, int64_t P, const float *W, const float *gramW, const float *Ho,
                                                                   float *Hn, float lambda, float delta, float *gram_slabs, double *stat_part,
                                                                   const int *done) {
     if (done && *done) return;
+    constexpr int LD = ST + 4;           // LDS row stride: 4 mod 32 banks, like 68
+    constexpr int C4 = ST / 4;           // float4 chunks per staged row
+    constexpr int NW = 64 * C4 / SMALLK_THREADS, NX = (16 * C4 + SMALLK_THREADS - 1) / SMALLK_THREADS;   // chunks per thread and stage
+    constexpr bool XALL = (16 * C4 >= SMALLK_THREADS);
     extern __shared__ __attribute__((aligned(16))) float smallk_lds[];
-    float *Wc = smallk_lds;              // [2][64 comps][68]   W(p, comp), p contiguous
-    float *Xc = Wc + 2 * 64 * 68;        // [2][16 cols][68]    X(p, col)
-    float *Gs = Xc + 2 * 16 * 68;        // [64 a][80]          gramW(comp, a), comp contiguous
+    float *Wc = smallk_lds;              // [2][64 comps][LD]   W(p, comp), p contiguous
+    float *Xc = Wc + 2 * 64 * LD;        // [2][16 cols][LD]    X(p, col)
+    float *Gs = Xc + 2 * 16 * LD;        // [64 a][80]          gramW(comp, a), comp contiguous
     float *Hs = Gs + 64 * 80;            // [16 cols][68]       Ho(a, col), a contiguous
     float *Cx = Hs + 16 * 68;            // [4 waves][64 lanes][4]
     float *Sn = Cx + 4 * 64 * 4;         // [16 cols][80]       Hn(comp, col), comp contiguous
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = wave & 3, half = wave >> 2, i = lane & 15, kg = lane >> 4;
     const int stripe = smallk_stripe();
     const int64_t c0 = (int64_t)stripe * 16;
-    // staging: W stage = 1024 float4 (2 per thread), X stage = 256 float4 (threads 0..255)
-    const int wc0 = tid >> 4, wp4 = tid & 15;
-    const float *wsrc0 = W + (int64_t)wc0 * ldx + 4 * wp4, *wsrc1 = W + (int64_t)(wc0 + 32) * ldx + 4 * wp4;
-    const float *xsrc = X + (c0 + (tid >> 4)) * ldx + 4 * (tid & 15);
-    smallk_v4 rw0[2], rw1[2], rx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // staging: W stage = 64 x C4 float4 (NW per thread: chunk tid + 512 q -> component chunk / C4), X stage = 16 x C4 float4
+    const bool xld = XALL || tid < 16 * C4;
+    smallk_v4 rw[2][NW], rx[2][NX];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) { rx[0][q] = smallk_v4{0.f, 0.f, 0.f, 0.f}; rx[1][q] = rx[0][q]; }
     auto gload = [&](int set, int64_t p0) {
-        rw0[set] = *reinterpret_cast<const smallk_v4 *>(wsrc0 + p0);
-        rw1[set] = *reinterpret_cast<const smallk_v4 *>(wsrc1 + p0);
-        if (tid < 256) rx[set] = *reinterpret_cast<const smallk_v4 *>(xsrc + p0);
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int c = tid + SMALLK_THREADS * q;
+            rw[set][q] = *reinterpret_cast<const smallk_v4 *>(W + (int64_t)(c / C4) * ldx + p0 + 4 * (c % C4));
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int c = tid + SMALLK_THREADS * q;
+            if (xld) rx[set][q] = *reinterpret_cast<const smallk_v4 *>(X + (c0 + c / C4) * ldx + p0 + 4 * (c % C4));
+        }
     };
     auto lstore = [&](int set, int buf) {
-        *reinterpret_cast<smallk_v4 *>(Wc + buf * 64 * 68 + wc0 * 68 + 4 * wp4) = rw0[set];
-        *reinterpret_cast<smallk_v4 *>(Wc + buf * 64 * 68 + (wc0 + 32) * 68 + 4 * wp4) = rw1[set];
-        if (tid < 256) *reinterpret_cast<smallk_v4 *>(Xc + buf * 16 * 68 + (tid >> 4) * 68 + 4 * (tid & 15)) = rx[set];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int c = tid + SMALLK_THREADS * q;
+            *reinterpret_cast<smallk_v4 *>(Wc + buf * 64 * LD + (c / C4) * LD + 4 * (c % C4)) = rw[set][q];
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int c = tid + SMALLK_THREADS * q;
+            if (xld) *reinterpret_cast<smallk_v4 *>(Xc + buf * 16 * LD + (c / C4) * LD + 4 * (c % C4)) = rx[set][q];
+        }
     };
-    const int T = (int)(P / 64);      // even: P is a multiple of 256
+    const int T = (int)(P / ST);      // even: P is a multiple of 256
     gload(0, 0);
     // operands of the epilogue (independent of the main loop): gramW and the old stripe -- requested behind the first stage so
     // that the cold round trips overlap
@@ -112,8 +136,8 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X
         smallk_v4 h0 = {0.f, 0.f, 0.f, 0.f};
         if (tid < 256) h0 = *reinterpret_cast<const smallk_v4 *>(Ho + (c0 + (tid >> 4)) * 64 + 4 * (tid & 15));
         lstore(0, 0);
-        gload(0, 64);
-        if (T > 2) gload(1, 128);
+        gload(0, ST);
+        if (T > 2) gload(1, 2 * ST);
         *reinterpret_cast<smallk_v4 *>(Gs + a * 80 + 4 * c4) = g0;
         *reinterpret_cast<smallk_v4 *>(Gs + (a + 32) * 80 + 4 * c4) = g1;
         if (tid < 256) *reinterpret_cast<smallk_v4 *>(Hs + (tid >> 4) * 68 + 4 * (tid & 15)) = h0;
@@ -123,15 +147,15 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X
     auto step = [&](int t, auto SET) {
         constexpr int set = decltype(SET)::value;      // = t & 1: stage t+1 waits in register set t & 1
         const int buf = t & 1;
-        const float *wa = Wc + buf * 64 * 68 + (16 * w + i) * 68 + 32 * half + kg;
-        const float *xb = Xc + buf * 16 * 68 + i * 68 + 32 * half + kg;
+        const float *wa = Wc + buf * 64 * LD + (16 * w + i) * LD + (ST / 2) * half + kg;
+        const float *xb = Xc + buf * 16 * LD + i * LD + (ST / 2) * half + kg;
 #pragma unroll
-        for (int m = 0; m < 8; m += 2) {
+        for (int m = 0; m < ST / 8; m += 2) {
             acc0 = smallk_mfma(wa[4 * m], xb[4 * m], acc0);
             acc1 = smallk_mfma(wa[4 * m + 4], xb[4 * m + 4], acc1);
         }
         if (t + 1 < T) lstore(set, buf ^ 1);
-        if (t + 3 < T) gload(set, (int64_t)(t + 3) * 64);
+        if (t + 3 < T) gload(set, (int64_t)(t + 3) * ST);
         __syncthreads();
     };
     for (int t = 0; t < T; t += 2) {
@@ -179,37 +203,54 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X
 }
 
 // W side.  gramH: 64 x 64, Wo / Wn: P x 64 (ld ldx), H: 64 x N (ld 64).  grid = P / 16, 512 threads.
-// Same structure with 64 COLUMNS per stage (H staged component-contiguous, X row-contiguous).
+// Same structure with ST COLUMNS per stage (H staged component-contiguous, X row-contiguous).
+template <int ST>
 __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X, int64_t ldx, int64_t N, const float *H, const float *gramH, const float *Wo,
                                                                   float *Wn, float lambda, float delta, float *gram_slabs, double *stat_part,
                                                                   const int *done) {
     if (done && *done) return;
     extern __shared__ __attribute__((aligned(16))) float smallk_lds[];
-    float *Hc = smallk_lds;              // [2][64 cols][80]    H(comp, col), comp contiguous
-    float *Xc = Hc + 2 * 64 * 80;        // [2][64 cols][16]    X(row, col), row contiguous
-    float *Gs = Xc + 2 * 64 * 16;        // [64 a][80]          gramH(comp, a)
+    constexpr int NH = ST * 16 / SMALLK_THREADS, NX = (ST * 4 + SMALLK_THREADS - 1) / SMALLK_THREADS;   // float4 chunks per thread and stage
+    constexpr bool XALL = (ST * 4 >= SMALLK_THREADS);
+    float *Hc = smallk_lds;              // [2][ST cols][80]    H(comp, col), comp contiguous
+    float *Xc = Hc + 2 * ST * 80;        // [2][ST cols][16]    X(row, col), row contiguous
+    float *Gs = Xc + 2 * ST * 16;        // [64 a][80]          gramH(comp, a)
     float *Ws = Gs + 64 * 80;            // [64 a][16 rows]     Wo(row, a), row contiguous
     float *Cx = Ws + 64 * 16;            // [4][64][4]
     float *Sn = Cx + 4 * 64 * 4;         // [16 rows][80]       Wn(row, comp), comp contiguous
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = wave & 3, half = wave >> 2, i = lane & 15, kg = lane >> 4;
     const int stripe = smallk_stripe();
     const int64_t r0 = (int64_t)stripe * 16;
-    // staging: H stage = 64 cols x 64 comps = 1024 float4 (2 per thread), X stage = 64 cols x 16 rows = 256 float4
-    const int hc0 = tid >> 4, h4 = tid & 15;
-    const float *hsrc0 = H + (int64_t)hc0 * 64 + 4 * h4, *hsrc1 = H + (int64_t)(hc0 + 32) * 64 + 4 * h4;
-    const float *xsrc = X + r0 + 4 * (tid & 3) + (int64_t)(tid >> 2) * ldx;
-    smallk_v4 rh0[2], rh1[2], rx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // two stages ahead, as in smallk_h_kernel
+    // staging: H stage = ST cols x 64 comps = 16 ST float4 (NH per thread: chunk tid + 512 q -> column chunk / 16), X stage = ST cols x 16 rows
+    const bool xld = XALL || tid < ST * 4;
+    smallk_v4 rh[2][NH], rx[2][NX];      // two stages ahead, as in smallk_h_kernel
+#pragma unroll
+    for (int q = 0; q < NX; ++q) { rx[0][q] = smallk_v4{0.f, 0.f, 0.f, 0.f}; rx[1][q] = rx[0][q]; }
     auto gload = [&](int set, int64_t j0) {
-        rh0[set] = *reinterpret_cast<const smallk_v4 *>(hsrc0 + j0 * 64);
-        rh1[set] = *reinterpret_cast<const smallk_v4 *>(hsrc1 + j0 * 64);
-        if (tid < 256) rx[set] = *reinterpret_cast<const smallk_v4 *>(xsrc + j0 * ldx);
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int c = tid + SMALLK_THREADS * q;
+            rh[set][q] = *reinterpret_cast<const smallk_v4 *>(H + (j0 + (c >> 4)) * 64 + 4 * (c & 15));
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int c = tid + SMALLK_THREADS * q;
+            if (xld) rx[set][q] = *reinterpret_cast<const smallk_v4 *>(X + r0 + 4 * (c & 3) + (j0 + (c >> 2)) * ldx);
+        }
     };
     auto lstore = [&](int set, int buf) {
-        *reinterpret_cast<smallk_v4 *>(Hc + buf * 64 * 80 + hc0 * 80 + 4 * h4) = rh0[set];
-        *reinterpret_cast<smallk_v4 *>(Hc + buf * 64 * 80 + (hc0 + 32) * 80 + 4 * h4) = rh1[set];
-        if (tid < 256) *reinterpret_cast<smallk_v4 *>(Xc + buf * 64 * 16 + (tid >> 2) * 16 + 4 * (tid & 3)) = rx[set];
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int c = tid + SMALLK_THREADS * q;
+            *reinterpret_cast<smallk_v4 *>(Hc + buf * ST * 80 + (c >> 4) * 80 + 4 * (c & 15)) = rh[set][q];
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int c = tid + SMALLK_THREADS * q;
+            if (xld) *reinterpret_cast<smallk_v4 *>(Xc + buf * ST * 16 + (c >> 2) * 16 + 4 * (c & 3)) = rx[set][q];
+        }
     };
-    const int T = (int)(N / 64);      // even: N is a multiple of 256
+    const int T = (int)(N / ST);      // even: N is a multiple of 256
     gload(0, 0);
     {
         const int a = tid >> 4, c4 = tid & 15;
@@ -218,8 +259,8 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X
         smallk_v4 w0 = {0.f, 0.f, 0.f, 0.f};
         if (tid < 256) w0 = *reinterpret_cast<const smallk_v4 *>(Wo + r0 + 4 * (tid & 3) + (int64_t)(tid >> 2) * ldx);
         lstore(0, 0);
-        gload(0, 64);
-        if (T > 2) gload(1, 128);
+        gload(0, ST);
+        if (T > 2) gload(1, 2 * ST);
         *reinterpret_cast<smallk_v4 *>(Gs + a * 80 + 4 * c4) = g0;
         *reinterpret_cast<smallk_v4 *>(Gs + (a + 32) * 80 + 4 * c4) = g1;
         if (tid < 256) *reinterpret_cast<smallk_v4 *>(Ws + (tid >> 2) * 16 + 4 * (tid & 3)) = w0;
@@ -229,15 +270,15 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X
     auto step = [&](int t, auto SET) {
         constexpr int set = decltype(SET)::value;
         const int buf = t & 1;
-        const float *ha = Hc + buf * 64 * 80 + (32 * half + kg) * 80 + 16 * w + i;
-        const float *xb = Xc + buf * 64 * 16 + (32 * half + kg) * 16 + i;
+        const float *ha = Hc + buf * ST * 80 + ((ST / 2) * half + kg) * 80 + 16 * w + i;
+        const float *xb = Xc + buf * ST * 16 + ((ST / 2) * half + kg) * 16 + i;
 #pragma unroll
-        for (int m = 0; m < 8; m += 2) {
+        for (int m = 0; m < ST / 8; m += 2) {
             acc0 = smallk_mfma(ha[4 * m * 80], xb[4 * m * 16], acc0);
             acc1 = smallk_mfma(ha[(4 * m + 4) * 80], xb[(4 * m + 4) * 16], acc1);
         }
         if (t + 1 < T) lstore(set, buf ^ 1);
-        if (t + 3 < T) gload(set, (int64_t)(t + 3) * 64);
+        if (t + 3 < T) gload(set, (int64_t)(t + 3) * ST);
         __syncthreads();
     };
     for (int t = 0; t < T; t += 2) {

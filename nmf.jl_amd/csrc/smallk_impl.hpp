@@ -11,8 +11,8 @@ template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o)
         const int64_t stripes_h = N / 16, stripes_w = P / 16;
         smallk_slabs.ensure((size_t)std::max(stripes_h, stripes_w) * 4096);
         if (!smallk_attr_set) {      // per context: the attribute belongs to the device the context lives on
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&smallk_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMALLK_H_LDS * 4));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&smallk_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMALLK_W_LDS * 4));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&smallk_h_kernel<SMALLK_ST>), hipFuncAttributeMaxDynamicSharedMemorySize, SMALLK_H_LDS * 4));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&smallk_w_kernel<SMALLK_ST>), hipFuncAttributeMaxDynamicSharedMemorySize, SMALLK_W_LDS * 4));
             smallk_attr_set = true;
         }
         if (!smallk_grams_valid) {
@@ -25,7 +25,7 @@ template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o)
             const T *Ho = H[hcur].p;
             T *Hn = H[hcur ^ 1].p;
             timed("smallk_H", 2.0 * P * N * K + 2.0 * K * K * N * 2, (double)(P * N + P * K + 2 * K * N) * sizeof(T), [&] {
-                hipLaunchKernelGGL(smallk_h_kernel, dim3((unsigned)stripes_h), dim3(SMALLK_THREADS), SMALLK_H_LDS * 4, stream, X.p, P, P, W[wcur].p, gramW_p,
+                hipLaunchKernelGGL(smallk_h_kernel<SMALLK_ST>, dim3((unsigned)stripes_h), dim3(SMALLK_THREADS), SMALLK_H_LDS * 4, stream, X.p, P, P, W[wcur].p, gramW_p,
                                    Ho, Hn, (float)o.lambda_h, (float)o.delta, smallk_slabs.p, stat_part.p, done);
                 HIP_TRY(hipGetLastError());
             });
@@ -38,7 +38,7 @@ template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o)
         const T *Wo = W[wcur].p;
         T *Wn = W[wcur ^ 1].p;
         timed("smallk_W", 2.0 * P * N * K + 2.0 * K * K * P * 2, (double)(P * N + 2 * P * K) * sizeof(T), [&] {
-            hipLaunchKernelGGL(smallk_w_kernel, dim3((unsigned)stripes_w), dim3(SMALLK_THREADS), SMALLK_W_LDS * 4, stream, X.p, P, N, H[hcur].p, gramH_p, Wo, Wn,
+            hipLaunchKernelGGL(smallk_w_kernel<SMALLK_ST>, dim3((unsigned)stripes_w), dim3(SMALLK_THREADS), SMALLK_W_LDS * 4, stream, X.p, P, N, H[hcur].p, gramH_p, Wo, Wn,
                                (float)o.lambda_w, (float)o.delta, smallk_slabs.p, stat_part.p, done);
             HIP_TRY(hipGetLastError());
         });

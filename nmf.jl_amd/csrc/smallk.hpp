@@ -77,7 +77,9 @@ __device__ __forceinline__ void smallk_stripe_gram(const float *S, float *slab, 
 // loads, 256 contiguous bytes per 16 threads), double-buffered, one barrier per stage; two register sets keep the global loads
 // two stages ahead.  Wave (w, half): output tile w (components 16w ..), contraction rows 32 half .. of every stage; every
 // fragment read is a conflict-free ds_read_b32 (row strides 68 / 80 / 16 floats put the 64 lanes on 64 different banks).
-template <int ST>
+// PROBE (scripts/kbench/smallk_probe.hip only; 0 in the library): 1 = no global loads inside the loop, 2 = no MFMAs, 3 = no
+// staging at all (neither the LDS stores nor the global loads), 4 = no fragment reads either (MFMAs on registers)
+template <int ST, int PROBE = 0>
 __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X, int64_t ldx, int64_t P, const float *W, const float *gramW, const float *Ho,
                                                                   float *Hn, float lambda, float delta, float *gram_slabs, double *stat_part,
                                                                   const int *done) {
@@ -151,11 +153,21 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X
         const float *xb = Xc + buf * 16 * LD + i * LD + (ST / 2) * half + kg;
 #pragma unroll
         for (int m = 0; m < ST / 8; m += 2) {
-            acc0 = smallk_mfma(wa[4 * m], xb[4 * m], acc0);
-            acc1 = smallk_mfma(wa[4 * m + 4], xb[4 * m + 4], acc1);
+            if constexpr (PROBE == 2) {
+                acc0[0] += wa[4 * m] * xb[4 * m];
+                acc1[0] += wa[4 * m + 4] * xb[4 * m + 4];
+            } else if constexpr (PROBE == 4) {
+                acc0 = smallk_mfma(acc1[1], acc1[2], acc0);
+                acc1 = smallk_mfma(acc0[1], acc0[2], acc1);
+            } else {
+                acc0 = smallk_mfma(wa[4 * m], xb[4 * m], acc0);
+                acc1 = smallk_mfma(wa[4 * m + 4], xb[4 * m + 4], acc1);
+            }
         }
-        if (t + 1 < T) lstore(set, buf ^ 1);
-        if (t + 3 < T) gload(set, (int64_t)(t + 3) * ST);
+        if constexpr (PROBE < 3)
+            if (t + 1 < T) lstore(set, buf ^ 1);
+        if constexpr (PROBE == 0 || PROBE == 2)
+            if (t + 3 < T) gload(set, (int64_t)(t + 3) * ST);
         __syncthreads();
     };
     for (int t = 0; t < T; t += 2) {

@@ -342,7 +342,8 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X
 // element: every load of a thread is independent, one round trip; the 16 partial sums are added in lane order: fixed order),
 // blocks [256, 256 + 32) sum the statistics partials (128 values, a wave per value as in finalize_partials_kernel).
 __global__ __launch_bounds__(256) void smallk_finish_kernel(float *gram, const float *slabs, int nstripes, const double *stat_part, double *stat_out,
-                                                           const int *done) {
+                                                           const int *done, Ctrl *ctrl = nullptr, const double *hstat = nullptr, int k = 0, float tol = 0.f,
+                                                           long long t = 0, unsigned *ticket = nullptr) {
     if (done && *done) return;
     if (blockIdx.x < 256) {
         __shared__ float sm[16][16];
@@ -364,6 +365,22 @@ __global__ __launch_bounds__(256) void smallk_finish_kernel(float *gram, const f
         for (int c = lane; c < nstripes; c += 64) s += stat_part[(int64_t)c * 128 + e];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane == 0) stat_out[e] = s;
+        if (ctrl != nullptr) {
+            // W side, not tracking: the stop rule of this iteration (check_kernel's work) runs in the LAST of the 32 statistics blocks
+            // to finish -- 32 device-scope increments, not a launch (4.9 us per iteration at 4096^2, k = 64).  Agent-scope release by
+            // every block, acquire by the last one (cdna_hip_programming.md); the counter only ever grows, 32 per launch.
+            __shared__ int last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = ((prev & 31u) == 31u) ? 1 : 0;
+                if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            if (last) check_body<float>(ctrl, stat_out, hstat, k, tol, t, nullptr);
+        }
     }
 }
 

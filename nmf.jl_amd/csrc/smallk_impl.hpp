@@ -5,7 +5,7 @@
 
 namespace nmfx {
 
-template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o) {
+template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o, long long t) {
     if constexpr (sizeof(T) == 4) {
         const int *done = done_flag();
         const int64_t stripes_h = N / 16, stripes_w = P / 16;
@@ -42,10 +42,19 @@ template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o)
                                (float)o.lambda_w, (float)o.delta, smallk_slabs.p, stat_part.p, done);
             HIP_TRY(hipGetLastError());
         });
+        // the stop rule of this iteration rides in the W-side finish launch unless the caller tracks the objective (check_kernel then
+        // also records the verbose table's relchange column)
+        const bool fuse_check = o.track_objective == 0;
+        if (fuse_check && !smallk_ticket.p) smallk_ticket.ensure(1);
         timed("smallk_finish_W", 0.0, (double)stripes_w * (4096 * sizeof(T) + 128 * sizeof(double)), [&] {
-            hipLaunchKernelGGL(smallk_finish_kernel, dim3(256 + 32), dim3(256), 0, stream, gramW_p, smallk_slabs.p, (int)stripes_w, stat_part.p, wstat.p, done);
+            if (fuse_check)
+                hipLaunchKernelGGL(smallk_finish_kernel, dim3(256 + 32), dim3(256), 0, stream, gramW_p, smallk_slabs.p, (int)stripes_w, stat_part.p, wstat.p, done, ctrl,
+                                   o.update_H ? hstat.p : (const double *)nullptr, (int)k, (float)o.tol, t, smallk_ticket.p);
+            else
+                hipLaunchKernelGGL(smallk_finish_kernel, dim3(256 + 32), dim3(256), 0, stream, gramW_p, smallk_slabs.p, (int)stripes_w, stat_part.p, wstat.p, done);
             HIP_TRY(hipGetLastError());
         });
+        check_fused = fuse_check;
         wcur ^= 1;
     }
 }

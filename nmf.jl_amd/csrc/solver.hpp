@@ -990,6 +990,7 @@ template <typename T> class Solver : public SolverBase {
     bool smallk_attr_set = false;
     bool smallk_grams_valid = false;     // gramW_p / gramH_p hold the Grams of the CURRENT factors (reset by every iterate())
     DevBuf<T> smallk_slabs;              // the stripes' Gram contributions
+    DevBuf<unsigned> smallk_ticket;      // arrival counter of the W-side finish launch's statistics blocks (the last one runs the stop rule)
     // measured crossover (scripts/bench: 1024^2 2.4x, 2048^2 1.75x, 4096^2 1.25x faster than the general path; 8192^2 0.8x): a stripe
     // kernel re-reads the whole other factor per 16-wide stripe, which stops paying once the problem is large enough to keep the
     // split-K products busy; very skewed shapes leave one side with too few stripes
@@ -997,7 +998,7 @@ template <typename T> class Solver : public SolverBase {
         return sizeof(T) == 4 && K == 64 && !sharded() && smallk_enabled && !use_bf16x3() && P * N <= (int64_t)4096 * 4096 &&
                std::max(P, N) <= 4 * std::min(P, N);
     }
-    void enqueue_multmse_smallk(const nmfx_opts &o);
+    void enqueue_multmse_smallk(const nmfx_opts &o, long long t);
     void enqueue_multdiv(const nmfx_opts &o, long long t);
     // multdiv on one GPU: the passes behind each numerator product fused (kernels.hpp: div_h_fused_kernel / div_w_fused_kernel);
     // svec / sH_p then carry sum(W, dims=1) / sum(H, dims=2) of the CURRENT factors from one side's pass to the other's

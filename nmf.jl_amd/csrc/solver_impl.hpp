@@ -132,7 +132,7 @@ template <typename T> void Solver<T>::gather_w_rows(T *Wfull, bool with_stats, c
 // ---------------------------------------------------------------------------
 template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long long t) {
     (void)t;
-    if (smallk_ok()) { enqueue_multmse_smallk(o); return; }
+    if (smallk_ok()) { enqueue_multmse_smallk(o, t); return; }
     const int *done = done_flag();
     if (o.update_H) {
         const T *Wp = W[wcur].p;

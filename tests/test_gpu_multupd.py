@@ -160,6 +160,28 @@ def test_multmse_small_k_path(built, shape, update_H, monkeypatch):
         assert rel_trace_err(ra.trace, ro.trace) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(300, 260, 5), (1000, 1500, 64)])
+@pytest.mark.parametrize("update_H", [True, False])
+def test_small_k_path_stop_rule_in_the_finish_launch(built, shape, update_H):
+    """Without objective tracking the small-k path evaluates stop_condition inside its W-side finish launch (the last of the 32
+    statistics blocks to arrive; csrc/smallk.hpp), with tracking the separate check kernel does: both must stop at the same
+    iteration with the same factors, for a tolerance that is reached and for one that is not."""
+    p, n, k = shape
+    T = np.float32
+    X, W0, H0 = planted(p, n, k, T, seed=p + 3 * k)
+    for tol, maxiter in ((2e-2, 200), (1e-30, 25)):
+        out = []
+        for track in (True, False):
+            W, H = W0.copy(order="F"), H0.copy(order="F")
+            r = nmfx.solve(nmfx.MultUpdate(T, obj="mse", maxiter=maxiter, tol=tol, update_H=update_H), X, W, H, track_objective=track)
+            out.append((r, W, H))
+        (ra, Wa, Ha), (rb, Wb, Hb) = out
+        assert ra.niters == rb.niters and ra.converged == rb.converged
+        assert (ra.converged and ra.niters < maxiter) if tol > 1e-10 else (not ra.converged and ra.niters == maxiter)
+        assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
+        assert np.isclose(ra.objvalue, rb.objvalue, rtol=1e-6)
+
+
 @pytest.mark.parametrize("T", [np.float32, np.float64])
 @pytest.mark.parametrize("shape", [(300, 260, 5), (1000, 1500, 70), (513, 2100, 130)])
 @pytest.mark.parametrize("update_H", [True, False])

@@ -338,29 +338,31 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X
     smallk_stripe_gram(Sn, gram_slabs + (int64_t)stripe * 4096, wave, i, kg);
 }
 
-// After a stripe kernel, ONE launch: blocks [0, 256) sum the stripes' Gram contributions (16 elements per block, 16 slab-lanes per
-// element: every load of a thread is independent, one round trip; the 16 partial sums are added in lane order: fixed order),
-// blocks [256, 256 + 32) sum the statistics partials (128 values, a wave per value as in finalize_partials_kernel).
+// After a stripe kernel, ONE launch: blocks [0, 128) sum the stripes' Gram contributions, blocks [128, 128 + 32) sum the statistics
+// partials (128 values, a wave per value as in finalize_partials_kernel).
+constexpr int SMALLK_GRAM_BLOCKS = 128;
 __global__ __launch_bounds__(256) void smallk_finish_kernel(float *gram, const float *slabs, int nstripes, const double *stat_part, double *stat_out,
                                                            const int *done, Ctrl *ctrl = nullptr, const double *hstat = nullptr, int k = 0, float tol = 0.f,
                                                            long long t = 0, unsigned *ticket = nullptr) {
     if (done && *done) return;
-    if (blockIdx.x < 256) {
-        __shared__ float sm[16][16];
-        const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
-        const int64_t i = (int64_t)blockIdx.x * 16 + e;
-        float acc = 0.f;
-        for (int k = sl; k < nstripes; k += 16) acc += slabs[(int64_t)k * 4096 + i];
-        sm[sl][e] = acc;
+    if (blockIdx.x < SMALLK_GRAM_BLOCKS) {
+        // 32 Gram elements (one 128-byte line of every slab) per block: thread = (float4 e4 of the line, slab lane sl of 32); a wave-load
+        // covers 8 whole lines; the 32 slab-lane partials are added in lane order (fixed order)
+        __shared__ smallk_v4 sm[32][8];
+        const int e4 = threadIdx.x & 7, sl = threadIdx.x >> 3;
+        const int64_t i = (int64_t)blockIdx.x * 32 + 4 * e4;
+        smallk_v4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = sl; k < nstripes; k += 32) acc += *reinterpret_cast<const smallk_v4 *>(slabs + (int64_t)k * 4096 + i);
+        sm[sl][e4] = acc;
         __syncthreads();
         if (sl == 0) {
-            float t = sm[0][e];
+            smallk_v4 t = sm[0][e4];
 #pragma unroll
-            for (int q = 1; q < 16; ++q) t += sm[q][e];
-            gram[i] = t;
+            for (int q = 1; q < 32; ++q) t += sm[q][e4];
+            *reinterpret_cast<smallk_v4 *>(gram + i) = t;
         }
     } else {
-        const int e = (blockIdx.x - 256) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int e = (blockIdx.x - SMALLK_GRAM_BLOCKS) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         double s = 0.0;
         for (int c = lane; c < nstripes; c += 64) s += stat_part[(int64_t)c * 128 + e];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);

@@ -30,7 +30,7 @@ template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o,
                 HIP_TRY(hipGetLastError());
             });
             timed("smallk_finish_H", 0.0, (double)stripes_h * (4096 * sizeof(T) + 128 * sizeof(double)), [&] {
-                hipLaunchKernelGGL(smallk_finish_kernel, dim3(256 + 32), dim3(256), 0, stream, gramH_p, smallk_slabs.p, (int)stripes_h, stat_part.p, hstat.p, done);
+                hipLaunchKernelGGL(smallk_finish_kernel, dim3(SMALLK_GRAM_BLOCKS + 32), dim3(256), 0, stream, gramH_p, smallk_slabs.p, (int)stripes_h, stat_part.p, hstat.p, done);
                 HIP_TRY(hipGetLastError());
             });
             hcur ^= 1;
@@ -48,10 +48,10 @@ template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o,
         if (fuse_check && !smallk_ticket.p) smallk_ticket.ensure(1);
         timed("smallk_finish_W", 0.0, (double)stripes_w * (4096 * sizeof(T) + 128 * sizeof(double)), [&] {
             if (fuse_check)
-                hipLaunchKernelGGL(smallk_finish_kernel, dim3(256 + 32), dim3(256), 0, stream, gramW_p, smallk_slabs.p, (int)stripes_w, stat_part.p, wstat.p, done, ctrl,
+                hipLaunchKernelGGL(smallk_finish_kernel, dim3(SMALLK_GRAM_BLOCKS + 32), dim3(256), 0, stream, gramW_p, smallk_slabs.p, (int)stripes_w, stat_part.p, wstat.p, done, ctrl,
                                    o.update_H ? hstat.p : (const double *)nullptr, (int)k, (float)o.tol, t, smallk_ticket.p);
             else
-                hipLaunchKernelGGL(smallk_finish_kernel, dim3(256 + 32), dim3(256), 0, stream, gramW_p, smallk_slabs.p, (int)stripes_w, stat_part.p, wstat.p, done);
+                hipLaunchKernelGGL(smallk_finish_kernel, dim3(SMALLK_GRAM_BLOCKS + 32), dim3(256), 0, stream, gramW_p, smallk_slabs.p, (int)stripes_w, stat_part.p, wstat.p, done);
             HIP_TRY(hipGetLastError());
         });
         check_fused = fuse_check;

@@ -36,6 +36,20 @@ __global__ void reduce_slabs_kernel(T *dst, const T *src, int64_t count, int nsl
     dst[i] = s;
 }
 
+// the same sum, 4 (Float32) / 2 (Float64) consecutive elements per thread as one 16-byte access per slab: a quarter of the load
+// instructions and 1 KB per wave-load (count, stride and the base pointers multiples of the vector: the padded operand sizes are)
+template <typename T>
+__global__ void reduce_slabs_vec_kernel(T *dst, const T *src, int64_t nvec, int nslab, int64_t stride, const int *done) {
+    NMFX_DONE_GUARD(done);
+    constexpr int V = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    vec_t s = *reinterpret_cast<const vec_t *>(src + i * V);
+    for (int k = 1; k < nslab; ++k) s += *reinterpret_cast<const vec_t *>(src + (int64_t)k * stride + i * V);
+    *reinterpret_cast<vec_t *>(dst + i * V) = s;
+}
+
 // Same sum for MANY slabs of a small matrix (the tail pieces of the fused Gram: ~128 slabs of k x k).  A thread per
 // element would chain `nslab` dependent loads; here 4 slab-lanes per element each add every 4th slab with 8 loads in
 // flight, then the 4 partial sums are combined in a fixed order (((l0 + l1) + l2) + l3): deterministic.

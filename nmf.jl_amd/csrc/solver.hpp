@@ -635,6 +635,10 @@ template <typename T> class Solver : public SolverBase {
             if (nslab >= 16)
                 hipLaunchKernelGGL(reduce_many_slabs_kernel<T>, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, stream, dst,
                                    src, count, nslab, stride, done);
+            else if (constexpr int V = 16 / (int)sizeof(T); count % V == 0 && stride % V == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 &&
+                                                        (reinterpret_cast<uintptr_t>(src) & 15) == 0)
+                hipLaunchKernelGGL(reduce_slabs_vec_kernel<T>, dim3((unsigned)((count / V + bs - 1) / bs)), dim3(bs), 0, stream, dst,
+                                   src, count / V, nslab, stride, done);
             else
                 hipLaunchKernelGGL(reduce_slabs_kernel<T>, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, stream, dst,
                                    src, count, nslab, stride, done);

@@ -544,12 +544,16 @@ __global__ void reduce_pieces_kernel(T *dst, int64_t ldd, const T *src, int64_t 
 //   mode 0: dst is flat (count elements), the rectangle is the contiguous range [off, off + plen): piece index e - off
 //   mode 1: dst is ld x cols column-major (ld a multiple of 256), the rectangle is rows [r0, r0 + prow) of every column, pieces
 //           are compact (ld = prow): piece index (i - r0) + a*prow
-template <typename T>
+// V consecutive elements per thread as one access per slab / piece (V = 16 bytes' worth when every offset, length and stride is a
+// multiple of it -- the launch sites check --, else 1)
+template <typename T, int V = 1>
 __global__ __launch_bounds__(256) void reduce_slabs_tail_kernel(T *dst, const T *src, int64_t count, int nslab, int64_t stride, const T *pieces,
                                                                 int npieces, int64_t pstride, int mode, int64_t off, int64_t plen, int64_t ld,
                                                                 int64_t r0, int64_t prow, const int *done) {
     NMFX_DONE_GUARD(done);
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    auto ldv = [](const T *p) { if constexpr (V == 1) return *p; else return *reinterpret_cast<const vec_t *>(p); };
+    int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
     int64_t pidx = -1;
     if (mode == 0) {
         if (e >= count) return;
@@ -557,30 +561,43 @@ __global__ __launch_bounds__(256) void reduce_slabs_tail_kernel(T *dst, const T 
     } else {
         // column index fastest over the blocks: the blocks that carry the pieces (the last row blocks of EVERY column) are then
         // consecutive block ids, i.e. dealt to all 8 XCDs (row index fastest put them all on two XCDs: 48 us instead of 24)
-        const unsigned cols = (unsigned)(count / ld), a = blockIdx.x % cols, i = (blockIdx.x / cols) * 256u + threadIdx.x;
+        const unsigned cols = (unsigned)(count / ld), a = blockIdx.x % cols, i = ((blockIdx.x / cols) * 256u + threadIdx.x) * (unsigned)V;
         e = (int64_t)i + (int64_t)a * ld;
         if ((int64_t)i >= r0 && (int64_t)i < r0 + prow) pidx = ((int64_t)i - r0) + (int64_t)a * prow;
     }
-    T lastv;
+    auto lastv = ldv(src);   // (type only; overwritten below)
     if (pidx >= 0) {
-        T acc = pieces[pidx];
+        auto acc = ldv(pieces + pidx);
         int q = 1;
-        for (; q + 8 <= npieces; q += 8) {
-            T v[8];
+        // the rectangle is a small part of the output, but every element of it is the sum of ~64 pieces: as many bytes as all the
+        // slabs together, read by a few dozen blocks -- 16 loads in flight per thread (summed in piece order all the same)
+        for (; q + 16 <= npieces; q += 16) {
+            decltype(acc) v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = pieces[(int64_t)(q + u) * pstride + pidx];
+            for (int u = 0; u < 16; ++u) v[u] = ldv(pieces + (int64_t)(q + u) * pstride + pidx);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+        for (; q + 8 <= npieces; q += 8) {
+            decltype(acc) v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ldv(pieces + (int64_t)(q + u) * pstride + pidx);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += v[u];
         }
-        for (; q < npieces; ++q) acc += pieces[(int64_t)q * pstride + pidx];
+        for (; q < npieces; ++q) acc += ldv(pieces + (int64_t)q * pstride + pidx);
         lastv = acc;
     } else {
-        lastv = src[(int64_t)(nslab - 1) * stride + e];
+        lastv = ldv(src + (int64_t)(nslab - 1) * stride + e);
     }
-    if (nslab == 1) { dst[e] = lastv; return; }
-    T s = src[e];
-    for (int k = 1; k < nslab - 1; ++k) s += src[(int64_t)k * stride + e];
-    dst[e] = s + lastv;
+    auto out = lastv;
+    if (nslab > 1) {
+        auto s = ldv(src + e);
+        for (int k = 1; k < nslab - 1; ++k) s += ldv(src + (int64_t)k * stride + e);
+        out = s + lastv;
+    }
+    if constexpr (V == 1) dst[e] = out;
+    else *reinterpret_cast<vec_t *>(dst + e) = out;
 }
 
 // ---- multdiv, single GPU: everything that follows a numerator product in ONE pass over the factor (src/multupd.jl:176-179, 188-191

@@ -627,6 +627,9 @@ template <typename T> class Solver : public SolverBase {
         note();
     }
 
+    static bool vec16_ok(const void *a, const void *b, const void *c) {
+        return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+    }
     void reduce_slabs_from(const char *name, T *dst, const T *src, int64_t count, int nslab, const int *done,
                            int64_t stride = -1) {
         if (stride < 0) stride = count;
@@ -815,9 +818,16 @@ template <typename T> class Solver : public SolverBase {
             gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done, (double)(P * N + P * K) * sizeof(T), sg);
             if (!keep_slabs || h_nslab > 2) {   // pieces + slabs in one launch
                 timed("reduce_WtX", 0.0, (double)K * N * (h_nslab + 1) * sizeof(T), [&] {
-                    hipLaunchKernelGGL(reduce_slabs_tail_kernel<T>, dim3((unsigned)((K * N + 255) / 256)), dim3(256), 0, stream, numH_p, reg, (int64_t)K * N,
-                                       h_nslab, h_stride, slabs.p + gram_slab_off, shg.pieces, lines * 128 * K, 0, c0 * K, lines * 128 * K, (int64_t)0,
-                                       (int64_t)0, (int64_t)0, done);
+                    // (every size here is a multiple of 64; the buffers are hipMalloc'ed and offset by multiples of 64 elements)
+                    constexpr int V = 16 / (int)sizeof(T);
+                    if (vec16_ok(numH_p, reg, slabs.p + gram_slab_off))
+                        hipLaunchKernelGGL((reduce_slabs_tail_kernel<T, V>), dim3((unsigned)((K * N / V + 255) / 256)), dim3(256), 0, stream, numH_p, reg, (int64_t)K * N,
+                                           h_nslab, h_stride, slabs.p + gram_slab_off, shg.pieces, lines * 128 * K, 0, c0 * K, lines * 128 * K, (int64_t)0,
+                                           (int64_t)0, (int64_t)0, done);
+                    else
+                        hipLaunchKernelGGL((reduce_slabs_tail_kernel<T, 1>), dim3((unsigned)((K * N + 255) / 256)), dim3(256), 0, stream, numH_p, reg, (int64_t)K * N,
+                                           h_nslab, h_stride, slabs.p + gram_slab_off, shg.pieces, lines * 128 * K, 0, c0 * K, lines * 128 * K, (int64_t)0,
+                                           (int64_t)0, (int64_t)0, done);
                     HIP_TRY(hipGetLastError());
                 });
                 h_in_slabs = false;
@@ -904,8 +914,13 @@ template <typename T> class Solver : public SolverBase {
             gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done, (double)(P * N + K * N) * sizeof(T), sg);
             if (!w_blocked && (!keep_slabs || w_nslab > 2)) {   // pieces + slabs in one launch
                 timed("reduce_XHt", 0.0, (double)P * K * (w_nslab + 1) * sizeof(T), [&] {
-                    hipLaunchKernelGGL(reduce_slabs_tail_kernel<T>, dim3((unsigned)(P / 256 * K)), dim3(256), 0, stream, numW_p, reg, (int64_t)P * K, w_nslab,
-                                       w_stride, slabs.p + gram_slab_off, shg.pieces, rows * K, 1, (int64_t)0, (int64_t)0, P, r0, rows, done);
+                    constexpr int V = 16 / (int)sizeof(T);
+                    if (P % (256 * V) == 0 && vec16_ok(numW_p, reg, slabs.p + gram_slab_off))
+                        hipLaunchKernelGGL((reduce_slabs_tail_kernel<T, V>), dim3((unsigned)(P / (256 * V) * K)), dim3(256), 0, stream, numW_p, reg, (int64_t)P * K, w_nslab,
+                                           w_stride, slabs.p + gram_slab_off, shg.pieces, rows * K, 1, (int64_t)0, (int64_t)0, P, r0, rows, done);
+                    else
+                        hipLaunchKernelGGL((reduce_slabs_tail_kernel<T, 1>), dim3((unsigned)(P / 256 * K)), dim3(256), 0, stream, numW_p, reg, (int64_t)P * K, w_nslab,
+                                           w_stride, slabs.p + gram_slab_off, shg.pieces, rows * K, 1, (int64_t)0, (int64_t)0, P, r0, rows, done);
                     HIP_TRY(hipGetLastError());
                 });
                 w_in_slabs = false;

@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "kernels.hpp"
 
 namespace nmfx {
@@ -152,6 +154,17 @@ __global__ __launch_bounds__(256) void cd_sweep_kernel(SampleView<const T> Wold,
         }
 }
 
+// value of the lane N places to the right inside the 16-lane DPP row (row_ror:N)
+template <int N> __device__ __forceinline__ float row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+template <int N> __device__ __forceinline__ double row_ror(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x120 + N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x120 + N, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // Same sweep, 16 lanes per sample row (4 rows per wavefront): lane l of a row's group holds the KPL = K/16 consecutive
 // components l*KPL .. l*KPL+KPL-1, so a Gram row is fetched with 16-byte loads, the dot product needs only a 4-step
 // butterfly, and the four rows of a wave share every shuffle instruction (the 64-lane form above spends most of its
@@ -198,12 +211,19 @@ __global__ __launch_bounds__(256) void cd_sweep16_kernel(SampleView<const T> Wol
                 T part = (T)0;
 #pragma unroll
                 for (int v = 0; v < KPLMAX; ++v) part += a[v] * w[v];
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 16);
-                const T hess = __shfl(a[s], lt, 16);
-                const T grad = part - __shfl(z[s], lt, 16);
-                const T wt = __shfl(w[s], lt, 16);
-                T nw = wt - grad / hess;
+                // 16-lane all-reduce by DPP row rotations (a DPP row IS a sample row's 16 lanes): the same pairs as the xor butterfly
+                // (rotating by 8, 4, 2, 1 adds partials that are already periodic in 8, 4, 2), i.e. the same bits, without four
+                // ds_bpermute round trips through the LDS crossbar on the dependency chain of every coordinate
+                part += row_ror<8>(part);
+                part += row_ror<4>(part);
+                part += row_ror<2>(part);
+                part += row_ror<1>(part);
+                // only the lane that owns coordinate t keeps the result, and it holds everything the update needs itself:
+                // a[s] = P(t, t), z[s] = Z(i, t) - l1, w[s] = W(i, t).  The other lanes compute garbage that is never stored
+                // (three more broadcasts per coordinate saved).
+                const T hess = a[s];
+                const T grad = part - z[s];
+                T nw = w[s] - grad / hess;
                 nw = (nw > (T)0) ? nw : ((nw != nw) ? nw : (T)0);
                 if (hess != (T)0 && l == lt) w[s] = nw;
             }
@@ -216,15 +236,6 @@ __global__ __launch_bounds__(256) void cd_sweep16_kernel(SampleView<const T> Wol
     }
 }
 
-// ---------------------------------------------------------------------------
-// GreedyCD (src/greedycd.jl:91-163).  Per sample row i (registers: W, G, S, D rows):
-//     S(r) = max(0, W(r) - G(r)/(eps + P(r,r))) - W(r);   D(r) = -G(r) S(r) - 0.5 P(r,r) S(r)^2        (:120-125, :150-153)
-//     q = argmax_r D(r)  (first index on ties, like Julia's argmax)
-// p_init = max over ALL rows of D(i, q_i), floor -1 (:127-132)   -> greedy_pinit_kernel + one tiny reduction
-// then at most k^2 steps per row (:137-158): stop when D(q) < nu * p_init;  Wnew(q) += S(q);  G(r) += S(q) P(q, r);
-// recompute S, D;  q = argmax.   Finally W = max(W + Wnew, 0) (:160-161).
-// G arrives as W*P - Z from the GEMM; + lambda (:113-115) is applied on load.
-// ---------------------------------------------------------------------------
 // g / den, correctly rounded, with den loop-invariant.  Float32: (float)((double)g * (1.0 / den)) IS the correctly rounded quotient --
 // the Float64 product is within 2^-52 of g / den, while a quotient of two 24-bit significands that is not itself a float stays at
 // least 2^-49 (relative) away from every rounding boundary of the float grid (g - m den is a non-zero multiple of the last place
@@ -234,6 +245,146 @@ __global__ __launch_bounds__(256) void cd_sweep16_kernel(SampleView<const T> Wol
 __device__ __forceinline__ float greedy_div(float g, float, double rden) { return (float)((double)g * rden); }
 __device__ __forceinline__ double greedy_div(double g, double den, double) { return g / den; }
 
+// ---------------------------------------------------------------------------
+// Blocked sweep (Float32, big problems).  The sweeps above are one long dependency chain per sample row: every coordinate
+// recomputes its gradient as a K-long dot product with the current row (a Gram row fetched from L2, a 16- or 64-lane reduction,
+// a division), 256 times in a row at k = 256 -- 250 us per side at 16384 rows, 10x what the arithmetic costs.  Here the
+// coordinates are taken 16 at a time.  For a block B of 16 coordinates the part of the gradient that does not change while B is
+// being swept,
+//     G_B = W_tile * P[:, B] - Z_B          (64 sample rows x K) * (K x 16)
+// is ONE matrix-core product per block (v_mfma_f32_16x16x4, 64 instructions per wave), and the sweep inside the block only needs
+// the 16 x 16 diagonal block of P:  w_t <- max(0, w_t - g_t / P_tt),  g_t' += P_t't * (w_t_new - w_t_old) for the other t' of the
+// block -- the same Gauss-Seidel sweep in exact arithmetic (each g_t is the full gradient at the moment coordinate t is updated),
+// a different summation order in floating point.  A workgroup owns 64 sample rows; the tile of W lives in LDS for the whole
+// sweep (updated block by block), four lanes share a sample row in the in-block sweep (4 coordinates each, the step broadcast
+// inside the quad by DPP).  Operand fragments: lane (i, kg) holds 4 consecutive contraction indices, MFMA q of a group of 16
+// contracts indices {q, 4 + q, 8 + q, 12 + q} of the group (any partition is a valid order of the sum), so both operands are
+// 16-byte reads -- W from LDS, P straight from global memory (P is symmetric: column c of the product is row c of P).
+template <int SEL> __device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SEL * 0x55, 0xf, 0xf, false));
+}
+template <int N, typename F, int... I> __device__ __forceinline__ void cd_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void cd_static_for(F &&f) { cd_static_for_impl<N>(static_cast<F &&>(f), std::make_integer_sequence<int, N>{}); }
+
+constexpr int CD_BLK_ROWS = 64, CD_BLK_GS = 20;
+static inline size_t cd_blocked_lds_bytes(int64_t K) { return (size_t)(CD_BLK_ROWS * (K + 4) + CD_BLK_ROWS * CD_BLK_GS + 16 * CD_BLK_GS + 32) * sizeof(float); }
+
+// KJ = K / 16 (compile time: the P fragments of a whole block, KJ 16-byte loads per lane, are requested BEFORE the in-block sweep of
+// the previous block and consumed after it -- with one wave per SIMD nothing else hides their L2 round trips)
+template <int KJ>
+__global__ __launch_bounds__(256) void cd_sweep_blocked_kernel(SampleView<const float> Wold, SampleView<float> Wnew, SampleView<const float> Z,
+                                                               const float *__restrict__ P, int64_t ldp, int64_t nsamples, int k, float l1,
+                                                               const int *done) {
+    NMFX_DONE_GUARD(done);
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float cd_lds[];
+    constexpr int K = 16 * KJ, LDW = K + 4;
+    float *Ws = cd_lds;                            // [64 rows][LDW]   the tile of W, component-contiguous
+    float *Gs = Ws + CD_BLK_ROWS * LDW;            // [64 rows][20]    W_tile * P[:, B]
+    float *Pt = Gs + CD_BLK_ROWS * CD_BLK_GS;      // [16 t][20]       P(c0 + t, c0 + t')
+    double *Pr = reinterpret_cast<double *>(Pt + 16 * CD_BLK_GS);   // [16 t]   1 / P(c0 + t, c0 + t) in Float64 (greedy_div)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kg = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * CD_BLK_ROWS;
+    const bool rows_contig = (Wold.ss == 1);       // W side: consecutive sample rows are consecutive in memory; H side: components are
+    // (every load of the tile in flight at once, KJ*4 per thread: batches of 8 cost one HBM round trip each, ~15 us in all)
+    {
+        constexpr int NL = CD_BLK_ROWS * K / 256;
+        float v[NL];
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int idx = tid + 256 * q;
+            const int r = rows_contig ? (idx & 63) : (idx / K), c = rows_contig ? (idx >> 6) : (idx - (idx / K) * K);
+            v[q] = (i0 + r < nsamples && c < k) ? Wold.at(i0 + r, c) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int idx = tid + 256 * q;
+            const int r = rows_contig ? (idx & 63) : (idx / K), c = rows_contig ? (idx >> 6) : (idx - (idx / K) * K);
+            Ws[r * LDW + c] = v[q];
+        }
+    }
+    __syncthreads();
+    const int rr = tid >> 2, part = tid & 3;       // in-block sweep: sample row rr, coordinates 4 part .. 4 part + 3 of the block
+    const bool live = i0 + rr < nsamples;
+    v4 bf[KJ];
+    auto load_p = [&](int c0) {
+        const float *prow = P + (int64_t)(c0 + i) * ldp + 4 * kg;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) bf[j] = *reinterpret_cast<const v4 *>(prow + 16 * j);
+    };
+    load_p(0);
+    // this row's Z and the diagonal block of P are requested ONE BLOCK AHEAD (Z comes from HBM: its round trip is longer than a product)
+    v4 z4n;
+    float pdn;
+    auto load_zd = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) z4n[u] = (live && c0 + 4 * part + u < k) ? Z.at(i0 + rr, c0 + 4 * part + u) : 0.f;
+        pdn = P[(int64_t)(c0 + (tid >> 4)) * ldp + c0 + (tid & 15)];
+    };
+    load_zd(0);
+    for (int c0 = 0; c0 < k; c0 += 16) {
+        v4 z4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) z4[u] = (live && c0 + 4 * part + u < k) ? (z4n[u] - l1) : 0.f;
+        const float pdiag = pdn;
+        if (c0 + 16 < k) load_zd(c0 + 16);
+        // G_B tile of this wave: rows 16 wave .. + 15
+        v4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        const float *arow = Ws + (16 * wave + i) * LDW + 4 * kg;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            const v4 a = *reinterpret_cast<const v4 *>(arow + 16 * j), b = bf[j];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc2, 0, 0, 0);
+        }
+        if (c0 + 16 < k) load_p(c0 + 16);      // lands during the in-block sweep below
+        acc += acc2;
+        // lane (n = i, mg = kg) holds rows 16 wave + 4 mg + {0..3} of column n
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gs[(16 * wave + 4 * kg + r) * CD_BLK_GS + i] = acc[r];
+        Pt[(tid >> 4) * CD_BLK_GS + (tid & 15)] = pdiag;
+        if ((tid >> 4) == (tid & 15)) Pr[tid & 15] = 1.0 / (double)pdiag;
+        __syncthreads();
+        v4 g4 = *reinterpret_cast<const v4 *>(Gs + rr * CD_BLK_GS + 4 * part) - z4;
+        v4 w4 = *reinterpret_cast<const v4 *>(Ws + rr * LDW + c0 + 4 * part);
+        cd_static_for<16>([&](auto TC) {
+            constexpr int t = decltype(TC)::value, owner = t >> 2, u = t & 3;
+            const v4 pv = *reinterpret_cast<const v4 *>(Pt + t * CD_BLK_GS + 4 * part);     // P(c0 + t, c0 + 4 part + {0..3})
+            const float hess = Pt[t * CD_BLK_GS + t];
+            const float wt = w4[u];
+            float nw = wt - greedy_div(g4[u], hess, Pr[t]);                                    // = g / hess, correctly rounded (only the owner's value is used)
+            nw = (nw > 0.f) ? nw : ((nw != nw) ? nw : 0.f);                                    // max(., zero(grad)); NaN propagates
+            nw = (hess != 0.f) ? nw : wt;
+            const float delta = quad_bcast<owner>(nw - wt);
+            if (part == owner) w4[u] = nw;
+            // four scalar FMAs, not `g4 += pv * delta`: the vector form compiles to v_pk_mul_f32 with delta in a register PAIR whose
+            // other half the allocator gave to a prefetch still in flight -- s_waitcnt vmcnt(0) in front of the first step, i.e. the
+            // next block's P fragments and Z waited for at once (+2 us per block)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g4[e] = __builtin_fmaf(pv[e], delta, g4[e]);
+        });
+        *reinterpret_cast<v4 *>(Ws + rr * LDW + c0 + 4 * part) = w4;
+        __syncthreads();
+    }
+    for (int idx = tid; idx < CD_BLK_ROWS * K; idx += 256) {
+        const int r = rows_contig ? (idx & 63) : (idx / K), c = rows_contig ? (idx >> 6) : (idx - (idx / K) * K);
+        if (i0 + r < nsamples && c < k) Wnew.at(i0 + r, c) = Ws[r * LDW + c];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GreedyCD (src/greedycd.jl:91-163).  Per sample row i (registers: W, G, S, D rows):
+//     S(r) = max(0, W(r) - G(r)/(eps + P(r,r))) - W(r);   D(r) = -G(r) S(r) - 0.5 P(r,r) S(r)^2        (:120-125, :150-153)
+//     q = argmax_r D(r)  (first index on ties, like Julia's argmax)
+// p_init = max over ALL rows of D(i, q_i), floor -1 (:127-132)   -> greedy_pinit_kernel + one tiny reduction
+// then at most k^2 steps per row (:137-158): stop when D(q) < nu * p_init;  Wnew(q) += S(q);  G(r) += S(q) P(q, r);
+// recompute S, D;  q = argmax.   Finally W = max(W + Wnew, 0) (:160-161).
+// G arrives as W*P - Z from the GEMM; + lambda (:113-115) is applied on load.
+// ---------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void greedy_sd(T w, T g, T prr, T den, double rden, T &s, T &d) {
     T t = op_sub(w, greedy_div(g, den, rden));
     t = (t <= (T)0) ? (T)0 : t;   // max(zero(T), t): a NaN fails the comparison and passes through like Julia's max (one compare instead of two)

@@ -38,6 +38,29 @@ void Solver<T>::cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<co
             hipLaunchKernelGGL((cd_sweep_lds_kernel<T>), dim3((unsigned)nsamples), dim3(64), lds, stream, Zo, Zn, Num, Pm, K, nsamples, (int)k, l1, done);
         return;
     }
+    if constexpr (sizeof(T) == 4) {
+        // the blocked sweep (matrix-core gradient per 16 coordinates, cd.hpp) wherever its tile of W fits LDS: k <= 512.  Its run time is
+        // that of ONE workgroup's 64 rows whatever the number of workgroups (<= one per CU), so it also wins on small problems
+        // (measured, ms per iteration old -> new: 1024^2 k=64 0.131 -> 0.109; 4096^2 k=256 0.469 -> 0.342; 8192 x 2048 k=512
+        // 1.755 -> 0.800; 16384^2 k=256 2.611 -> 2.237).  NMFX_CD_BLOCKED=0 keeps the row-chain kernels.
+        const size_t lds = cd_blocked_lds_bytes(K);
+        const bool shape = (K == 64 || K == 128 || K == 256 || K == 384 || K == 512);
+        if (shape && lds <= 160 * 1024 && cd_blocked != 0) {
+            auto launch = [&](auto KJC) {
+                constexpr int KJ = decltype(KJC)::value;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&cd_sweep_blocked_kernel<KJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (nsamples > 0)
+                    hipLaunchKernelGGL(cd_sweep_blocked_kernel<KJ>, dim3((unsigned)((nsamples + CD_BLK_ROWS - 1) / CD_BLK_ROWS)), dim3(256), lds, stream, Zo, Zn, Num, Pm, K,
+                                       nsamples, (int)k, l1, done);
+            };
+            if (K == 64) launch(std::integral_constant<int, 4>{});
+            else if (K == 128) launch(std::integral_constant<int, 8>{});
+            else if (K == 256) launch(std::integral_constant<int, 16>{});
+            else if (K == 384) launch(std::integral_constant<int, 24>{});
+            else launch(std::integral_constant<int, 32>{});
+            return;
+        }
+    }
     const int kpl = (int)(K / 16);                       // K is 64 or a multiple of 128: kpl is a multiple of 4
     const int reg_budget = (sizeof(T) == 4) ? 32 : 16;   // components per lane kept in registers (w, z, a: 3 arrays)
     if (kpl <= reg_budget) {

@@ -131,6 +131,7 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = std::getenv("NMFX_CHOL_SLOTS")) chol_slots = std::max(0, std::min(128, std::atoi(e)));
         if (const char *e = std::getenv("NMFX_FORCE_SHARDED")) force_sharded = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_CD_LDS")) cd_force_lds = std::atoi(e) != 0;
+        if (const char *e = std::getenv("NMFX_CD_BLOCKED")) cd_blocked = std::atoi(e) != 0 ? 1 : 0;
         if (const char *e = std::getenv("NMFX_RS_FUSED")) rs_fused_enabled = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_STREAM_WH")) stream_wh = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
@@ -1032,6 +1033,7 @@ template <typename T> class Solver : public SolverBase {
     template <typename F> void with_kmax(F &&f);
     bool cd_use_lds() const;
     bool cd_force_lds = false;   // NMFX_CD_LDS=1: the LDS forms of the sweeps also for k <= 1024 (tests: bit-identical to the register forms)
+    int cd_blocked = -1;                 // NMFX_CD_BLOCKED=0: CoordinateDescent on the row-chain sweep kernels instead of the blocked one (Float32, k <= 512)
     void prepare_cd_permutations(const nmfx_opts &o);
     const int *cd_permutation_window(const nmfx_opts &o, long long t);
     static constexpr long long CD_PERM_WINDOW = 256;

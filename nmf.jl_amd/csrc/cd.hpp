@@ -263,115 +263,154 @@ __device__ __forceinline__ double greedy_div(double g, double den, double) { ret
 template <int SEL> __device__ __forceinline__ float quad_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SEL * 0x55, 0xf, 0xf, false));
 }
+template <typename T> struct Mfma16;
+template <> struct Mfma16<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+};
 template <int N, typename F, int... I> __device__ __forceinline__ void cd_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
 }
 template <int N, typename F> __device__ __forceinline__ void cd_static_for(F &&f) { cd_static_for_impl<N>(static_cast<F &&>(f), std::make_integer_sequence<int, N>{}); }
 
-constexpr int CD_BLK_ROWS = 64, CD_BLK_GS = 20;
-static inline size_t cd_blocked_lds_bytes(int64_t K) { return (size_t)(CD_BLK_ROWS * (K + 4) + CD_BLK_ROWS * CD_BLK_GS + 16 * CD_BLK_GS + 32) * sizeof(float); }
+constexpr int CD_BLK_GS = 20;
+// ROWS sample rows per workgroup (64: Float32; Float64: 64 up to k = 256, 32 beyond -- the tile of W must fit LDS), 4 lanes per row
+template <typename T> static inline size_t cd_blocked_lds_bytes(int64_t K, int rows) {
+    return (size_t)(rows * (K + 16 / sizeof(T)) + rows * CD_BLK_GS + 16 * CD_BLK_GS) * sizeof(T) + 16 * sizeof(double);
+}
+template <int SEL> __device__ __forceinline__ double quad_bcast(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), SEL * 0x55, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), SEL * 0x55, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float cd_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double cd_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// KJ = K / 16 (compile time: the P fragments of a whole block, KJ 16-byte loads per lane, are requested BEFORE the in-block sweep of
-// the previous block and consumed after it -- with one wave per SIMD nothing else hides their L2 round trips)
-template <int KJ>
-__global__ __launch_bounds__(256) void cd_sweep_blocked_kernel(SampleView<const float> Wold, SampleView<float> Wnew, SampleView<const float> Z,
-                                                               const float *__restrict__ P, int64_t ldp, int64_t nsamples, int k, float l1,
-                                                               const int *done) {
+// KG = K / (4 VEC) groups of contraction indices, VEC = 16 bytes' worth of T (compile time: the P fragments of a whole block, KG
+// 16-byte loads per lane, are requested BEFORE the in-block sweep of the previous block and consumed after it -- with one wave per
+// SIMD nothing else hides their L2 round trips).  Lane (i, kg) holds VEC consecutive indices of a group; MFMA q contracts indices
+// {q, VEC + q, 2 VEC + q, 3 VEC + q} of the group.
+template <typename T, int KG, int ROWS>
+__global__ __launch_bounds__(ROWS * 4) void cd_sweep_blocked_kernel(SampleView<const T> Wold, SampleView<T> Wnew, SampleView<const T> Z,
+                                                                    const T *__restrict__ P, int64_t ldp, int64_t nsamples, int k, T l1,
+                                                                    const int *done) {
     NMFX_DONE_GUARD(done);
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) float cd_lds[];
-    constexpr int K = 16 * KJ, LDW = K + 4;
-    float *Ws = cd_lds;                            // [64 rows][LDW]   the tile of W, component-contiguous
-    float *Gs = Ws + CD_BLK_ROWS * LDW;            // [64 rows][20]    W_tile * P[:, B]
-    float *Pt = Gs + CD_BLK_ROWS * CD_BLK_GS;      // [16 t][20]       P(c0 + t, c0 + t')
-    double *Pr = reinterpret_cast<double *>(Pt + 16 * CD_BLK_GS);   // [16 t]   1 / P(c0 + t, c0 + t) in Float64 (greedy_div)
+    constexpr int VEC = 16 / sizeof(T), GR = 4 * VEC, K = GR * KG, LDW = K + VEC, NT = ROWS * 4;
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    typedef T acc_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char cd_lds_raw[];
+    T *Ws = reinterpret_cast<T *>(cd_lds_raw);     // [ROWS][LDW]      the tile of W, component-contiguous
+    T *Gs = Ws + ROWS * LDW;                       // [ROWS][20]       W_tile * P[:, B]
+    T *Pt = Gs + ROWS * CD_BLK_GS;                 // [16 t][20]       P(c0 + t, c0 + t')
+    double *Pr = reinterpret_cast<double *>(Pt + 16 * CD_BLK_GS);   // [16 t]   1 / P(c0 + t, c0 + t) in Float64 (greedy_div, Float32 only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kg = lane >> 4;
-    const int64_t i0 = (int64_t)blockIdx.x * CD_BLK_ROWS;
+    const int64_t i0 = (int64_t)blockIdx.x * ROWS;
     const bool rows_contig = (Wold.ss == 1);       // W side: consecutive sample rows are consecutive in memory; H side: components are
-    // (every load of the tile in flight at once, KJ*4 per thread: batches of 8 cost one HBM round trip each, ~15 us in all)
+    // (every load of the tile in flight at once: batches of 8 cost one HBM round trip each, ~15 us in all)
     {
-        constexpr int NL = CD_BLK_ROWS * K / 256;
-        float v[NL];
+        constexpr int NL = ROWS * K / NT;
+        T v[NL];
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
-            const int idx = tid + 256 * q;
-            const int r = rows_contig ? (idx & 63) : (idx / K), c = rows_contig ? (idx >> 6) : (idx - (idx / K) * K);
-            v[q] = (i0 + r < nsamples && c < k) ? Wold.at(i0 + r, c) : 0.f;
+            const int idx = tid + NT * q;
+            const int r = rows_contig ? (idx % ROWS) : (idx / K), c = rows_contig ? (idx / ROWS) : (idx - (idx / K) * K);
+            v[q] = (i0 + r < nsamples && c < k) ? Wold.at(i0 + r, c) : (T)0;
         }
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
-            const int idx = tid + 256 * q;
-            const int r = rows_contig ? (idx & 63) : (idx / K), c = rows_contig ? (idx >> 6) : (idx - (idx / K) * K);
+            const int idx = tid + NT * q;
+            const int r = rows_contig ? (idx % ROWS) : (idx / K), c = rows_contig ? (idx / ROWS) : (idx - (idx / K) * K);
             Ws[r * LDW + c] = v[q];
         }
     }
     __syncthreads();
     const int rr = tid >> 2, part = tid & 3;       // in-block sweep: sample row rr, coordinates 4 part .. 4 part + 3 of the block
     const bool live = i0 + rr < nsamples;
-    v4 bf[KJ];
+    vec_t bf[KG];
     auto load_p = [&](int c0) {
-        const float *prow = P + (int64_t)(c0 + i) * ldp + 4 * kg;
+        const T *prow = P + (int64_t)(c0 + i) * ldp + VEC * kg;
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) bf[j] = *reinterpret_cast<const v4 *>(prow + 16 * j);
+        for (int j = 0; j < KG; ++j) bf[j] = *reinterpret_cast<const vec_t *>(prow + GR * j);
     };
     load_p(0);
     // this row's Z and the diagonal block of P are requested ONE BLOCK AHEAD (Z comes from HBM: its round trip is longer than a product)
-    v4 z4n;
-    float pdn;
+    constexpr int ND = 256 / NT;                   // elements of the 16 x 16 diagonal block per thread (1, or 2 with 32-row tiles)
+    T z4n[4];
+    T pdn[ND];
     auto load_zd = [&](int c0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) z4n[u] = (live && c0 + 4 * part + u < k) ? Z.at(i0 + rr, c0 + 4 * part + u) : 0.f;
-        pdn = P[(int64_t)(c0 + (tid >> 4)) * ldp + c0 + (tid & 15)];
+        for (int u = 0; u < 4; ++u) z4n[u] = (live && c0 + 4 * part + u < k) ? Z.at(i0 + rr, c0 + 4 * part + u) : (T)0;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const int e = tid + NT * d;
+            pdn[d] = P[(int64_t)(c0 + (e >> 4)) * ldp + c0 + (e & 15)];
+        }
     };
     load_zd(0);
     for (int c0 = 0; c0 < k; c0 += 16) {
-        v4 z4;
+        T z4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) z4[u] = (live && c0 + 4 * part + u < k) ? (z4n[u] - l1) : 0.f;
-        const float pdiag = pdn;
+        for (int u = 0; u < 4; ++u) z4[u] = (live && c0 + 4 * part + u < k) ? (T)(z4n[u] - l1) : (T)0;
+        T pdiag[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) pdiag[d] = pdn[d];
         if (c0 + 16 < k) load_zd(c0 + 16);
         // G_B tile of this wave: rows 16 wave .. + 15
-        v4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        const float *arow = Ws + (16 * wave + i) * LDW + 4 * kg;
+        acc_t acc = {(T)0, (T)0, (T)0, (T)0}, acc2 = {(T)0, (T)0, (T)0, (T)0};
+        const T *arow = Ws + (16 * wave + i) * LDW + VEC * kg;
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) {
-            const v4 a = *reinterpret_cast<const v4 *>(arow + 16 * j), b = bf[j];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc2, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc2, 0, 0, 0);
+        for (int j = 0; j < KG; ++j) {
+            const vec_t a = *reinterpret_cast<const vec_t *>(arow + GR * j), b = bf[j];
+#pragma unroll
+            for (int q = 0; q < VEC; q += 2) {
+                acc = Mfma16<T>::mma(a[q], b[q], acc);
+                acc2 = Mfma16<T>::mma(a[q + 1], b[q + 1], acc2);
+            }
         }
         if (c0 + 16 < k) load_p(c0 + 16);      // lands during the in-block sweep below
         acc += acc2;
-        // lane (n = i, mg = kg) holds rows 16 wave + 4 mg + {0..3} of column n
+        // D layout: Float32 lane (n = i, mg = kg) holds rows 4 mg + r of column n; Float64 rows mg + 4 r
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Gs[(16 * wave + 4 * kg + r) * CD_BLK_GS + i] = acc[r];
-        Pt[(tid >> 4) * CD_BLK_GS + (tid & 15)] = pdiag;
-        if ((tid >> 4) == (tid & 15)) Pr[tid & 15] = 1.0 / (double)pdiag;
+        for (int r = 0; r < 4; ++r) Gs[(16 * wave + ((sizeof(T) == 4) ? 4 * kg + r : kg + 4 * r)) * CD_BLK_GS + i] = acc[r];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const int e = tid + NT * d;
+            Pt[(e >> 4) * CD_BLK_GS + (e & 15)] = pdiag[d];
+            if (sizeof(T) == 4 && (e >> 4) == (e & 15)) Pr[e & 15] = 1.0 / (double)pdiag[d];
+        }
         __syncthreads();
-        v4 g4 = *reinterpret_cast<const v4 *>(Gs + rr * CD_BLK_GS + 4 * part) - z4;
-        v4 w4 = *reinterpret_cast<const v4 *>(Ws + rr * LDW + c0 + 4 * part);
+        T g4[4], w4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            g4[u] = Gs[rr * CD_BLK_GS + 4 * part + u] - z4[u];
+            w4[u] = Ws[rr * LDW + c0 + 4 * part + u];
+        }
         cd_static_for<16>([&](auto TC) {
             constexpr int t = decltype(TC)::value, owner = t >> 2, u = t & 3;
-            const v4 pv = *reinterpret_cast<const v4 *>(Pt + t * CD_BLK_GS + 4 * part);     // P(c0 + t, c0 + 4 part + {0..3})
-            const float hess = Pt[t * CD_BLK_GS + t];
-            const float wt = w4[u];
-            float nw = wt - greedy_div(g4[u], hess, Pr[t]);                                    // = g / hess, correctly rounded (only the owner's value is used)
-            nw = (nw > 0.f) ? nw : ((nw != nw) ? nw : 0.f);                                    // max(., zero(grad)); NaN propagates
-            nw = (hess != 0.f) ? nw : wt;
-            const float delta = quad_bcast<owner>(nw - wt);
+            const T hess = Pt[t * CD_BLK_GS + t];
+            const T wt = w4[u];
+            T nw = wt - greedy_div(g4[u], hess, Pr[t]);                                        // = g / hess, correctly rounded (only the owner's value is used)
+            nw = (nw > (T)0) ? nw : ((nw != nw) ? nw : (T)0);                                  // max(., zero(grad)); NaN propagates
+            nw = (hess != (T)0) ? nw : wt;
+            const T delta = quad_bcast<owner>((T)(nw - wt));
             if (part == owner) w4[u] = nw;
-            // four scalar FMAs, not `g4 += pv * delta`: the vector form compiles to v_pk_mul_f32 with delta in a register PAIR whose
+            // four scalar FMAs, not a vector `g4 += pv * delta`: that compiles to v_pk_mul_f32 with delta in a register PAIR whose
             // other half the allocator gave to a prefetch still in flight -- s_waitcnt vmcnt(0) in front of the first step, i.e. the
             // next block's P fragments and Z waited for at once (+2 us per block)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g4[e] = __builtin_fmaf(pv[e], delta, g4[e]);
+            for (int e = 0; e < 4; ++e) g4[e] = cd_fma(Pt[t * CD_BLK_GS + 4 * part + e], delta, g4[e]);   // P(c0 + t, c0 + 4 part + e)
         });
-        *reinterpret_cast<v4 *>(Ws + rr * LDW + c0 + 4 * part) = w4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Ws[rr * LDW + c0 + 4 * part + u] = w4[u];
         __syncthreads();
     }
-    for (int idx = tid; idx < CD_BLK_ROWS * K; idx += 256) {
-        const int r = rows_contig ? (idx & 63) : (idx / K), c = rows_contig ? (idx >> 6) : (idx - (idx / K) * K);
+    for (int idx = tid; idx < ROWS * K; idx += NT) {
+        const int r = rows_contig ? (idx % ROWS) : (idx / K), c = rows_contig ? (idx / ROWS) : (idx - (idx / K) * K);
         if (i0 + r < nsamples && c < k) Wnew.at(i0 + r, c) = Ws[r * LDW + c];
     }
 }

@@ -38,26 +38,34 @@ void Solver<T>::cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<co
             hipLaunchKernelGGL((cd_sweep_lds_kernel<T>), dim3((unsigned)nsamples), dim3(64), lds, stream, Zo, Zn, Num, Pm, K, nsamples, (int)k, l1, done);
         return;
     }
-    if constexpr (sizeof(T) == 4) {
+    {
         // the blocked sweep (matrix-core gradient per 16 coordinates, cd.hpp) wherever its tile of W fits LDS: k <= 512.  Its run time is
-        // that of ONE workgroup's 64 rows whatever the number of workgroups (<= one per CU), so it also wins on small problems
-        // (measured, ms per iteration old -> new: 1024^2 k=64 0.131 -> 0.109; 4096^2 k=256 0.469 -> 0.342; 8192 x 2048 k=512
+        // that of ONE workgroup's rows whatever the number of workgroups (<= one per CU), so it also wins on small problems
+        // (measured in Float32, ms per iteration old -> new: 1024^2 k=64 0.131 -> 0.109; 4096^2 k=256 0.469 -> 0.342; 8192 x 2048 k=512
         // 1.755 -> 0.800; 16384^2 k=256 2.611 -> 2.237).  NMFX_CD_BLOCKED=0 keeps the row-chain kernels.
-        const size_t lds = cd_blocked_lds_bytes(K);
         const bool shape = (K == 64 || K == 128 || K == 256 || K == 384 || K == 512);
-        if (shape && lds <= 160 * 1024 && cd_blocked != 0) {
-            auto launch = [&](auto KJC) {
-                constexpr int KJ = decltype(KJC)::value;
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&cd_sweep_blocked_kernel<KJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (shape && cd_blocked != 0) {
+            auto launch = [&](auto KGC, auto ROWSC) {
+                constexpr int KG = decltype(KGC)::value, ROWS = decltype(ROWSC)::value;
+                const size_t lds = cd_blocked_lds_bytes<T>(K, ROWS);
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&cd_sweep_blocked_kernel<T, KG, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 if (nsamples > 0)
-                    hipLaunchKernelGGL(cd_sweep_blocked_kernel<KJ>, dim3((unsigned)((nsamples + CD_BLK_ROWS - 1) / CD_BLK_ROWS)), dim3(256), lds, stream, Zo, Zn, Num, Pm, K,
-                                       nsamples, (int)k, l1, done);
+                    hipLaunchKernelGGL((cd_sweep_blocked_kernel<T, KG, ROWS>), dim3((unsigned)((nsamples + ROWS - 1) / ROWS)), dim3(ROWS * 4), lds, stream, Zo, Zn, Num, Pm,
+                                       K, nsamples, (int)k, l1, done);
             };
-            if (K == 64) launch(std::integral_constant<int, 4>{});
-            else if (K == 128) launch(std::integral_constant<int, 8>{});
-            else if (K == 256) launch(std::integral_constant<int, 16>{});
-            else if (K == 384) launch(std::integral_constant<int, 24>{});
-            else launch(std::integral_constant<int, 32>{});
+            constexpr int GR = 64 / (int)sizeof(T);      // contraction indices per fragment group: 16 (Float32) / 8 (Float64)
+            using R64 = std::integral_constant<int, 64>;
+            using R32 = std::integral_constant<int, 32>;
+            if (K == 64) launch(std::integral_constant<int, 64 / GR>{}, R64{});
+            else if (K == 128) launch(std::integral_constant<int, 128 / GR>{}, R64{});
+            else if (K == 256) launch(std::integral_constant<int, 256 / GR>{}, R64{});
+            else if constexpr (sizeof(T) == 4) {
+                if (K == 384) launch(std::integral_constant<int, 384 / GR>{}, R64{});
+                else launch(std::integral_constant<int, 512 / GR>{}, R64{});
+            } else {                                      // Float64: 64 rows x 384 (512) components no longer fit 160 KiB
+                if (K == 384) launch(std::integral_constant<int, 384 / GR>{}, R32{});
+                else launch(std::integral_constant<int, 512 / GR>{}, R32{});
+            }
             return;
         }
     }

@@ -1033,7 +1033,7 @@ template <typename T> class Solver : public SolverBase {
     template <typename F> void with_kmax(F &&f);
     bool cd_use_lds() const;
     bool cd_force_lds = false;   // NMFX_CD_LDS=1: the LDS forms of the sweeps also for k <= 1024 (tests: bit-identical to the register forms)
-    int cd_blocked = -1;                 // NMFX_CD_BLOCKED=0: CoordinateDescent on the row-chain sweep kernels instead of the blocked one (Float32, k <= 512)
+    int cd_blocked = -1;                 // NMFX_CD_BLOCKED=0: CoordinateDescent on the row-chain sweep kernels instead of the blocked one (k <= 512)
     void prepare_cd_permutations(const nmfx_opts &o);
     const int *cd_permutation_window(const nmfx_opts &o, long long t);
     static constexpr long long CD_PERM_WINDOW = 256;

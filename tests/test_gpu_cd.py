@@ -226,14 +226,14 @@ def test_lds_forms_of_the_sweeps_are_bit_identical(built, T, alg, shape):
 
 @pytest.mark.parametrize("shape", [(90, 120, 5), (200, 130, 64), (300, 260, 70), (240, 200, 130), (400, 450, 300), (600, 700, 500)])   # k < min(p, n): a rank-deficient Gram makes the f32 sweep chaotic on the CPU too
 @pytest.mark.parametrize("variant", ["plain", "l1", "w_only", "shuffle"])
-def test_cd_blocked_sweep_matches_the_row_chain_sweep(built, shape, variant, monkeypatch):
-    """Float32 CoordinateDescent with k <= 512 sweeps 16 coordinates at a time: the gradient of the block from one matrix-core product
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_cd_blocked_sweep_matches_the_row_chain_sweep(built, T, shape, variant, monkeypatch):
+    """CoordinateDescent with k <= 512 sweeps 16 coordinates at a time (Float64 beyond k = 256: 32-row tiles): the gradient of the block from one matrix-core product
     per 64 sample rows, the sweep inside the block on the 16 x 16 diagonal block of the Gram (cd.hpp: cd_sweep_blocked_kernel) -- the
     same Gauss-Seidel sweep in exact arithmetic, another summation order.  Against the row-chain kernels (NMFX_CD_BLOCKED=0) and
     against the CPU oracle: objective trajectories to the f32 tolerance of this file, factors to rounding; padded components
     (k not a multiple of 16 / of the padded width 64, 128, 256, 384, 512) stay inert."""
     p, n, k = shape
-    T = np.float32
     X, W0, H0 = uniform(p, n, k, T, seed=11 + k)
     kw = dict(maxiter=4, tol=1e-30)
     if variant == "l1":
@@ -253,7 +253,8 @@ def test_cd_blocked_sweep_matches_the_row_chain_sweep(built, shape, variant, mon
     (rb, Wb, Hb), (rc, Wc, Hc) = out["1"], out["0"]
     assert rb.niters == rc.niters == 4
     assert rel_trace_err(rb.trace, rc.trace) < TOL[T]
-    assert np.max(np.abs(Wb - Wc)) <= 2e-3 * max(1.0, np.max(np.abs(Wc))) and np.max(np.abs(Hb - Hc)) <= 2e-3 * max(1.0, np.max(np.abs(Hc)))
+    ftol = 2e-3 if T == np.float32 else 1e-8
+    assert np.max(np.abs(Wb - Wc)) <= ftol * max(1.0, np.max(np.abs(Wc))) and np.max(np.abs(Hb - Hc)) <= ftol * max(1.0, np.max(np.abs(Hc)))
     assert np.all(Wb >= 0) and np.all(Hb >= 0)
     if variant == "w_only":
         assert np.array_equal(Hb, H0)

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X
         if (tid < 256) h0 = *reinterpret_cast<const smallk_v4 *>(Ho + (c0 + (tid >> 4)) * 64 + 4 * (tid & 15));
         lstore(0, 0);
         gload(0, ST);
-        if (T > 2) gload(1, 2 * ST);
+        gload(1, (int64_t)((T > 2) ? 2 : T - 1) * ST);      // (unconditional: see the step below)
         *reinterpret_cast<smallk_v4 *>(Gs + a * 80 + 4 * c4) = g0;
         *reinterpret_cast<smallk_v4 *>(Gs + (a + 32) * 80 + 4 * c4) = g1;
         if (tid < 256) *reinterpret_cast<smallk_v4 *>(Hs + (tid >> 4) * 68 + 4 * (tid & 15)) = h0;
@@ -149,25 +149,43 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X
     auto step = [&](int t, auto SET) {
         constexpr int set = decltype(SET)::value;      // = t & 1: stage t+1 waits in register set t & 1
         const int buf = t & 1;
-        const float *wa = Wc + buf * 64 * LD + (16 * w + i) * LD + (ST / 2) * half + kg;
-        const float *xb = Xc + buf * 16 * LD + i * LD + (ST / 2) * half + kg;
+        // Both operands are contraction-contiguous in LDS: ONE ds_read_b128 per operand feeds four MFMAs -- lane (i, kg) holds rows
+        // 16 j + 4 kg + {0..3} of its line, MFMA m of group j contracts rows 16 j + {m, 4 + m, 8 + m, 12 + m} (any partition of the
+        // rows into fours is a valid order of the sum).  ALL fragments of the stage are requested before the first MFMA: written as
+        // `acc = mfma(wa[..], xb[..], acc)` in a loop the compiler issued each pair of reads behind the previous pair's MFMAs and waited
+        // lgkmcnt(0) in front of every pair -- an LDS round trip exposed 8 times per stage (MFMA pipe 48 % busy).
+        const float *wa = Wc + buf * 64 * LD + (16 * w + i) * LD + (ST / 2) * half + 4 * kg;
+        const float *xb = Xc + buf * 16 * LD + i * LD + (ST / 2) * half + 4 * kg;
+        constexpr int NJ = ST / 32;
+        smallk_v4 fa[NJ], fb[NJ];
+        if constexpr (PROBE != 4) {
 #pragma unroll
-        for (int m = 0; m < ST / 8; m += 2) {
+            for (int j = 0; j < NJ; ++j) {
+                fa[j] = *reinterpret_cast<const smallk_v4 *>(wa + 16 * j);
+                fb[j] = *reinterpret_cast<const smallk_v4 *>(xb + 16 * j);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
             if constexpr (PROBE == 2) {
-                acc0[0] += wa[4 * m] * xb[4 * m];
-                acc1[0] += wa[4 * m + 4] * xb[4 * m + 4];
+                acc0 += fa[j] * fb[j];
             } else if constexpr (PROBE == 4) {
                 acc0 = smallk_mfma(acc1[1], acc1[2], acc0);
                 acc1 = smallk_mfma(acc0[1], acc0[2], acc1);
+                acc0 = smallk_mfma(acc1[0], acc1[3], acc0);
+                acc1 = smallk_mfma(acc0[0], acc0[3], acc1);
             } else {
-                acc0 = smallk_mfma(wa[4 * m], xb[4 * m], acc0);
-                acc1 = smallk_mfma(wa[4 * m + 4], xb[4 * m + 4], acc1);
+                acc0 = smallk_mfma(fa[j][0], fb[j][0], acc0);
+                acc1 = smallk_mfma(fa[j][1], fb[j][1], acc1);
+                acc0 = smallk_mfma(fa[j][2], fb[j][2], acc0);
+                acc1 = smallk_mfma(fa[j][3], fb[j][3], acc1);
             }
         }
-        if constexpr (PROBE < 3)
-            if (t + 1 < T) lstore(set, buf ^ 1);
-        if constexpr (PROBE == 0 || PROBE == 2)
-            if (t + 3 < T) gload(set, (int64_t)(t + 3) * ST);
+        // Staging is UNCONDITIONAL (the last steps re-load the final stage and store into a buffer nobody reads): with `if (t + 3 < T)`
+        // around the loads the compiler could not count them at the store below and waited vmcnt(0) there -- for the loads issued one
+        // step ago as well as for the ones it needs, i.e. the two-stages-ahead prefetch was one stage deep.
+        if constexpr (PROBE < 3) lstore(set, buf ^ 1);
+        if constexpr (PROBE == 0 || PROBE == 2) gload(set, (int64_t)((t + 3 < T) ? t + 3 : T - 1) * ST);
         __syncthreads();
     };
     for (int t = 0; t < T; t += 2) {
@@ -272,7 +290,7 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X
         if (tid < 256) w0 = *reinterpret_cast<const smallk_v4 *>(Wo + r0 + 4 * (tid & 3) + (int64_t)(tid >> 2) * ldx);
         lstore(0, 0);
         gload(0, ST);
-        if (T > 2) gload(1, 2 * ST);
+        gload(1, (int64_t)((T > 2) ? 2 : T - 1) * ST);      // (unconditional: see the step below)
         *reinterpret_cast<smallk_v4 *>(Gs + a * 80 + 4 * c4) = g0;
         *reinterpret_cast<smallk_v4 *>(Gs + (a + 32) * 80 + 4 * c4) = g1;
         if (tid < 256) *reinterpret_cast<smallk_v4 *>(Ws + (tid >> 2) * 16 + 4 * (tid & 3)) = w0;
@@ -284,13 +302,21 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X
         const int buf = t & 1;
         const float *ha = Hc + buf * ST * 80 + ((ST / 2) * half + kg) * 80 + 16 * w + i;
         const float *xb = Xc + buf * ST * 16 + ((ST / 2) * half + kg) * 16 + i;
+        // all fragments of the stage first, then the MFMAs; staging unconditional (see smallk_h_kernel)
+        constexpr int NM = ST / 8;
+        float fa[NM], fb[NM];
 #pragma unroll
-        for (int m = 0; m < ST / 8; m += 2) {
-            acc0 = smallk_mfma(ha[4 * m * 80], xb[4 * m * 16], acc0);
-            acc1 = smallk_mfma(ha[(4 * m + 4) * 80], xb[(4 * m + 4) * 16], acc1);
+        for (int m = 0; m < NM; ++m) {
+            fa[m] = ha[4 * m * 80];
+            fb[m] = xb[4 * m * 16];
         }
-        if (t + 1 < T) lstore(set, buf ^ 1);
-        if (t + 3 < T) gload(set, (int64_t)(t + 3) * ST);
+#pragma unroll
+        for (int m = 0; m < NM; m += 2) {
+            acc0 = smallk_mfma(fa[m], fb[m], acc0);
+            acc1 = smallk_mfma(fa[m + 1], fb[m + 1], acc1);
+        }
+        lstore(set, buf ^ 1);
+        gload(set, (int64_t)((t + 3 < T) ? t + 3 : T - 1) * ST);
         __syncthreads();
     };
     for (int t = 0; t < T; t += 2) {

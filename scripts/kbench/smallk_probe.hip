@@ -1,5 +1,6 @@
 // Development micro-benchmark: where do the 31 us of a small-k stripe kernel go?  smallk_h_kernel with parts of its main loop
-// removed (template parameter PROBE, smallk.hpp).  Measured (MI355X, 4096 x 4096, event-timed: +4 us over the kernel's own duration):
+// removed (template parameter PROBE, smallk.hpp).  Measured BEFORE the staging / fragment-read fixes of round 3 (MI355X, 4096 x 4096,
+// event-timed: +4 us over the kernel's own duration; after them: full 34.7, no global loads 33.0, no MFMAs 27.7, no staging 26.3, registers only 21.9):
 // full 35.8 us; no global loads in the loop 31.9; no MFMAs 35.2 (the MFMAs are entirely hidden); no staging 24.8; MFMAs on
 // registers only 21.7 = the 13.7 us MFMA floor + 8 us of launch / prologue / epilogue.  So the loop is the staging path
 // (global load -> VGPR -> ds_write -> barrier -> ds_read), not the matrix cores.  Two re-designs that attack it were built and

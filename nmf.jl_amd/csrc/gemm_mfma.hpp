@@ -580,7 +580,7 @@ template <typename T> struct EpiStore {
 
 // Multiplicative update (src/multupd.jl:101-103, 112-114):
 //   out = old * ( max(0, num - lambda) / (acc + delta) ),  acc = Gram-form denominator
-// num may still be split-K slabs (summed here in ascending slab order, like reduce_slabs_kernel).
+// num may still be ONE or TWO split-K slabs (summed here in ascending slab order, like reduce_slabs_kernel).
 // STATS = 1 additionally accumulates the stop_condition sums of the component that runs along c
 // (src/common.jl:100-104: dev = sum (new-old)^2, sum = sum (new+old)^2; term in T, sum in Float64) and writes
 // one partial per r-tile:  stat_partial[(tr*ncomp + c)*2 + {0,1}]  -- the layout finalize_partials_kernel reduces.
@@ -617,10 +617,17 @@ template <typename T, int STATS> struct EpiMultUpdate {
     __device__ __forceinline__ Pre prefetch(int ro, int co) const {
         const uint32_t so = la.soff(ro, co);
         T nu = buf_ld<T>(rnum, la.lb, so);
-        for (int s = 1; s < nslab; ++s) {
-            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(num + ((int64_t)s * slab_stride + tile_off)), 0, -1, 0x00020000);
-            nu += buf_ld<T>(rs, la.lb, so);
+        // The second slab (the usual case: the numerator product ran 2-way split-K) is loaded UNCONDITIONALLY -- from slab 0 again when
+        // there is only one -- and selected afterwards.  As a loop over a run-time slab count every element's load sat in its own
+        // basic block behind s_waitcnt vmcnt(0): 16 dependent memory round trips per wave tile in front of the main loop (ISA).
+        {
+            const int64_t s1 = (nslab > 1) ? slab_stride : 0;
+            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(num + (s1 + tile_off)), 0, -1, 0x00020000);
+            const T v1 = buf_ld<T>(rs, la.lb, so);
+            const T sum = nu + v1;
+            nu = (nslab > 1) ? sum : nu;
         }
+        // (nslab <= 2 here: the callers combine three or more slabs by a reduction launch first -- Solver::h_num_nslab / w_num_nslab)
         return Pre{nu, buf_ld<T>(rold, la.lb, so)};
     }
     __device__ __forceinline__ void apply(int ro, int co, T v, int jt, const Pre &pre) {

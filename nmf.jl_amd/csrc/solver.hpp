@@ -854,7 +854,10 @@ template <typename T> class Solver : public SolverBase {
     // after wt_times(..., with_gram=true): where the numerator / the Gram operand live
     bool h_in_slabs = false, w_in_slabs = false;
     const T *h_num() const { return h_in_slabs ? slabs.p : numH_p; }
-    int h_num_nslab() const { return h_in_slabs ? h_nslab : 1; }
+    int h_num_nslab() const {   // (EpiMultUpdate sums at most two slabs)
+        if (h_in_slabs && h_nslab > 2) throw StatusError{NMFX_ERR_UNSUPPORTED, "internal: more than two numerator slabs left for the update epilogue"};
+        return h_in_slabs ? h_nslab : 1;
+    }
 
     // numW = Amat * H'  (P x K, ld P), Amat = X or Q              src/multupd.jl:109,187; projals.jl:101; alspgrad.jl:221
     // with_gram: also gramH = HH' (src/projals.jl:100, alspgrad.jl:220) in the same launch: B operand = [Amat ; H],
@@ -965,7 +968,10 @@ template <typename T> class Solver : public SolverBase {
         }
     }
     const T *w_num() const { return w_in_slabs ? slabs.p + slab_w_off : numW_p; }
-    int w_num_nslab() const { return w_in_slabs ? w_nslab : 1; }
+    int w_num_nslab() const {
+        if (w_in_slabs && w_nslab > 2) throw StatusError{NMFX_ERR_UNSUPPORTED, "internal: more than two numerator slabs left for the update epilogue"};
+        return w_in_slabs ? w_nslab : 1;
+    }
 
     void stats_w(const T *Wn, const T *Wo, const int *done) {
         timed("stats_W", 0.0, 2.0 * P * K * sizeof(T), [&] {

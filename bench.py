@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--cpu-sample-cols", type=int, default=2048)
     ap.add_argument("--check-every", type=int, default=1 << 30,
                     help="iterations between the host's polls of the device stop flag (default: never inside the timed region; the "
-                         "API default is 4 -- small problems pay a host round trip per poll)")
+                         "API default is 0 = adaptive -- small problems pay a host round trip per poll)")
     ap.add_argument("--sim-ranks", type=int, default=0,
                     help="measurement aid (1 GPU): time rank 0's COMPUTE of an N-rank run -- X, H are the rank's column shard, the "
                          "collectives move their bytes device-locally (results are not a factorisation; never a headline number)")
@@ -310,64 +310,46 @@ def _blas_pool():
 
 
 def cpu_baseline(p, n, k, T, Xt, W0, H0, ns):
-    """NMF.jl's CPU path = the NumPy restatement executing the reference's operation sequence, on the first `ns`
-    columns of the same X (per-iteration cost is linear in n); value is scaled to the full problem.
+    """NMF.jl's CPU path = the oracle's restatement of the reference's operation sequence with prepare_state's arrays allocated
+    ONCE (oracle/nmf_oracle.py::_MultMSEState, like MultUpdMSE_State, src/multupd.jl:63-80), on the first `ns` columns of the same X
+    (per-iteration cost is linear in n); value is scaled to the full problem.
     PURE iterations are timed: update_wh! + the preW/preH copies + stop_condition of nmf_skeleton! (src/common.jl:66-73),
     i.e. what one GPU 'step' does -- not prepare_state's W*H product, not the final objective pass.
-    BLAS threads: the pool is pinned explicitly (threadpoolctl) and the timing is taken at the pool's cap and at half / a
-    quarter / an eighth of it (skinny k = 256 products do not always scale to every core); the FASTEST setting is the baseline, and
-    `cores` reports the threads it actually used next to the host's core count."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import nmf_oracle as orc
+    It runs in a PROCESS OF ITS OWN (oracle/cpu_time.py): this process carries torch's OpenMP pool and a second OpenBLAS next to
+    NumPy's; the child loads NumPy's OpenBLAS only.  BLAS pool pinned per trial (threadpoolctl) at the pool's cap and at 1/2 ... 1/16
+    of it (skinny k = 256 products do not scale to every core; two sockets); the FASTEST setting is the baseline, `cores` = the
+    threads it used, and the line carries the seconds of every call site (each mul!, each element-wise loop, the copies,
+    stop_condition) of that setting."""
+    import subprocess
+    import tempfile
     ns = min(ns, n)
     Xs = np.asfortranarray(Xt[:ns, :].cpu().numpy().T)            # p x ns, column-major
-    tiny = float(np.finfo(T).tiny)
-    o = orc.resolve_opts(orc.ALG_NAMES["multmse"], T, orc.Opts(maxiter=1, tol=tiny))
     host_cores = os.cpu_count()
-    cap, blas = _blas_pool()
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # noqa: BLE001
-        threadpool_limits = None
-    cands = [cap] if (cap and threadpool_limits) else [None]
-    if cap and threadpool_limits:
-        cands += [c for c in (cap // 2, cap // 4, cap // 8) if c >= 2]
-
-    def timed_iters(nthr, budget_s, max_iters):
-        Ws, Hs = W0.copy(order="F"), np.asfortranarray(H0[:, :ns].copy())
-        cm = threadpool_limits(limits=nthr, user_api="blas") if (nthr and threadpool_limits) else None
-        try:
-            st = orc._MultMSE(T, o, Xs, Ws, Hs)                    # prepare_state (src/multupd.jl:70-78): NOT timed
-            st.update(Xs, Ws, Hs)                                  # warm-up (BLAS threads, page faults)
-            iters, t_used = 0, 0.0
-            while iters < max_iters and t_used < budget_s:
-                t0 = time.perf_counter()
-                preW, preH = Ws.copy(), Hs.copy()                  # common.jl:66-67
-                st.update(Xs, Ws, Hs)                              # common.jl:70
-                orc.stop_condition(Ws, preW, Hs, preH, T(tiny))    # common.jl:73
-                t_used += time.perf_counter() - t0
-                iters += 1
-        finally:
-            if cm is not None:
-                cm.restore_original_limits()
-        return t_used / iters, iters
-
-    trials = []
-    for c in cands:
-        t_it, iters = timed_iters(c, 8.0, 4)
-        trials.append({"blas_threads": c, "seconds_per_sample_iter": round(t_it, 4), "iters": iters})
-    best = min(trials, key=lambda d: d["seconds_per_sample_iter"])
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "sample.npz")
+        np.savez(f, X=Xs, W0=np.asfortranarray(W0), H0=np.asfortranarray(H0[:, :ns]))
+        env = {k_: v for k_, v in os.environ.items() if k_ not in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_time.py"), f, "4.0"], capture_output=True, text=True, timeout=900, env=env)
+    if r.returncode != 0:
+        return {"value": None, "unit": "iters/s", "cores": None, "host_cores": host_cores, "kind": "port", "error": (r.stderr or r.stdout)[-400:]}
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    best = d["best"]
     t_iter_full = best["seconds_per_sample_iter"] * (n / ns)
     used = best["blas_threads"]
     out = {"value": round(1.0 / t_iter_full, 5), "unit": "iters/s", "cores": used if used else host_cores, "host_cores": host_cores,
            "kind": "port",
            "sample": f"first {ns} of {n} columns of the same X = {ns / n:.4f} of the workload (p={p}, k={k}); {best['iters']} timed pure outer "
                      f"iterations (update_wh! + preW/preH copies + stop_condition; prepare_state and the final objective are not "
-                     f"timed) of oracle/nmf_oracle.py -- the reference's 6-GEMM sequence on NumPy's OpenBLAS pinned to {used} threads "
-                     f"(pool cap {cap} on a {host_cores}-core host; fastest of the settings in `thread_trials`), element-wise passes "
-                     f"single-threaded like stock Julia; time scaled by n/{ns}",
-           "seconds_per_iter_full_est": round(t_iter_full, 3),
-           "gflops_reference_equiv": round(12.0 * p * n * k / t_iter_full / 1e9, 1), "thread_trials": trials, "blas": blas}
+                     f"timed) of oracle/nmf_oracle.py::_MultMSEState -- the reference's 6-mul! sequence with its state allocated once, in a "
+                     f"process of its own (NumPy's OpenBLAS the only BLAS loaded) pinned to {used} threads (pool cap {d['pool_cap']} on a "
+                     f"{host_cores}-core host; fastest of `thread_trials`), element-wise loops single-threaded like stock Julia; time scaled by n/{ns}",
+           "seconds_per_iter_full_est": round(t_iter_full, 4),
+           "gflops_reference_equiv": round(12.0 * p * n * k / t_iter_full / 1e9, 1),
+           # where the sample iteration's time goes at the fastest setting (seconds per call site), and the six mul! on their own
+           "phase_seconds": best["phase_seconds"], "gemm_phases_gflops": best["gemm_gflops"], "gemm_seconds": best["gemm_seconds"],
+           "non_gemm_seconds": best["non_gemm_seconds"],
+           "thread_trials": [{k_: t[k_] for k_ in ("blas_threads", "iters", "seconds_per_sample_iter", "gemm_gflops", "non_gemm_seconds")} for t in d["thread_trials"]],
+           "blas": d["blas"]}
     out["julia_reference"] = julia_reference(p, ns, k, T)
     return out
 

@@ -244,6 +244,24 @@ int nmfx_local_group_create(nmfx_local_group **out, int nranks);   /* nranks <= 
 void nmfx_local_group_destroy(nmfx_local_group *group);            /* contexts still attached keep the group alive: freed when the last one is destroyed */
 int nmfx_comm_init_local(nmfx_ctx *ctx, nmfx_local_group *group, int rank);
 int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode);
+/* Peer-to-peer exchange (csrc/peer.hpp): the exchange step as a PUSH over directly mapped peer memory with device-side arrival
+ * flags -- every rank stores piece q straight into rank q's window (hipIpc-mapped between processes, the pointer itself inside one
+ * process), all xGMI links at once instead of a ring's one; the consumer adds the contributions in rank order (bit-identical to the
+ * in-process transport).  Third transport behind the same code path:
+ *   nmfx_comm_p2p_export  after any nmfx_comm_init* (and before nmfx_set_X like them): allocates this rank's window and returns
+ *                         its handle (NMFX_P2P_HANDLE_BYTES).  The communicator the context already has becomes the FALLBACK for
+ *                         collectives the windows cannot serve (the pipelined mode's second stream).
+ *   nmfx_comm_p2p_attach  all_handles = the nranks handles in rank order (the host ships them by any means, like the unique id):
+ *                         maps the peers' windows; from here on the exchange runs over them.
+ *   nmfx_comm_init_p2p    a communicator with NO other transport (then export + attach as above): no RCCL involved; also works
+ *                         with several processes on ONE device, where RCCL refuses duplicate GPUs (tests/test_gpu_peer.py).
+ * Waits are bounded (NMFX_P2P_TIMEOUT_S, default 30): a rank that never arrives turns into NMFX_ERR_RCCL ("peer exchange timed
+ * out") at the end of the solve instead of a hung GPU.  nmfx_comm_p2p_stats: collectives served by the windows / by the fallback. */
+#define NMFX_P2P_HANDLE_BYTES 128
+int nmfx_comm_init_p2p(nmfx_ctx *ctx, int rank, int nranks);
+int nmfx_comm_p2p_export(nmfx_ctx *ctx, void *handle_out /* NMFX_P2P_HANDLE_BYTES */);
+int nmfx_comm_p2p_attach(nmfx_ctx *ctx, const void *all_handles /* nranks x NMFX_P2P_HANDLE_BYTES */);
+int nmfx_comm_p2p_stats(nmfx_ctx *ctx, int64_t *served_by_windows, int64_t *served_by_base);
 /* Measurement aid (no reference counterpart, results are NOT a factorisation): "rank r of n" without peers -- collectives move
  * the bytes they would receive device-locally -- so the per-rank compute of the sharded path at an n-rank shard shape can be
  * timed on one GPU (bench.py --sim-ranks). */

@@ -23,7 +23,8 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     work[4].ensure((size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K));
     work[5].ensure((size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K));
     T *GD0 = work[4].p + (wrows ? row0 : 0), *GD1 = work[5].p + (wrows ? row0 : 0);
-    pg_part.ensure((size_t)3 * 65536);
+    pg_part.ensure((size_t)3 * 65536 + 8);
+    double *pg_red = pg_part.p + (size_t)3 * 65536;                        // the rank-local sums on their way through a collective
     if (!pg_state) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pg_state), sizeof(PgState)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pg_host), sizeof(PgState)));
@@ -34,6 +35,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     init.idle = 1;
     HIP_TRY(hipMemcpyAsync(pg_state, &init, sizeof init, hipMemcpyHostToDevice, stream));
     const bool reduce_scalars = (left && sharded()) || wrows;                    // H is column-sharded; W row-sharded or replicated
+    const bool tiny_ok = reduce_scalars && comm->tiny_capable();                 // peer transport: the scalars travel inside the decision kernels
     const T epsT = std::numeric_limits<T>::epsilon();
     const int *idle = &pg_state->idle, *gate = &pg_state->gate;
     // G = Gram*Z - B  (+ projgradnorm^2 partials)            :124-130 / :280-286
@@ -57,10 +59,17 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
             gemm<KSTRIDED, KSTRIDED, 2>("gemm_pg_step", Gram, K, K, Z, P, Rw, K, 1, false, e, idle, 4.0 * Rw * K * sizeof(T), sg);
         }
         nblk = last_blocks;
-        // sharded: the per-block partials themselves are all-reduced (a few KB: the same latency-bound collective as 3 doubles, and
-        // no local reduction launch in front of it); every rank then sums the same numbers in the same order
-        if (reduce_scalars) comm->all_reduce(pg_part.p, (size_t)3 * nblk, CT_F64, false, stream);
-        hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, beta, sigma, epsT, traceiter, last_enqueued ? 1 : 0);
+        // sharded: the three sums are global (ONE step size for all of Z, alspgrad.jl:150-155).  Peer transport: the decision kernel
+        // exchanges the rank-local sums itself (16-byte tagged granules, no collective launch).  Other transports: local sums by a
+        // one-block launch, all-reduce of 3 doubles (a count that does not depend on the rank's block grid), then the decision.
+        if (reduce_scalars && !tiny_ok) {
+            hipLaunchKernelGGL(pg_local_sum_kernel, dim3(1), dim3(256), 0, stream, pg_part.p, nblk, 3, pg_red);
+            comm->all_reduce(pg_red, 3, CT_F64, false, stream);
+            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_red, 1, beta, sigma, epsT, traceiter, last_enqueued ? 1 : 0, TinyAR());
+        } else {
+            hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, beta, sigma, epsT, traceiter, last_enqueued ? 1 : 0,
+                               reduce_scalars ? comm->tiny() : TinyAR());
+        }
     };
     // ~2048 blocks: row chunks of >= 1024 rows, the rest of the parallelism from the columns
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, rows / 1024));
@@ -125,8 +134,13 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
             } else {
                 nblk = advance();
             }
-            if (reduce_scalars) comm->all_reduce(pg_part.p, (size_t)nblk, CT_F64, false, stream);
-            hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, tolg);
+            if (reduce_scalars && !tiny_ok) {
+                hipLaunchKernelGGL(pg_local_sum_kernel, dim3(1), dim3(256), 0, stream, pg_part.p, nblk, 1, pg_red);
+                comm->all_reduce(pg_red, 1, CT_F64, false, stream);
+                hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_red, 1, tolg, TinyAR());
+            } else {
+                hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, tolg, reduce_scalars ? comm->tiny() : TinyAR());
+            }
             for (int sidx = 0; sidx < SPEC; ++sidx) step(sidx == SPEC - 1);
         }
         fetch();
@@ -191,6 +205,7 @@ template <typename T> void Solver<T>::subsolve(int which, const nmfx_opts &o, nm
         out->niters = w_subsolve(W[wcur].p, H[hcur].p, o, (T)o.tolg, &inner);
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    if (comm) comm->health();
     out->inner_iters = inner;
     out->backtracks = pg_backtracks;
 }
@@ -249,6 +264,7 @@ template <typename T> void Solver<T>::run_alspgrad(const nmfx_opts &o, nmfx_resu
         HIP_TRY(hipMemcpyAsync(&objv, obj_final.p, sizeof(double), hipMemcpyDeviceToHost, stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    if (comm) comm->health();
     end_iter_trace(o, t);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev_beg, ev_end));

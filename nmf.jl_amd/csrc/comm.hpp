@@ -33,10 +33,28 @@ struct CommError {
 enum : int { CT_F32 = 0, CT_F64 = 1, CT_BYTE = 2 };
 static inline size_t ct_size(int ct) { return ct == CT_F32 ? 4 : (ct == CT_F64 ? 8 : 1); }
 
+constexpr int LOCAL_MAX_RANKS = 16;
+
+// every rank's exchange window as mapped into THIS rank's address space (peer.hpp)
+struct PeerWin {
+    unsigned char *p[LOCAL_MAX_RANKS];
+};
+// what a one-block kernel needs to all-reduce a handful of doubles INSIDE itself (peer.hpp: tiny_allreduce); n <= 1: nothing to do
+struct TinyAR {
+    PeerWin win;
+    int rank = 0, n = 1;
+    unsigned long long timeout_ticks = 0;   // wall_clock64 ticks (100 MHz)
+};
+
 struct Comm {
     int rank = 0, nranks = 1;
     virtual ~Comm() {}
     virtual const char *transport() const = 0;
+    // did an exchange of this rank time out on the device?  (throws CommError; transports without device-side waits: no-op)
+    virtual void health() {}
+    // in-kernel all-reduce of a few doubles (peer transport)
+    virtual bool tiny_capable() const { return false; }
+    virtual TinyAR tiny() { return TinyAR(); }
     // in-place element-wise sum / max over the ranks
     virtual void all_reduce(void *buf, size_t count, int ct, bool max_op, hipStream_t s) = 0;
     // recv[i] = sum_q send_q[rank*recvcount + i]
@@ -106,8 +124,18 @@ struct SimComm : Comm {
     }
 };
 
+// "rank r of n" with NO transport of its own: the base of a PeerComm that must serve every collective from its windows
+// (nmfx_comm_init_p2p: several processes on ONE device -- where RCCL refuses duplicate GPUs -- or a deployment without RCCL)
+struct NoComm : Comm {
+    NoComm(int rank_, int nranks_) { rank = rank_; nranks = nranks_; }
+    const char *transport() const override { return "none"; }
+    [[noreturn]] static void fail() { throw CommError{"this collective cannot be served by the peer windows (other stream or not attached) and the communicator has no base transport"}; }
+    void all_reduce(void *, size_t, int, bool, hipStream_t) override { fail(); }
+    void reduce_scatter(const void *, void *, size_t, int, hipStream_t) override { fail(); }
+    void all_gather(const void *, void *, size_t, int, hipStream_t) override { fail(); }
+};
+
 // --------------------------------------------------------------------------------------------------- in-process group
-constexpr int LOCAL_MAX_RANKS = 16;
 
 struct PeerPtrs {
     const void *p[LOCAL_MAX_RANKS];

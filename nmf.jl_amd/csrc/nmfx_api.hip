@@ -167,6 +167,31 @@ int nmfx_comm_init_sim(nmfx_ctx *ctx, int rank, int nranks) {
     return guarded(ctx, [&] { ctx->impl->comm_init_sim(rank, nranks); });
 }
 
+int nmfx_comm_init_p2p(nmfx_ctx *ctx, int rank, int nranks) {
+    if (!ctx) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->comm_init_p2p(rank, nranks); });
+}
+
+int nmfx_comm_p2p_export(nmfx_ctx *ctx, void *handle_out) {
+    if (!ctx || !handle_out) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->p2p_export(handle_out); });
+}
+
+int nmfx_comm_p2p_attach(nmfx_ctx *ctx, const void *all_handles) {
+    if (!ctx || !all_handles) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->p2p_attach(all_handles); });
+}
+
+int nmfx_comm_p2p_stats(nmfx_ctx *ctx, int64_t *served_by_windows, int64_t *served_by_base) {
+    if (!ctx) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        long long w = 0, b = 0;
+        ctx->impl->p2p_stats(&w, &b);
+        if (served_by_windows) *served_by_windows = w;
+        if (served_by_base) *served_by_base = b;
+    });
+}
+
 int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode) {
     if (!ctx || (mode != NMFX_COMM_ROW_SHARDED && mode != NMFX_COMM_REPLICATED_W && mode != NMFX_COMM_PIPELINED)) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { ctx->impl->comm_set_mode(mode); });

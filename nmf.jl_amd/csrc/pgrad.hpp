@@ -13,6 +13,7 @@
 
 #include "gemm_mfma.hpp"
 #include "kernels.hpp"
+#include "peer.hpp"
 
 namespace nmfx {
 
@@ -149,13 +150,27 @@ __device__ __forceinline__ void pg_block_sum3(const double *partial, int n, doub
     __syncthreads();
 }
 
+// out[w] = sum of partial[i * nslot + w] over the launch's n blocks (nslot = 1 or 3), in the order pg_begin_kernel / pg_decide_kernel
+// use themselves: the rank-LOCAL sums of a sharded sub-solve on a transport without the in-kernel all-reduce (RCCL, the in-process
+// group).  The collective that follows then moves nslot doubles whatever the ranks' block counts are -- all-reducing the per-block
+// partials themselves (round 3) used a rank-dependent count as soon as ragged column shards straddle a 256-column boundary.
+__global__ void pg_local_sum_kernel(const double *partial, int n, int nslot, double *out) {
+    __shared__ double sm[4];
+    if (nslot == 3) { pg_block_sum3(partial, n, out); return; }
+    const double s = pg_block_sum(partial, n, 1, 0, sm);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
 // start of an inner iteration (src/alspgrad.jl:129-137): red[3] = projgradnorm^2 from the gradient GEMM's partials
-// (sharded: all-reduced across the ranks first, block by block); converged if < tolg, else arm back-tracking.
-template <typename T> __global__ void pg_begin_kernel(PgState *st, const double *partial, int n_local, T tolg) {
+// (sharded: the rank's own sum first, then the ranks' sums in rank order -- inside this kernel on the peer transport (`tiny`),
+// by an all-reduce of ONE double in front of it otherwise); converged if < tolg, else arm back-tracking.
+template <typename T> __global__ void pg_begin_kernel(PgState *st, const double *partial, int n_local, T tolg, TinyAR tiny) {
     if (st->gate) return;
     __shared__ double sm[4];
+    __shared__ double tsm[PEER_TINY_MAX];
     if (n_local > 0) {
-        const double s = pg_block_sum(partial, n_local, 1, 0, sm);
+        double s = pg_block_sum(partial, n_local, 1, 0, sm);
+        if (tiny.n > 1) tiny_allreduce(tiny, &s, 1, tsm);
         if (threadIdx.x == 0) st->red[3] = s;
     }
     __syncthreads();
@@ -180,12 +195,15 @@ __global__ void pg_resume_kernel(PgState *st) {
 
 // The branch logic of one back-tracking step (src/alspgrad.jl:155-177); n_local > 0: sum the step's partials first.
 template <typename T>
-__global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local, T beta, T sigma, T epsT, int traceiter, int last_enqueued) {
+__global__ void pg_decide_kernel(PgState *st, const double *partial, int n_local, T beta, T sigma, T epsT, int traceiter, int last_enqueued, TinyAR tiny) {
     if (st->idle) return;
     __shared__ double r3[3];
+    __shared__ double tsm[PEER_TINY_MAX];
     if (n_local > 0) pg_block_sum3(partial, n_local, r3);
+    double v3[3] = {r3[0], r3[1], r3[2]};
+    if (n_local > 0 && tiny.n > 1) tiny_allreduce(tiny, v3, 3, tsm);   // the ranks' sums, added in rank order (every rank decides on the same bits)
     if (threadIdx.x != 0) return;
-    if (n_local > 0) { st->red[0] = r3[0]; st->red[1] = r3[1]; st->red[2] = r3[2]; }
+    if (n_local > 0) { st->red[0] = v3[0]; st->red[1] = v3[1]; st->red[2] = v3[2]; }
     T alpha = (T)st->alpha;
     if (!isfinite(alpha)) { st->nonfinite = 1; st->idle = 1; st->gate = 1; return; }   // :140 (the step's sums are garbage then)
     const T dv1 = (T)st->red[0], dv2 = (T)st->red[1];

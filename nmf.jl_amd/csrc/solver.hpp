@@ -21,6 +21,7 @@
 
 #include "../../include/nmfx.h"
 #include "comm.hpp"
+#include "peer.hpp"
 #include "gemm_mfma.hpp"
 #include "gemm_bf16x3.hpp"
 #include "gemm_stream.hpp"
@@ -74,6 +75,10 @@ struct SolverBase {
     virtual void spa_init(int warm_sweeps, int64_t *anchors_out, int64_t *unsolved_out) = 0;
     virtual void pdsolve_host(int right, const void *A_host, const void *B_host, double lambda, void *X_host, bool clamp) = 0;
     virtual void comm_init_sim(int rank, int nranks) = 0;
+    virtual void comm_init_p2p(int rank, int nranks) = 0;
+    virtual void p2p_export(void *handle_out) = 0;
+    virtual void p2p_attach(const void *all_handles) = 0;
+    virtual void p2p_stats(long long *served_by_windows, long long *served_by_base) = 0;
     virtual double objective(int alg, const nmfx_opts &o) = 0;
     virtual bool check_nonneg(int which) = 0;
     virtual void randinit(uint64_t seed, bool normalize, bool zeroh, int64_t h_col_offset) = 0;
@@ -273,6 +278,44 @@ template <typename T> class Solver : public SolverBase {
         HIP_TRY(hipSetDevice(device));
         attach(new SimComm(rank_, nranks_));
     }
+    // Peer-to-peer exchange (peer.hpp).  comm_init_p2p: a communicator whose ONLY transport is the ranks' windows (the host ships
+    // the 128-byte handles, as it ships RCCL's unique id); p2p_export on a context that already has a communicator (RCCL, the
+    // in-process group, the timing stand-in) wraps it: the windows serve what fits, the wrapped transport the rest.
+    void comm_init_p2p(int rank_, int nranks_) override {
+        HIP_TRY(hipSetDevice(device));
+        if (nranks_ < 1 || nranks_ > LOCAL_MAX_RANKS || rank_ < 0 || rank_ >= nranks_) throw StatusError{NMFX_ERR_BAD_ARG, "peer communicator: need 0 <= rank < nranks <= 16"};
+        attach(new NoComm(rank_, nranks_));
+    }
+    // a slot holds one rank's contribution to the largest group of the W side's exchange: the Pc x K piece of the numerator (or of the
+    // new W: the all-gather chunk), two k x k Grams, the k-vectors and the statistics
+    size_t p2p_slot_bytes() const {
+        const size_t piece = std::max((size_t)std::max<int64_t>(Pc, 0) * K * sizeof(T) + 4096, ag_chunk_bytes + 4096);
+        return piece + 2 * ((size_t)K * K * sizeof(T) + 256) + 8 * ((size_t)K * sizeof(double) + 256) + 4096;
+    }
+    void p2p_export(void *handle_out) override {
+        HIP_TRY(hipSetDevice(device));
+        if (!comm) throw StatusError{NMFX_ERR_STATE, "nmfx_comm_p2p_export needs a communicator (nmfx_comm_init / _init_local / _init_sim / _init_p2p first)"};
+        if (nranks > LOCAL_MAX_RANKS) throw StatusError{NMFX_ERR_UNSUPPORTED, "peer exchange: at most 16 ranks"};
+        PeerComm *pc = dynamic_cast<PeerComm *>(comm);
+        if (!pc) {
+            Comm *b = comm;
+            pc = new PeerComm(b, device, p2p_slot_bytes());   // (throws before taking ownership of b only if the window cannot be allocated)
+            comm = pc;
+        }
+        pc->export_handle(handle_out);
+    }
+    void p2p_attach(const void *all_handles) override {
+        HIP_TRY(hipSetDevice(device));
+        PeerComm *pc = dynamic_cast<PeerComm *>(comm);
+        if (!pc) throw StatusError{NMFX_ERR_STATE, "nmfx_comm_p2p_attach: call nmfx_comm_p2p_export first"};
+        pc->attach(all_handles);
+    }
+    void p2p_stats(long long *w, long long *b) override {
+        PeerComm *pc = dynamic_cast<PeerComm *>(comm);
+        if (w) *w = pc ? pc->n_peer : 0;
+        if (b) *b = pc ? pc->n_base : 0;
+    }
+    PeerComm *peer() const { PeerComm *pc = dynamic_cast<PeerComm *>(comm); return (pc && pc->attached) ? pc : nullptr; }
     // 0: row-sharded W side (reduce-scatter / all-gather, the default whenever the shapes allow it); 1: the replicated W
     // update behind one packed all-reduce (round-1 formulation, kept for comparison and as the fallback); 2: row-sharded with
     // the exchange pipelined against the big products (MultUpdate-MSE; the other algorithms run as in mode 0)

@@ -468,6 +468,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         }
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    if (comm) comm->health();   // a device-side wait of the peer exchange that timed out surfaces here
     end_iter_trace(o, niters);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev_beg, ev_end));

@@ -16,6 +16,7 @@ ALG_MULTMSE, ALG_MULTDIV, ALG_PROJALS, ALG_ALSPGRAD, ALG_CD, ALG_GREEDYCD = 0, 1
 PREC_FP32, PREC_BF16X3 = 0, 1
 OK, ERR_BAD_ARG, ERR_DIM_MISMATCH, ERR_NOT_POSDEF, ERR_ALPHA_NONFINITE, ERR_HIP, ERR_RCCL, ERR_NO_DEVICE, ERR_STATE, ERR_UNSUPPORTED = range(10)
 UNIQUE_ID_BYTES = 128
+P2P_HANDLE_BYTES = 128
 
 # every symbol include/nmfx.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -23,7 +24,7 @@ SYMBOLS = [
     "nmfx_set_factors", "nmfx_get_factors", "nmfx_iterate", "nmfx_solve", "nmfx_alspgrad_subsolve",
     "nmfx_comm_get_unique_id", "nmfx_comm_init", "nmfx_objective", "nmfx_profile_enable", "nmfx_profile_get",
     "nmfx_device_info", "nmfx_check_nonneg", "nmfx_randinit", "nmfx_solve_replicates", "nmfx_nndsvd", "nmfx_get_iter_trace", "nmfx_rsvd_begin", "nmfx_rsvd_finish",
-    "nmfx_local_group_create", "nmfx_local_group_destroy", "nmfx_comm_init_local", "nmfx_comm_set_mode", "nmfx_comm_init_sim", "nmfx_pdsolve", "nmfx_pdrsolve", "nmfx_spa_init",
+    "nmfx_local_group_create", "nmfx_local_group_destroy", "nmfx_comm_init_local", "nmfx_comm_set_mode", "nmfx_comm_init_sim", "nmfx_comm_init_p2p", "nmfx_comm_p2p_export", "nmfx_comm_p2p_attach", "nmfx_comm_p2p_stats", "nmfx_pdsolve", "nmfx_pdrsolve", "nmfx_spa_init",
 ]
 COMM_ROW_SHARDED, COMM_REPLICATED_W, COMM_PIPELINED = 0, 1, 2
 
@@ -91,6 +92,10 @@ def load():
     lib.nmfx_comm_init_local.argtypes = [vp, vp, i32]
     lib.nmfx_comm_set_mode.argtypes = [vp, i32]
     lib.nmfx_comm_init_sim.argtypes = [vp, i32, i32]
+    lib.nmfx_comm_init_p2p.argtypes = [vp, i32, i32]
+    lib.nmfx_comm_p2p_export.argtypes = [vp, vp]
+    lib.nmfx_comm_p2p_attach.argtypes = [vp, vp]
+    lib.nmfx_comm_p2p_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     lib.nmfx_spa_init.argtypes = [vp, i32, vp, C.POINTER(C.c_int64)]
     lib.nmfx_pdsolve.argtypes = [vp, vp, C.c_double, vp, vp, i32]
     lib.nmfx_pdrsolve.argtypes = [vp, vp, vp, C.c_double, vp, i32]

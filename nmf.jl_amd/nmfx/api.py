@@ -437,6 +437,31 @@ class Context:
         """Timing stand-in: rank `rank` of `nranks` without peers (results are not a factorisation; bench.py --sim-ranks)."""
         self._ck(self.lib.nmfx_comm_init_sim(self.h, rank, nranks))
 
+    def comm_init_p2p(self, rank: int, nranks: int):
+        """Rank `rank` of `nranks` with the peer windows as the ONLY transport (no RCCL): follow with comm_p2p_export /
+        comm_p2p_attach.  Works with several processes on one device (where RCCL refuses duplicate GPUs)."""
+        self._ck(self.lib.nmfx_comm_init_p2p(self.h, rank, nranks))
+
+    def comm_p2p_export(self) -> bytes:
+        """Allocate this rank's exchange window and return its 128-byte handle (the host ships the handles of all ranks, in rank
+        order, to every rank -- like RCCL's unique id).  Needs a communicator (any transport); it becomes the fallback for
+        collectives the windows cannot serve."""
+        buf = C.create_string_buffer(L.P2P_HANDLE_BYTES)
+        self._ck(self.lib.nmfx_comm_p2p_export(self.h, buf))
+        return buf.raw
+
+    def comm_p2p_attach(self, handles):
+        """Map every rank's window (handles: the nranks exported handles in rank order) and switch the exchange to them."""
+        blob = b"".join(handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        self._ck(self.lib.nmfx_comm_p2p_attach(self.h, buf))
+
+    def comm_p2p_stats(self):
+        """(collectives served by the peer windows, collectives handed to the wrapped transport) so far."""
+        w, b = C.c_int64(), C.c_int64()
+        self._ck(self.lib.nmfx_comm_p2p_stats(self.h, C.byref(w), C.byref(b)))
+        return w.value, b.value
+
     def comm_set_mode(self, mode: str):
         """'row_sharded' (default: reduce-scatter / all-gather, each rank updates its rows of W) or 'replicated_w'
         (one packed all-reduce, every rank applies the full W update)."""

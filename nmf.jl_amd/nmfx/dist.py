@@ -34,9 +34,29 @@ def broadcast_unique_id(make_id, group=None) -> bytes:
     return bytes(uid)
 
 
-def init_comm(ctx, group=None):
-    """Attach an RCCL communicator spanning `group` (default: world) to a Context."""
+def init_comm(ctx, group=None, transport="rccl"):
+    """Attach a communicator spanning `group` (default: world) to a Context.
+    transport = "rccl": RCCL over xGMI.  "p2p": RCCL for the bootstrap and as the fallback, the exchange itself over the ranks'
+    peer-mapped windows (all xGMI links at once, device-side flags; csrc/peer.hpp).  "p2p_only": the windows alone, no RCCL
+    communicator at all (also works with several ranks on ONE device, where RCCL refuses duplicate GPUs)."""
     import torch.distributed as dist
     from .api import comm_unique_id
-    uid = broadcast_unique_id(comm_unique_id, group)
-    ctx.comm_init(uid, dist.get_rank(group), dist.get_world_size(group))
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if transport == "p2p_only":
+        ctx.comm_init_p2p(rank, world)
+    else:
+        uid = broadcast_unique_id(comm_unique_id, group)
+        ctx.comm_init(uid, rank, world)
+    if transport in ("p2p", "p2p_only"):
+        attach_p2p(ctx, group)
+    elif transport != "rccl":
+        raise ValueError(f"unknown transport {transport!r}")
+
+
+def attach_p2p(ctx, group=None):
+    """Export this rank's window, all-gather the 128-byte handles through the host, map the peers' windows."""
+    import torch.distributed as dist
+    mine = ctx.comm_p2p_export()
+    allh = [None] * dist.get_world_size(group)
+    dist.all_gather_object(allh, mine, group=group)
+    ctx.comm_p2p_attach(allh)

@@ -250,6 +250,79 @@ class _MultMSE:
         self.WH = W @ H                                           # :115
 
 
+class _MultMSEState:
+    """MultUpdMSE_State (src/multupd.jl:63-80) as the reference keeps it: WH, WtX, WtWH, XHt, WHHt allocated ONCE in
+    prepare_state, every mul! and every element-wise loop of update_wh! (:83-116) writing in place.  Same operations in the
+    same order as _MultMSE.update (the factors agree to a few ulp, tests/test_oracle_kat.py: `matmul(..., out=F-ordered)` takes
+    another gemm call form than `@`, nothing else differs) but no temporaries: this is the form
+    bench.py's cpu_baseline times (the allocating form spends most of its time in first-touch page faults of the p x n
+    temporaries, which NMF.jl does not have).  `phases` (optional dict) accumulates seconds per call site."""
+
+    def __init__(self, T, o, X, W, H):
+        self.T, self.o = T, o
+        p, n = X.shape
+        k = W.shape[1]
+        f = dict(dtype=T, order="F")
+        self.WH = np.empty((p, n), **f)
+        np.matmul(W, H, out=self.WH)                              # :72
+        self.WtX, self.WtWH, self.tH = (np.empty((k, n), **f) for _ in range(3))   # :73-74 (+ the loop's scalar temporaries)
+        self.XHt, self.WHHt, self.tW = (np.empty((p, k), **f) for _ in range(3))   # :75-76
+        self.preW, self.preH = np.empty((p, k), **f), np.empty((k, n), **f)        # nmf_skeleton!: common.jl:52-53
+        self.sW = np.empty((p, k), **f)                           # stop_condition's running sums (scalar registers in Julia)
+        self.sH = np.empty((k, n), **f)
+
+    def update(self, X, W, H, phases=None):
+        import time as _t
+        T, o = self.T, self.o
+        lw, lh, d = T(o.lambda_w), T(o.lambda_h), T(o.delta)
+
+        def ph(name, f):
+            if phases is None:
+                f()
+                return
+            t0 = _t.perf_counter()
+            f()
+            phases[name] = phases.get(name, 0.0) + (_t.perf_counter() - t0)
+
+        def upd(F, num, den, tmp, lam):
+            np.subtract(num, lam, out=tmp)
+            np.maximum(T(0), tmp, out=tmp)
+            np.add(den, d, out=den)
+            np.divide(tmp, den, out=tmp)
+            np.multiply(F, tmp, out=F)
+
+        if o.update_H:
+            ph("mul! WtX = W'X      :98", lambda: np.matmul(W.T, X, out=self.WtX))
+            ph("mul! WtWH = W'WH    :99", lambda: np.matmul(W.T, self.WH, out=self.WtWH))
+            ph("H loop              :101-103", lambda: upd(H, self.WtX, self.WtWH, self.tH, lh))
+            ph("mul! WH = W H       :104", lambda: np.matmul(W, H, out=self.WH))
+        ph("mul! XHt = X H'     :109", lambda: np.matmul(X, H.T, out=self.XHt))
+        ph("mul! WHHt = WH H'   :110", lambda: np.matmul(self.WH, H.T, out=self.WHHt))
+        ph("W loop              :112-114", lambda: upd(W, self.XHt, self.WHHt, self.tW, lw))
+        ph("mul! WH = W H       :115", lambda: np.matmul(W, H, out=self.WH))
+
+    def stop_condition(self, W, H, tol):
+        """stop_condition(W, preW, H, preH, tol) (src/common.jl:92-111) on the state's preW / preH, no allocations."""
+        T = self.T
+        tol = T(tol)
+
+        def sums(a, b, axis, tmp):
+            np.subtract(a, b, out=tmp)
+            np.multiply(tmp, tmp, out=tmp)
+            np.cumsum(tmp, axis=axis, dtype=T, out=tmp)
+            dev = (tmp[-1, :] if axis == 0 else tmp[:, -1]).copy()
+            np.add(a, b, out=tmp)
+            np.multiply(tmp, tmp, out=tmp)
+            np.cumsum(tmp, axis=axis, dtype=T, out=tmp)
+            sm = (tmp[-1, :] if axis == 0 else tmp[:, -1]).copy()
+            return dev, sm
+
+        dw, sw = sums(W, self.preW, 0, self.sW)
+        dh, sh = sums(H, self.preH, 1, self.sH)
+        bad = (np.sqrt(dw) > tol * np.sqrt(sw)) | (np.sqrt(dh) > tol * np.sqrt(sh))
+        return not bool(np.any(bad))
+
+
 class _MultDiv:
     """src/multupd.jl:121-193."""
 

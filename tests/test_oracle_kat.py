@@ -178,6 +178,27 @@ def test_stop_condition_agrees():
             assert co.stop_condition(W, pW, H, pH, tol) == expect
 
 
+@pytest.mark.parametrize("T,lim", [(np.float32, 2e-6), (np.float64, 1e-14)])
+def test_preallocated_multmse_state_is_the_same_iteration(T, lim):
+    """bench.py's cpu_baseline times _MultMSEState (prepare_state's arrays allocated once, src/multupd.jl:63-80, every mul! and
+    loop in place): the same operations in the same order as the allocating _MultMSE -- factors equal to a few ulp, the stop
+    decision identical."""
+    X, W0, H0 = planted(70, 90, 6, T, seed=3)
+    o = orc.resolve_opts(orc.MULTMSE, T, orc.Opts(maxiter=3, tol=1e-30, lambda_w=1e-3, lambda_h=2e-3))
+    W1, H1, W2, H2 = (a.copy(order="F") for a in (W0, H0, W0, H0))
+    a, b = orc._MultMSE(T, o, X, W1, H1), orc._MultMSEState(T, o, X, W2, H2)
+    for tol in (1e-30, 1e-30, 0.5, 1e-30):
+        pW, pH = W1.copy(), H1.copy()
+        a.update(X, W1, H1)
+        np.copyto(b.preW, W2)
+        np.copyto(b.preH, H2)
+        phases = {}
+        b.update(X, W2, H2, phases)
+        assert len(phases) == 8
+        assert orc.stop_condition(W1, pW, H1, pH, T(tol)) == b.stop_condition(W2, H2, tol)
+        assert np.abs(W1 - W2).max() <= lim * np.abs(W1).max() and np.abs(H1 - H2).max() <= lim * np.abs(H1).max()
+
+
 @pytest.mark.parametrize("T,lims", [(np.float64, (1e-12, 1e-12, 1e-9, 1e-9, 1e-12, 1e-11)), (np.float32, (2e-6, 2e-6, 2e-3, 1e-3, 1e-4, 2e-3))])
 def test_two_restatements_agree(T, lims):
     """The C and NumPy restatements are independent (own GEMM / Cholesky / reductions vs BLAS / LAPACK)."""

@@ -111,9 +111,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dev_sim = os.environ.get("NMFX_BENCH_BACKEND") == "gloo-sim"   # development aid (1-GPU box): gloo rendezvous + peer-less collectives
+    # development aid (1-GPU box, all ranks on NMFX_BENCH_DEVICE): gloo rendezvous + the REAL peer-window exchange between the
+    # processes (RCCL refuses several ranks on one device, so there is neither an RCCL reference run nor an RCCL fallback)
+    dev_gloo = os.environ.get("NMFX_BENCH_BACKEND") == "gloo-p2p"
+    if dev_gloo:
+        a.transport = "p2p_only"
     if world > 1:
         import torch.distributed as dist
-        if dev_sim:
+        if dev_sim or dev_gloo:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
@@ -131,18 +136,6 @@ def main():
     torch.cuda.synchronize()
 
     algid = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3, "cd": 4, "greedycd": 5}[a.alg]
-    ctx = nmfx.Context(T, p, nl, k, device=local_rank)
-    if world > 1:                       # before set_X: attaching a communicator may change the row padding
-        if dev_sim:
-            ctx.comm_init_sim(rank, world)
-        else:
-            nmfx.dist.init_comm(ctx)
-        ctx.comm_set_mode(a.comm_mode)
-    elif shards > 1:
-        ctx.comm_init_sim(0, shards)
-        ctx.comm_set_mode(a.comm_mode)
-    ctx.set_X_device(Xt.data_ptr(), p)
-    ctx.set_factors(W0, H0)
     eps = float(np.finfo(T).eps)
     lam = float(np.sqrt(eps)) if a.alg == "multdiv" else (float(np.cbrt(eps)) if a.alg == "projals" else 0.0)
     tiny = float(np.finfo(T).tiny)      # stop rule can never fire: exactly K iterations are executed
@@ -158,6 +151,105 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    wd = Watchdog(a.watchdog_s, rank, {"metric": "nmf_multupdate_mse_iters_per_sec" if a.alg == "multmse" else f"nmf_{a.alg}_iters_per_sec",
+                                       "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True,
+                                       "scaling": "strong", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                                       "config": {"workload": f"X={p}x{n} k={k} {a.dtype} alg=:{a.alg}", "parallelism": f"colshard{world}+{a.comm_mode}+{a.transport}"}})
+
+    def make_ctx(transport, mode):
+        """A context with X and the start factors resident; world > 1: a communicator of the given transport in the given mode."""
+        c = nmfx.Context(T, p, nl, k, device=local_rank)
+        if world > 1:                       # before set_X: attaching a communicator may change the row padding
+            if dev_sim:
+                c.comm_init_sim(rank, world)
+                if transport != "rccl":
+                    h = c.comm_p2p_export()
+                    c.comm_p2p_attach([h] * world)
+            else:
+                nmfx.dist.init_comm(c, transport=transport)
+            c.comm_set_mode(mode)
+        elif shards > 1:
+            c.comm_init_sim(0, shards)
+            if transport != "rccl":         # the peer transport's launch sequence with every "peer" window = the own one
+                h = c.comm_p2p_export()
+                c.comm_p2p_attach([h] * shards)
+            c.comm_set_mode(mode)
+        c.set_X_device(Xt.data_ptr(), p)
+        c.set_factors(W0, H0)
+        return c
+
+    def agree(ok):
+        """world > 1: True only if every rank says True."""
+        if world == 1:
+            return ok
+        import torch.distributed as dist
+        tt = torch.tensor([1.0 if ok else 0.0], device=("cpu" if (dev_sim or dev_gloo) else device), dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        return bool(tt.item() > 0.5)
+
+    def w_hash_and_obj(c, res):
+        import hashlib
+        Wchk = np.empty((p, k), dtype=T, order="F")
+        c.get_factors(Wchk, None)
+        return hashlib.sha256(Wchk.tobytes()).hexdigest(), float(res.objvalue), bool(np.isfinite(Wchk).all())
+
+    def probe(c, iters=3):
+        """A few iterations from the start factors; (ok, objective, errors): finite everywhere, W identical on every rank."""
+        import torch.distributed as dist
+        try:
+            c.set_factors(W0, H0)
+            res, _ = c.iterate(algid, opts(iters))
+            mine = w_hash_and_obj(c, res)
+            err = None
+        except Exception as e:  # noqa: BLE001
+            mine, err = ("", float("nan"), False), repr(e)
+        allv = [None] * world
+        dist.all_gather_object(allv, (mine, err))
+        ok = (all(v[1] is None and v[0][2] and np.isfinite(v[0][1]) for v in allv) and len({v[0][0] for v in allv}) == 1
+              and len({v[0][1] for v in allv}) == 1)
+        return ok, allv[0][0][1], [v[1] for v in allv if v[1] is not None]
+
+    # Multi-GPU: the requested transport / mode is VERIFIED before the timed region -- three iterations on it against three on plain RCCL
+    # (row-sharded), same start: finite, W bit-identical on all ranks, objective equal to 1e-5 -- and replaced by the next candidate
+    # when it fails (peer windows -> RCCL row-sharded -> RCCL replicated W); what ran is recorded in config.parallelism / `fallback`.
+    transport, mode, fallback_log = a.transport, a.comm_mode, []
+    if world > 1 and not dev_sim:
+        os.environ.setdefault("NMFX_P2P_TIMEOUT_S", "20")
+        ok_ref, obj_ref = False, float("nan")
+        if (transport, mode) != ("rccl", "row_sharded") and not dev_gloo:
+            wd.arm("verify:rccl+row_sharded")
+            ref_ctx = make_ctx("rccl", "row_sharded")
+            ok_ref, obj_ref, errs = probe(ref_ctx)
+            ref_ctx.close()
+            if not ok_ref:
+                fallback_log.append({"candidate": "rccl+row_sharded (reference run)", "ok": False, "errors": errs[:2]})
+        cands = [(transport, mode)] + [c_ for c_ in (("rccl", "row_sharded"), ("rccl", "replicated_w")) if c_ != (transport, mode) and not dev_gloo]
+        ctx = None
+        for tr, md in cands:
+            wd.arm(f"verify:{tr}+{md}")
+            try:
+                c = make_ctx(tr, md)
+                ok, obj, errs = probe(c)
+                same = ok and (not ok_ref or abs(obj - obj_ref) <= 1e-5 * abs(obj_ref))
+            except Exception as e:  # noqa: BLE001
+                c, same, obj, errs = None, False, float("nan"), [repr(e)]
+            same = agree(same)
+            fallback_log.append({"candidate": f"{tr}+{md}", "ok": same, "objective_after_3": obj,
+                                 "rccl_row_sharded_objective_after_3": (obj_ref if ok_ref else None), "errors": errs[:2]})
+            if same:
+                ctx, transport, mode = c, tr, md
+                break
+            if c is not None:
+                c.close()
+        if ctx is None:
+            if rank == 0:
+                print(json.dumps(dict(wd.base, value=None, status="no_working_exchange", fallback=fallback_log)), flush=True)
+            raise SystemExit(4)
+        ctx.set_factors(W0, H0)
+        wd.arm("warmup+timed")
+    else:
+        ctx = make_ctx(transport, mode)
+
     if a.warmup > 0:
         ctx.iterate(algid, opts(a.warmup))
     # hipEvent pairs on the solver stream around the dominant GEMM launches and the collectives (a pair costs ~10 us): 1 launch
@@ -168,11 +260,12 @@ def main():
     res, _ = ctx.iterate(algid, opts(a.steps))
     barrier()
     dt = time.perf_counter() - t0
+    wd.disarm()
     prof = ctx.profile_get()
     ctx.profile_enable(0)
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=("cpu" if dev_sim else device), dtype=torch.float64)
+        tt = torch.tensor([dt], device=("cpu" if (dev_sim or dev_gloo) else device), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert res.niters == a.steps, (res.niters, a.steps)
@@ -242,7 +335,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"X={p}x{n} k={k} {a.dtype} alg=:{a.alg} (planted-rank dense X, seed {SEED}), "
                                    f"column-sharded over {world} GPU(s)", "p": p, "n": n, "k": k,
-                       "parallelism": f"colshard{world}" + (f"+{a.comm_mode}" if world > 1 else ""), "precision": a.precision,
+                       "parallelism": f"colshard{world}" + (f"+{mode}+{transport}" if (world > 1 or shards > 1) else ""), "precision": a.precision,
                        "check_every": (a.check_every if a.check_every < (1 << 30) else "never (stop rule evaluated on the device only)")},
             "gflops_algorithmic": round(f_alg * a.steps / dt / 1e9, 1),
             "frac_of_mfma_peak": round(f_alg * a.steps / dt / 1e12 / (((2500.0 / 3.0) if a.precision == "bf16x3" else
@@ -266,10 +359,12 @@ def main():
                                             "fraction is what the fusion leaves unused, not a shortfall"} for s in hb]
         if consistency is not None:
             out["multi_gpu_consistency"] = consistency
+        if fallback_log:
+            out["exchange_verification"] = {"requested": f"{a.transport}+{a.comm_mode}", "ran": f"{transport}+{mode}", "candidates": fallback_log}
         # the exchange step's collectives (hipEvent brackets on the solver's stream: includes waiting for the slowest peer)
         coll = [s for s in prof if s["name"].startswith("comm_")]
         if coll:
-            out["collectives"] = {"transport": ("sim (device-local copies)" if (dev_sim or shards != world) else "rccl"), "mode": a.comm_mode,
+            out["collectives"] = {"transport": (f"sim of {transport} (device-local)" if (dev_sim or shards != world) else transport), "mode": mode,
                                   "per_iteration_us": round(sum(s["ms_total"] / s["launches"] for s in coll) * 1e3, 1),
                                   "calls": [{"name": s["name"], "avg_us": round(s["ms_total"] / s["launches"] * 1e3, 1), "sampled": s["launches"],
                                              "bytes": s["bytes"] / s["launches"]} for s in coll]}

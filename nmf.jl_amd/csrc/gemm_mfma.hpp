@@ -578,6 +578,48 @@ template <typename T> struct EpiStore {
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };
 
+// EpiStore whose main output is blocked along c into pieces of piece_rows (as above) that live in DIFFERENT allocations: piece g is the
+// (piece_rows x R) column-major matrix at piece[g] -- rank g's receive slot of the peer-to-peer exchange (peer.hpp), mapped into this
+// process: the X_g H_g' product stores row block g of the numerator straight into rank g's memory (write-through, system-scope
+// stores: they leave this GPU's caches as they are issued), so the reduce-scatter of the row-sharded W side has no send buffer, no
+// pack launch and no collective -- only a flag behind the launch.  Tail segments (the Gram riding in the launch) stay local.
+constexpr int EPI_MAX_PIECES = 16;
+template <typename T> struct EpiStorePeer {
+    T *piece[EPI_MAX_PIECES];
+    int64_t piece_rows;
+    T *C2 = nullptr;
+    int64_t ld2 = 0, stride2 = 0, r_off = 0, c_off = 0;
+    rsrc_t rd;
+    LaneAddr<T> la;
+    bool remote;
+    struct Pre {};
+    static constexpr bool EARLY = false, HEAVY = false;
+    __device__ __forceinline__ void setup(int split, const TileCtx &t) {
+        int64_t ldc;
+        T *dst;
+        if (split >= 0) {
+            const int64_t g = t.cw0 / piece_rows;
+            dst = piece[g] - g * piece_rows;                    // element (r, c) at dst + c + r * piece_rows
+            ldc = piece_rows;
+            remote = true;
+        } else { dst = C2 + (int64_t)(-1 - split) * stride2 - (c_off + r_off * ld2); ldc = ld2; remote = false; }
+        rd = tile_rsrc(dst, ldc, t);
+        la.init(t, ldc);
+    }
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ Pre prefetch(int, int) const { return Pre{}; }
+    __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &) {
+        if (remote) {
+            if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, (int)la.lb, (int)la.soff(ro, co), 17);
+            else {
+                typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, v), rd, (int)la.lb, (int)la.soff(ro, co), 17);
+            }
+        } else buf_st(rd, la.lb, la.soff(ro, co), v);
+    }
+    template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
+};
+
 // Multiplicative update (src/multupd.jl:101-103, 112-114):
 //   out = old * ( max(0, num - lambda) / (acc + delta) ),  acc = Gram-form denominator
 // num may still be ONE or TWO split-K slabs (summed here in ascending slab order, like reduce_slabs_kernel).

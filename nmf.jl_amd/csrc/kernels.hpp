@@ -410,11 +410,20 @@ __global__ void gathered_to_full_kernel(T *full, const unsigned char *recv, int 
 //   blocks [nb1, nb1 + nb2) : the fused Gram's tail pieces summed (reduce_many_slabs_kernel: 4 slab-lanes per element, fixed order)
 //   the rest                : stop_condition's H statistics finalised from the update GEMM's per-tile partials
 //                             (finalize_partials_kernel: a wave per output)
+// Destinations of the three outputs on the peer-to-peer transport (peer.hpp): piece g of the numerator goes to num[g] (rank g's receive
+// slot), the Gram and the statistics to EVERY rank's slot (n > 0; system-scope write-through stores).  n == 0: the local buffers.
+template <typename T> struct CombineDst {
+    T *num[16];
+    T *gram[16];
+    double *hstat[16];
+    int n;
+};
+template <typename T> __device__ __forceinline__ void peer_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 template <typename T>
 __global__ __launch_bounds__(256) void w_side_combine_kernel(T *dst_blk, const T *slabs, int64_t P, int64_t K, int64_t Pc, int nslab, int64_t stride,
                                                              T *gram, const T *gsrc, int64_t gcount, int gslabs, int64_t gstride,
                                                              const double *hpart, int hchunks, int hcount, double *hstat, unsigned nb1,
-                                                             unsigned nb2, const int *done) {
+                                                             unsigned nb2, const int *done, CombineDst<T> pd) {
     NMFX_DONE_GUARD(done);
     __shared__ T sm[4][64];
     if (blockIdx.x < nb1) {
@@ -424,7 +433,8 @@ __global__ __launch_bounds__(256) void w_side_combine_kernel(T *dst_blk, const T
         const int64_t o = (int64_t)i + (int64_t)a * P;
         T s = slabs[o];
         for (int q = 1; q < nslab; ++q) s += slabs[(int64_t)q * stride + o];
-        dst_blk[((int64_t)blk * K + a) * Pc + il] = s;
+        if (pd.n > 0) peer_store(pd.num[blk] + (int64_t)a * Pc + il, s);
+        else dst_blk[((int64_t)blk * K + a) * Pc + il] = s;
     } else if (blockIdx.x < nb1 + nb2) {
         const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
         const int64_t i = (int64_t)(blockIdx.x - nb1) * 64 + e;
@@ -442,7 +452,11 @@ __global__ __launch_bounds__(256) void w_side_combine_kernel(T *dst_blk, const T
         }
         sm[sl][e] = acc;
         __syncthreads();
-        if (sl == 0 && i < gcount) gram[i] = ((sm[0][e] + sm[1][e]) + sm[2][e]) + sm[3][e];
+        if (sl == 0 && i < gcount) {
+            const T v = ((sm[0][e] + sm[1][e]) + sm[2][e]) + sm[3][e];
+            if (pd.n > 0) { for (int q = 0; q < pd.n; ++q) peer_store(pd.gram[q] + i, v); }
+            else gram[i] = v;
+        }
     } else {
         const int e = (int)(blockIdx.x - nb1 - nb2) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
         if (e >= hcount) return;
@@ -450,7 +464,44 @@ __global__ __launch_bounds__(256) void w_side_combine_kernel(T *dst_blk, const T
         double s = 0.0;
         for (int c = lane; c < hchunks; c += 64) s += hpart[(int64_t)c * hcount + e];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) hstat[e] = s;
+        if (lane == 0) {
+            if (pd.n > 0) { for (int q = 0; q < pd.n; ++q) peer_store(pd.hstat[q] + e, s); }
+            else hstat[e] = s;
+        }
+    }
+}
+
+// The read side of the row-sharded W step's first exchange on the peer-to-peer transport, ONE launch: this rank's rows of the numerator,
+// the Gram H H' and the H statistics, each the sum of the n ranks' contributions IN RANK ORDER (slot q at base + q * slot_bytes; the order
+// of the in-process group's reduction kernels, so both transports give the same bits).  blocks [0, nb1): numerator, [nb1, nb1 + nb2):
+// Gram, the rest: statistics (nstat may be 0).
+template <typename T>
+__global__ __launch_bounds__(256) void peer_sum3_kernel(T *num, const unsigned char *num_src, size_t nnum, T *gram, const unsigned char *gram_src, size_t ngram,
+                                                        double *stat, const unsigned char *stat_src, size_t nstat, size_t slot_bytes, int n, unsigned nb1,
+                                                        unsigned nb2, const int *done) {
+    NMFX_DONE_GUARD(done);
+    if (blockIdx.x < nb1) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnum; i += (size_t)nb1 * blockDim.x) {
+            const unsigned char *b = num_src + i * sizeof(T);
+            T s = *reinterpret_cast<const T *>(b);
+            for (int q = 1; q < n; ++q) s += *reinterpret_cast<const T *>(b + (size_t)q * slot_bytes);
+            num[i] = s;
+        }
+    } else if (blockIdx.x < nb1 + nb2) {
+        for (size_t i = (size_t)(blockIdx.x - nb1) * blockDim.x + threadIdx.x; i < ngram; i += (size_t)nb2 * blockDim.x) {
+            const unsigned char *b = gram_src + i * sizeof(T);
+            T s = *reinterpret_cast<const T *>(b);
+            for (int q = 1; q < n; ++q) s += *reinterpret_cast<const T *>(b + (size_t)q * slot_bytes);
+            gram[i] = s;
+        }
+    } else {
+        const unsigned nb3 = gridDim.x - nb1 - nb2;
+        for (size_t i = (size_t)(blockIdx.x - nb1 - nb2) * blockDim.x + threadIdx.x; i < nstat; i += (size_t)nb3 * blockDim.x) {
+            const unsigned char *b = stat_src + i * sizeof(double);
+            double s = *reinterpret_cast<const double *>(b);
+            for (int q = 1; q < n; ++q) s += *reinterpret_cast<const double *>(b + (size_t)q * slot_bytes);
+            stat[i] = s;
+        }
     }
 }
 

@@ -421,6 +421,7 @@ struct PeerComm : Comm {
         ops.push_back(Op{3, nullptr, nullptr, 0, CT_BYTE, false, off});
         return off;
     }
+    size_t direct_off(size_t off) const { return region(seq + 1) + (size_t)rank * slot_bytes + off; }   // offset of direct_dst inside every window
     unsigned char *direct_dst(int q, size_t off) const { return win.p[q] + region(seq + 1) + (size_t)rank * slot_bytes + off; }
     const unsigned char *direct_src(int q, size_t off) const { return mine + region(seq + 1) + (size_t)q * slot_bytes + off; }
 };

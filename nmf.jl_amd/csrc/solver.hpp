@@ -936,13 +936,23 @@ template <typename T> class Solver : public SolverBase {
             const int tt = (int)((K / 128) * (K / 128));
             const int per = tail_piece(tiles * sw, tt, (int)(N / BK));
             const int pieces = (int)((N / BK + per - 1) / per);
+            Seg sg;
+            sg.B2 = Hp; sg.ldb2 = K; sg.c_split = P; sg.tail_tiles = (int)(K / 128);
+            if (direct && peer_dst != nullptr) {
+                // peer-to-peer transport: row block g of the product goes straight into rank g's receive slot (EpiStorePeer)
+                EpiStorePeer<T> e;
+                for (int g = 0; g < EPI_MAX_PIECES; ++g) e.piece[g] = (g < nranks) ? peer_dst->num[g] : nullptr;
+                e.piece_rows = Pc;
+                e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = (int64_t)K * K; e.r_off = 0; e.c_off = P;
+                gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, sw, false, e, done,
+                                         (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
+            } else {
             EpiStore<T> e{direct ? numW_p : reg, direct ? Pc : P, w_stride, nullptr};
             if (direct) { e.piece_rows = Pc; e.piece_stride = (int64_t)K * Pc; }
             e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = (int64_t)K * K; e.r_off = 0; e.c_off = P;
-            Seg sg;
-            sg.B2 = Hp; sg.ldb2 = K; sg.c_split = P; sg.tail_tiles = (int)(K / 128);
             gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, sw, false, e, done,
                                      (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
+            }
             w_direct = direct;
             if (w_defer_combine) { w_pieces = pieces; w_in_slabs = false; return; }   // the caller's combine launch sums both
             reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
@@ -1054,6 +1064,8 @@ template <typename T> class Solver : public SolverBase {
     void enqueue_objective(int alg, const nmfx_opts &o, double *dst, const int *done);
     void enqueue_multmse(const nmfx_opts &o, long long t);
     void multmse_w_rows_fused(const nmfx_opts &o, long long t);
+    void multmse_w_rows_fused_peer(const nmfx_opts &o, long long t, PeerComm *pc);
+    const CombineDst<T> *peer_dst = nullptr;   // set around times_ht: the peers' receive slots of the numerator (peer-to-peer transport)
     // k <= 64, Float32, one GPU: the 4-launch path of smallk.hpp (smallk_impl.hpp)
     bool smallk_enabled = true;          // NMFX_SMALLK=0 keeps the general path
     bool smallk_attr_set = false;

@@ -190,6 +190,10 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
 //   ->  one launch that unpacks W and takes stop_condition's column sums over all rows (gather_stats_kernel), one block that adds them
 //   up and runs the stop rule (stats_check_kernel).
 template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, long long t) {
+    if (PeerComm *pc = peer()) {
+        const size_t need = (size_t)Pc * K * sizeof(T) + 2 * ((size_t)K * K * sizeof(T) + 256) + (size_t)2 * K * sizeof(double) + 1024;
+        if (nranks <= EPI_MAX_PIECES && need <= pc->slot_bytes) { multmse_w_rows_fused_peer(o, t, pc); return; }
+    }
     const int *done = done_flag();
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;
@@ -201,7 +205,7 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
     timed("combine_W", 0.0, ((double)P * K * (w_nslab + 1) + (double)K * K * (w_pieces + 1)) * sizeof(T), [&] {
         hipLaunchKernelGGL(w_side_combine_kernel<T>, dim3(nb1 + nb2 + nb3), dim3(256), 0, stream, numW_p, slabs.p + slab_w_off, P, K, Pc, w_nslab,
                            w_stride, gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, w_pieces, (int64_t)K * K, stat_part.p, h_stat_chunks,
-                           (int)(2 * K), hstat.p, nb1, nb2, done);
+                           (int)(2 * K), hstat.p, nb1, nb2, done, CombineDst<T>{{}, {}, {}, 0});
         HIP_TRY(hipGetLastError());
     });
     timed("comm_reduce_scatter_numW", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
@@ -237,6 +241,99 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
     timed("gather_W_stats", 0.0, 3.0 * P * K * sizeof(T), [&] {
         hipLaunchKernelGGL(gather_stats_kernel<T>, dim3((unsigned)(nranks * cpp), (unsigned)K), dim3(256), 0, stream, Wn, Wo, ag_recv.p, chunk, P, Pc, cpp, (int)K,
                            stat_part.p, done);
+        hipLaunchKernelGGL(stats_check_kernel<T>, dim3(1), dim3(256), 0, stream, stat_part.p, nranks * cpp, (int)K, wstat.p, ctrl,
+                           o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done);
+        HIP_TRY(hipGetLastError());
+    });
+    check_fused = fuse_check;
+    wcur ^= 1;
+}
+
+// The same step on the peer-to-peer transport (peer.hpp): no collective launches at all.
+//   exchange 1 : the X_g H_g' launch stores row block g of the numerator STRAIGHT into rank g's receive slot (EpiStorePeer; with split-K
+//                slabs: the combine launch does), the combine launch stores H_g H_g' and the H statistics into every rank's slot
+//                -> flag -> one-block wait -> ONE launch adds the ranks' contributions in rank order (peer_sum3_kernel)
+//   exchange 2 : the rank's new rows and W_g'W_g pushed into every rank's slot by one copy launch each -> flag -> wait ->
+//                gather_stats_kernel reads the ranks' row blocks straight out of the slots
+// Same arithmetic in the same order as the in-process group's reduction kernels: bit-identical iterates (tests/test_gpu_peer.py).
+template <typename T> void Solver<T>::multmse_w_rows_fused_peer(const nmfx_opts &o, long long t, PeerComm *pc) {
+    const int *done = done_flag();
+    const T *Hp = H[hcur].p;
+    const T *Wo = W[wcur].p;
+    T *Wn = W[wcur ^ 1].p;
+    const int G = nranks;
+    const size_t piece_b = (size_t)Pc * K * sizeof(T), gram_b = (size_t)K * K * sizeof(T), hs_b = (size_t)2 * K * sizeof(double);
+    // ---- exchange 1
+    pc->group_start();
+    pc->group_stream = stream;
+    const size_t o_num = pc->direct_reserve(piece_b), o_gram = pc->direct_reserve(gram_b), o_hs = o.update_H ? pc->direct_reserve(hs_b) : 0;
+    CombineDst<T> pd;
+    std::memset(&pd, 0, sizeof pd);
+    pd.n = G;
+    for (int q = 0; q < G; ++q) {
+        pd.num[q] = reinterpret_cast<T *>(pc->direct_dst(q, o_num));
+        pd.gram[q] = reinterpret_cast<T *>(pc->direct_dst(q, o_gram));
+        pd.hstat[q] = reinterpret_cast<double *>(pc->direct_dst(q, o_hs));
+    }
+    const unsigned char *s_num = pc->direct_src(0, o_num), *s_gram = pc->direct_src(0, o_gram), *s_hs = pc->direct_src(0, o_hs);
+    w_blocked = true; w_defer_combine = true; peer_dst = &pd;
+    times_ht(X.p, Hp, true, done);
+    w_blocked = false; w_defer_combine = false; peer_dst = nullptr;
+    {
+        const unsigned nb1 = w_direct ? 0u : (unsigned)(P / 256 * K), nb2 = (unsigned)((K * K + 63) / 64), nb3 = o.update_H ? (unsigned)((2 * K + 3) / 4) : 0u;
+        timed("combine_W", 0.0, ((double)P * K * (w_nslab + 1) + (double)K * K * (w_pieces + 1)) * sizeof(T), [&] {
+            hipLaunchKernelGGL(w_side_combine_kernel<T>, dim3(nb1 + nb2 + nb3), dim3(256), 0, stream, numW_p, slabs.p + slab_w_off, P, K, Pc, w_nslab,
+                               w_stride, gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, w_pieces, (int64_t)K * K, stat_part.p, h_stat_chunks,
+                               (int)(2 * K), hstat.p, nb1, nb2, done, pd);
+            HIP_TRY(hipGetLastError());
+        });
+    }
+    timed("comm_p2p_flag_wait_numW", 0.0, (double)(P * K + K * K) * sizeof(T), [&] { pc->group_end(); });
+    {
+        const unsigned nb1 = (unsigned)std::min<int64_t>((Pc * K + 1023) / 1024, 2048), nb2 = (unsigned)std::min<int64_t>((K * K + 255) / 256, 256), nb3 = o.update_H ? 2u : 0u;
+        timed("sum_numW_slots", 0.0, (double)G * (Pc * K + K * K) * sizeof(T), [&] {
+            hipLaunchKernelGGL(peer_sum3_kernel<T>, dim3(nb1 + nb2 + nb3), dim3(256), 0, stream, rs_out.p, s_num, (size_t)Pc * K, gramH_p, s_gram, (size_t)K * K, hstat.p,
+                               s_hs, o.update_H ? (size_t)2 * K : (size_t)0, pc->slot_bytes, G, nb1, nb2, done);
+            HIP_TRY(hipGetLastError());
+        });
+    }
+    const size_t chunk = piece_b;
+    T *mine = reinterpret_cast<T *>(ag_recv.p + (size_t)rank * chunk);
+    EpiMultUpdateRows<T> e{rs_out.p, Pc, Wo + row0, P, mine, (T)o.lambda_w, (T)o.delta};                  // multupd.jl:110-114
+    gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo + row0, P, Pc, K, 1, false, e, done, 3.0 * Pc * K * sizeof(T));
+    if (o.update_H) {
+        const int sg = pick_splits((int)((K / 64) * (K / 64)), Pc);
+        EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
+        force_quarter_tiles = true;
+        gemm<KCONTIG, KCONTIG>("gemm_WtW_rows", mine, Pc, K, mine, Pc, K, Pc, sg, true, eg, done, (double)(Pc * K) * sizeof(T));
+        force_quarter_tiles = false;
+        reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, sg, done);
+    }
+    // ---- exchange 2
+    pc->group_start();
+    pc->group_stream = stream;
+    const size_t o_w = pc->direct_reserve(piece_b), o_gw = o.update_H ? pc->direct_reserve(gram_b) : 0;
+    const unsigned char *s_w = pc->direct_src(0, o_w), *s_gw = pc->direct_src(0, o_gw);
+    timed("push_W_rows", 0.0, (double)G * (Pc * K) * sizeof(T), [&] {
+        // (the pushes carry no `done` guard: behind the stop they re-send the last rows, which nobody reads)
+        hipLaunchKernelGGL(peer_push_kernel, dim3(PeerComm::grid_for(piece_b / 16 + 1), G), dim3(256), 0, stream, pc->win, pc->direct_off(o_w), reinterpret_cast<const unsigned char *>(mine),
+                           piece_b, (size_t)0);
+        if (o.update_H)
+            hipLaunchKernelGGL(peer_push_kernel, dim3(PeerComm::grid_for(gram_b / 16 + 1), G), dim3(256), 0, stream, pc->win, pc->direct_off(o_gw),
+                               reinterpret_cast<const unsigned char *>(gramW_p), gram_b, (size_t)0);
+        HIP_TRY(hipGetLastError());
+    });
+    timed("comm_p2p_flag_wait_W", 0.0, (double)(P * K) * sizeof(T), [&] { pc->group_end(); });
+    gramw_sharded_valid = o.update_H != 0;
+    const bool fuse_check = o.track_objective == 0;
+    const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(64 / nranks, Pc / 1024));   // chunks per piece
+    timed("gather_W_stats", 0.0, 3.0 * P * K * sizeof(T), [&] {
+        hipLaunchKernelGGL(gather_stats_kernel<T>, dim3((unsigned)(nranks * cpp), (unsigned)K), dim3(256), 0, stream, Wn, Wo, s_w, pc->slot_bytes, P, Pc, cpp, (int)K,
+                           stat_part.p, done);
+        if (o.update_H)
+            hipLaunchKernelGGL(peer_sum3_kernel<T>, dim3((unsigned)std::min<int64_t>((K * K + 255) / 256, 256)), dim3(256), 0, stream, gramW_p, s_gw, (size_t)K * K, (T *)nullptr,
+                               (const unsigned char *)nullptr, (size_t)0, (double *)nullptr, (const unsigned char *)nullptr, (size_t)0, pc->slot_bytes, G,
+                               (unsigned)std::min<int64_t>((K * K + 255) / 256, 256), 0u, done);
         hipLaunchKernelGGL(stats_check_kernel<T>, dim3(1), dim3(256), 0, stream, stat_part.p, nranks * cpp, (int)K, wstat.p, ctrl,
                            o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done);
         HIP_TRY(hipGetLastError());

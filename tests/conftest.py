@@ -2,7 +2,14 @@ import os
 import sys
 
 import pytest
-import torch  # noqa: F401  first: pins ONE HIP runtime for the process (see nmfx/_lib.py)
+
+# Several ranks of the peer-to-peer transport inside ONE process (tests/test_gpu_peer.py, contexts on threads): a rank's wait kernel
+# spins on the device until its peers' signal kernels have run, so no two ranks' streams may share a hardware queue (HIP multiplexes a
+# process's streams onto GPU_MAX_HW_QUEUES = 4 queues by default; a signal queued behind a spinning wait would never run).  Read by
+# the HIP runtime at initialisation, hence before torch.  One process per GPU -- the production layout -- needs nothing of the kind.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
+import torch  # noqa: E402,F401  first: pins ONE HIP runtime for the process (see nmfx/_lib.py)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for sub in ("nmf.jl_amd", "oracle", "tests"):

@@ -60,7 +60,39 @@ def parse():
                          "collectives move their bytes device-locally (results are not a factorisation; never a headline number)")
     ap.add_argument("--comm-mode", default="row_sharded", choices=["row_sharded", "replicated_w", "pipelined"],
                     help="multi-GPU W side: reduce-scatter / row-sharded update / all-gather (default) or one packed all-reduce + replicated update")
+    ap.add_argument("--transport", default="p2p", choices=["p2p", "rccl", "p2p_only"],
+                    help="multi-GPU exchange: p2p (default) = the ranks' peer-mapped windows with device-side flags (all xGMI links at once), RCCL for "
+                         "the bootstrap and as the fallback -- verified against an RCCL run of the same iterations before the timed region and "
+                         "dropped for plain RCCL if it fails; rccl = RCCL collectives; p2p_only = windows without any RCCL communicator")
+    ap.add_argument("--watchdog-s", type=float, default=600.0,
+                    help="multi-GPU: a stage that takes longer than this prints a JSON line with status = comm_timeout and exits (a mismatched "
+                         "collective would otherwise hang until the driver's timeout and leave no line at all)")
     return ap.parse_args()
+
+
+class Watchdog:
+    """A stage of a multi-rank run that does not finish (a collective some rank never enters) must still produce a line."""
+
+    def __init__(self, seconds, rank, base):
+        self.seconds, self.rank, self.base, self.timer, self.stage = seconds, rank, base, None, None
+
+    def arm(self, stage):
+        import threading
+        self.disarm()
+        self.stage = stage
+        self.timer = threading.Timer(self.seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self):
+        if self.rank == 0:
+            print(json.dumps(dict(self.base, value=None, status="comm_timeout", stage=self.stage, watchdog_s=self.seconds)), flush=True)
+        os._exit(3)
 
 
 def synth(p, n, k, c0, c1, tdtype, device, normalize_w0=True, warm=0.0):

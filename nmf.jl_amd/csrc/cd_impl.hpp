@@ -206,13 +206,14 @@ void Solver<T>::greedy_side(const char *tag, SampleView<const T> Zo, SampleView<
                             T lambda, bool sharded_samples, const int *done) {
     const T epsT = std::numeric_limits<T>::epsilon();
     const unsigned blocks = (unsigned)std::max<int64_t>(1, (nsamples + 3) / 4);   // >= 1: a rank without samples still takes part in the p_init all-reduce
-    work[3].ensure((size_t)blocks + 8);
+    // (sized once for BOTH sides: growing it between the W side and the H side would hipFree -- a device-wide synchronisation -- in the
+    // middle of an iteration, which deadlocks several in-process ranks whose peers spin on the device for this rank's next flag)
+    work[3].ensure((size_t)std::max(P, N) + 16);
     T *part = work[3].p, *pinit = work[3].p + blocks;
     if (cd_use_lds()) {
         const int kp = (int)((k + 63) / 64 * 64);
         const size_t lds = GreedyLds<T>::bytes(kp);
         cd_lds_check(lds);
-        work[3].ensure((size_t)std::max<int64_t>(1, nsamples) + 8);
         T *part1 = work[3].p, *pinit1 = work[3].p + std::max<int64_t>(1, nsamples);
         timed(tag, 0.0, 4.0 * (double)nsamples * K * sizeof(T), [&] {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_pinit_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -75,7 +75,8 @@ def same_run(a, b, alg):
         assert np.array_equal(W, Wa)
     for (r1, t1), (r2, t2) in zip(ra, rb):
         assert r1.niters == r2.niters and r1.converged == r2.converged
-        assert np.array_equal(np.asarray(t1), np.asarray(t2), equal_nan=True)
+        assert (t1 is None and t2 is None) or np.array_equal(np.asarray(t1, dtype=np.float64), np.asarray(t2, dtype=np.float64), equal_nan=True)
+        assert r1.objvalue == r2.objvalue or (np.isnan(r1.objvalue) and np.isnan(r2.objvalue))
         if alg == "alspgrad":
             assert r1.inner_iters == r2.inner_iters and r1.backtracks == r2.backtracks
 

@@ -354,4 +354,132 @@ __global__ __launch_bounds__(256) void trtri_offdiag_kernel(const T *U, T *Uinv,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// potrs!: X = inv(U'U) B by two triangular substitutions (pdsolve!, src/utils.jl:63-70: potrf! + potrs!) -- the reference's route,
+// blocked by 32:   U'y = b :  y_i = inv(U_ii)' (b_i - sum_{j<i} U_ji' y_j)      x from U x = y :  x_i = inv(U_ii) (y_i - sum_{j>i} U_ij x_j)
+// Half the flops of the product form Uinv (Uinv' B) (rounds 1-3) and no triangular inverse beyond the 32 x 32 diagonal blocks.
+//
+// potrs_prep_kernel packs what both sweeps read into ONE k x k matrix Tm (leading dimension ld, zero outside k x k):
+//   off-diagonal blocks : upper = U, lower = U' (so that BOTH sweeps read the block they need with the row index contiguous)
+//   diagonal blocks     : Dinv_i = inv(U_ii) in the upper triangle (diagonal included), its transpose in the strictly lower one
+// Every product of either sweep is then  acc(a, c) = sum_l Tm(32 j + a, 32 i + l) * S(32 i + l, c)  -- the trailing updates with
+// j != i (forward: j > i, backward: j < i), the diagonal solves with j == i and the other triangle masked.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void potrs_prep_kernel(const T *U, const T *Dinv, T *Tm, int64_t ld, int k, int K, const int *done) {
+    NMFX_DONE_GUARD(done);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)K * K; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e % K), c = (int)(e / K);
+        T v = (T)0;
+        if (r < k && c < k) {
+            if ((r >> 5) == (c >> 5)) v = (r <= c) ? Dinv[r + (int64_t)c * ld] : Dinv[c + (int64_t)r * ld];
+            else v = (r < c) ? U[r + (int64_t)c * ld] : U[c + (int64_t)r * ld];
+        }
+        Tm[r + (int64_t)c * ld] = v;
+    }
+}
+
+// One workgroup (4 waves) per panel of NB columns of B, the K x NB panel resident in LDS for both sweeps (S[row][col], row stride
+// NB + 1).  Right-looking: block step i solves its 32 rows against the diagonal block (a wave owns all 32 rows of its 32 / 16
+// columns, so the solve is in place without a barrier), then ALL later block rows take their update  r_j -= Tm_ji y_i  on the matrix
+// cores, (block row, column tile) items dealt round-robin to the 4 waves.  2 barriers per step, K / 32 steps per sweep.
+// Epilogue: projectnn! (max(x, 0), NaN passes through, src/utils.jl:34-41) if clamp, store; with `old` != nullptr also
+// stop_condition's sums of every component over the panel's columns (src/common.jl:100-104), partial[(panel * ncomp + a) * 2 + {0, 1}]
+// -- the layout finalize_partials_kernel reduces.  B = sum of nslab slabs (ascending), like the split-K combine it replaces.
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void potrs_panel_kernel(const T *Tm, int64_t ldt, const T *B, int nslab, int64_t slab_stride, int64_t ldb, T *Xout,
+                                                          const T *old, int K, int clamp, double *stat_partial, int ncomp, const int *done) {
+    NMFX_DONE_GUARD(done);
+    using M = Mfma<T>;
+    constexpr int MT = M::MT, KS = M::KS, SUB = 32 / MT, NTN = NB / MT, LDP = NB + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
+    T *S = reinterpret_cast<T *>(chol_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane % MT, ks = lane / MT;
+    const int64_t c0 = (int64_t)blockIdx.x * NB;
+    const int nb = K / 32;
+    // panel in: column c of B is contiguous in the component a
+    for (int e = tid; e < K * NB; e += 256) {
+        const int a = e % K, c = e / K;
+        const int64_t o = a + (c0 + c) * ldb;
+        T v = B[o];
+        for (int q = 1; q < nslab; ++q) v += B[(int64_t)q * slab_stride + o];
+        S[a * LDP + c] = v;
+    }
+    __syncthreads();
+    auto acc_row = [&](int reg) { return (sizeof(T) == 4) ? ((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) : ((lane >> 4) + 4 * reg); };
+    // acc[si] (rows 32 jb + si*MT .., columns nj*MT ..) = sum_l Tm(32 jb + a, 32 ib + l) S(32 ib + l, c);  tri: 0 none, +1 keep a >= l, -1 keep a <= l
+    auto product = [&](typename M::acc_t (&acc)[SUB], int jb, int ib, int nj, int tri) {
+#pragma unroll
+        for (int si = 0; si < SUB; ++si)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) acc[si][r] = (T)0;
+        T af[32 / KS][SUB], bf[32 / KS];
+#pragma unroll
+        for (int kk = 0; kk < 32 / KS; ++kk) {
+            const int l = kk * KS + ks;
+#pragma unroll
+            for (int si = 0; si < SUB; ++si) {
+                const int a = si * MT + li;
+                T v = Tm[(int64_t)(32 * jb + a) + (int64_t)(32 * ib + l) * ldt];
+                if (tri > 0) v = (a >= l) ? v : (T)0;
+                if (tri < 0) v = (a <= l) ? v : (T)0;
+                af[kk][si] = v;
+            }
+            bf[kk] = S[(32 * ib + l) * LDP + nj * MT + li];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 32 / KS; ++kk)
+#pragma unroll
+            for (int si = 0; si < SUB; ++si) acc[si] = M::mma(af[kk][si], bf[kk], acc[si]);
+    };
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        for (int step = 0; step < nb; ++step) {
+            const int i = sweep == 0 ? step : nb - 1 - step;
+            // diagonal solve, in place: wave w owns column tiles w, w + 4, ...
+            for (int nj = wave; nj < NTN; nj += 4) {
+                typename M::acc_t acc[SUB];
+                product(acc, i, i, nj, sweep == 0 ? 1 : -1);
+#pragma unroll
+                for (int si = 0; si < SUB; ++si)
+#pragma unroll
+                    for (int reg = 0; reg < M::NACC; ++reg) S[(32 * i + si * MT + acc_row(reg)) * LDP + nj * MT + li] = acc[si][reg];
+            }
+            __syncthreads();
+            // trailing update of every block row still to be solved in this sweep
+            const int nrem = nb - 1 - step;
+            for (int it = wave; it < nrem * NTN; it += 4) {
+                const int jr = it / NTN, nj = it % NTN;
+                const int j = sweep == 0 ? i + 1 + jr : i - 1 - jr;
+                typename M::acc_t acc[SUB];
+                product(acc, j, i, nj, 0);
+#pragma unroll
+                for (int si = 0; si < SUB; ++si)
+#pragma unroll
+                    for (int reg = 0; reg < M::NACC; ++reg) S[(32 * j + si * MT + acc_row(reg)) * LDP + nj * MT + li] -= acc[si][reg];
+            }
+            __syncthreads();
+        }
+    }
+    // panel out: thread = component
+    for (int a = tid; a < K; a += 256) {
+        double dev = 0.0, sum = 0.0;
+        for (int c = 0; c < NB; ++c) {
+            T v = S[a * LDP + c];
+            if (clamp) v = (v < (T)0) ? (T)0 : v;
+            const int64_t o = a + (c0 + c) * ldb;
+            if (old != nullptr) {
+                const T ov = old[o];
+                const T d = v - ov, sp = v + ov;
+                dev += (double)(T)(d * d);
+                sum += (double)(T)(sp * sp);
+            }
+            Xout[o] = v;
+        }
+        if (old != nullptr && stat_partial != nullptr) {
+            stat_partial[((int64_t)blockIdx.x * ncomp + a) * 2] = dev;
+            stat_partial[((int64_t)blockIdx.x * ncomp + a) * 2 + 1] = sum;
+        }
+    }
+}
+
 }  // namespace nmfx

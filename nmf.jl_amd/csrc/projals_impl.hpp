@@ -12,7 +12,7 @@ namespace nmfx {
 
 // U = potrf(A + lambda I) in place (upper triangle of A), Uinv = inv(U).  adddiag! (src/utils.jl:15-24) + potrf! of
 // pdsolve! / pdrsolve! (src/utils.jl:63-84).  A non-positive pivot raises ctrl->status = NOT_POSDEF (PosDefException).
-template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const char *tag_potrf, const char *tag_trtri, const int *done) {
+template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const char *tag_potrf, const char *tag_trtri, const int *done, T *Tm) {
     const size_t kk = (size_t)K * K;
     // potrf: 32 x 32 diagonal block + 32 x kp row panel in LDS (kp = k rounded up to 32)
     const size_t lds32 = potrf_lds_bytes();
@@ -43,9 +43,26 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tri));
         const unsigned nblk = (unsigned)((k + 31) / 32);
         hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3(nblk), dim3(64), 0, stream, A, Uinv, K, (int)k, done);
-        hipLaunchKernelGGL((trtri_offdiag_kernel<T>), dim3(nblk), dim3(256), lds_tri, stream, A, Uinv, K, (int)k, nfit, done);
+        if (Tm != nullptr)   // left solve by substitution (potrs!): only the diagonal blocks' inverses are needed, packed with U and U' (chol.hpp)
+            hipLaunchKernelGGL((potrs_prep_kernel<T>), dim3((unsigned)std::min<int64_t>((K * K + 255) / 256, 1024)), dim3(256), 0, stream, A, Uinv, Tm, K, (int)k, (int)K, done);
+        else
+            hipLaunchKernelGGL((trtri_offdiag_kernel<T>), dim3(nblk), dim3(256), lds_tri, stream, A, Uinv, K, (int)k, nfit, done);
         HIP_TRY(hipGetLastError());
     });
+}
+
+// potrs! (src/utils.jl:69) after spd_factor(..., Tm): out = inv(A) B by the two blocked triangular substitutions of potrs_panel_kernel;
+// clamp = projectnn!; old != nullptr: stop_condition's sums against `old` into stat_part (finalised by stats_h_finalize(N / NB))
+template <typename T> int Solver<T>::spd_solve_left_potrs(const T *Tm, const T *B, T *out, bool clamp, const T *old, const int *done) {
+    constexpr int NB = POTRS_NB;
+    const size_t lds = (size_t)K * (NB + 1) * sizeof(T);
+    timed("potrs_clampH", 2.0 * (double)K * K * N, 3.0 * K * N * sizeof(T), [&] {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrs_panel_kernel<T, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((potrs_panel_kernel<T, NB>), dim3((unsigned)(N / NB)), dim3(256), lds, stream, Tm, K, B, 1, (int64_t)0, K, out, old, (int)K, clamp ? 1 : 0,
+                           old ? stat_part.p : (double *)nullptr, (int)K, done);
+        HIP_TRY(hipGetLastError());
+    });
+    return (int)(N / NB);
 }
 
 // pdsolve! (src/utils.jl:63-70) after the factorisation: out = inv(A) B for B, out K x N (ld K): Y = Uinv' B, out = Uinv Y
@@ -91,12 +108,14 @@ template <typename T> void Solver<T>::pdsolve_host(int right, const void *A_host
     T *G = right ? gramH_p : gramW_p;
     HIP_TRY(hipMemsetAsync(G, 0, kk * sizeof(T), stream));
     HIP_TRY(hipMemcpy2DAsync(G, K * sizeof(T), right ? B_host : A_host, k * sizeof(T), k * sizeof(T), k, hipMemcpyHostToDevice, stream));
-    spd_factor(G, (T)lambda, work[1].p, "potrf", "trtri", nullptr);
+    const bool subst = !right && potrs_ok();
+    spd_factor(G, (T)lambda, work[1].p, "potrf", "trtri", nullptr, subst ? work[2].p : (T *)nullptr);
     have_F = false;   // the factor buffers are scratch for this call
     if (!right) {     // x <- inv(A) x, x is k x n
         HIP_TRY(hipMemsetAsync(numH_p, 0, (size_t)K * N * sizeof(T), stream));
         HIP_TRY(hipMemcpy2DAsync(numH_p, K * sizeof(T), B_host, k * sizeof(T), k * sizeof(T), n, hipMemcpyHostToDevice, stream));
-        spd_solve_left(work[1].p, numH_p, work[0].p, H[0].p, clamp, nullptr);
+        if (subst) spd_solve_left_potrs(work[2].p, numH_p, H[0].p, clamp, nullptr, nullptr);
+        else spd_solve_left(work[1].p, numH_p, work[0].p, H[0].p, clamp, nullptr);
         HIP_TRY(hipMemcpy2DAsync(X_host, k * sizeof(T), H[0].p, K * sizeof(T), k * sizeof(T), n, hipMemcpyDeviceToHost, stream));
     } else {          // x <- A inv(B), A and x are p x k
         HIP_TRY(hipMemsetAsync(numW_p, 0, (size_t)P * K * sizeof(T), stream));
@@ -111,7 +130,6 @@ template <typename T> void Solver<T>::pdsolve_host(int right, const void *A_host
 }
 
 template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long long t) {
-    (void)t;
     const int *done = done_flag();
     const size_t kk = (size_t)K * K;
     work[0].ensure((size_t)K * N);   // Y = Uinv' * W'X
@@ -133,6 +151,7 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // order (its Gram travels inside the one packed all-reduce that follows the product).
     const bool under = chol_slots > 0 && !use_bf16x3() && K % 128 == 0 && (!sharded() || rs);
     if (under) ensure_fstream();
+    const bool subst = potrs_ok();   // H solve by triangular substitution (potrs!) instead of Uinv (Uinv' B)
     auto factor_under = [&](T *G, T lambda, const char *t1, const char *t2, bool with_potri) {
         HIP_TRY(hipEventRecord(ev_fork, stream));
         HIP_TRY(hipStreamWaitEvent(fstream, ev_fork, 0));
@@ -143,7 +162,7 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
                 explicit Swap(Solver<T> &s_) : s(s_) { std::swap(s.stream, s.fstream); s.potrf_nt = 512; }
                 ~Swap() { std::swap(s.stream, s.fstream); s.potrf_nt = 1024; }
             } on_side(*this);
-            spd_factor(G, lambda, Uinv, t1, t2, done);
+            spd_factor(G, lambda, Uinv, t1, t2, done, (!with_potri && subst) ? invA : (T *)nullptr);
             if (with_potri) {            // potri! + copytri! (src/utils.jl:79-80) belong to the factorisation, not to the product
                 EpiStore<T> e1{invA, K, 0, nullptr};
                 gemm<KSTRIDED, KSTRIDED>("gemm_potri", Uinv, K, K, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * K * sizeof(T));
@@ -156,7 +175,9 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
         const T *Ho = H[hcur].p;
         T *Hn = H[hcur ^ 1].p;
         if (under) {
-            gram_w_only(Wp, done);                                             // :92 W'W (W is replicated: no exchange)
+            // :92 W'W (W is replicated: no exchange) -- or, from the second iteration of the fused row-sharded step on, already there:
+            // the sum over the ranks of W_g'W_g of their own new rows, which travelled with the all-gather of W
+            if (!gramw_sharded_valid) gram_w_only(Wp, done);
             factor_under(gramW_p, (T)o.lambda_h, "potrf_WtW", "trtri_WtW", false);   // :92 adddiag!, :94 potrf!
             short_grid = true;
             try { wt_times(Wp, X.p, false, done); } catch (...) { short_grid = false; throw; }   // :93 H <- W'X
@@ -164,9 +185,12 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
             HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
         } else {
             wt_times(Wp, X.p, true, done);                                     // :92 W'W, :93 H <- W'X (one launch)
-            spd_factor(gramW_p, (T)o.lambda_h, Uinv, "potrf_WtW", "trtri_WtW", done);
+            spd_factor(gramW_p, (T)o.lambda_h, Uinv, "potrf_WtW", "trtri_WtW", done, subst ? invA : (T *)nullptr);
         }
-        {   // :94 potrs! as Uinv * (Uinv' * B), :95 projectnn! and stop_condition's sums over H in the second product's epilogue
+        if (subst) {   // :94 potrs! (two blocked triangular substitutions), :95 projectnn!, stop_condition's sums over H -- one launch
+            const int chunks = spd_solve_left_potrs(invA, numH_p, Hn, true, Ho, done);
+            stats_h_finalize(chunks, done);
+        } else {   // :94 potrs! as Uinv * (Uinv' * B), :95 projectnn! and stop_condition's sums over H in the second product's epilogue
             EpiStore<T> e1{Y, K, 0, nullptr};
             gemm<KCONTIG, KCONTIG>("gemm_UinvtB", numH_p, K, N, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * N * sizeof(T));
             EpiClampStats<T> e2{Ho, Hn, K, stat_part.p, (int)K};
@@ -187,6 +211,51 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
         try { times_ht(X.p, Hp, false, done); } catch (...) { short_grid = false; w_blocked = false; throw; }   // :101 XH'
         short_grid = false;
         w_blocked = false;
+        if (rs && rs_fused_enabled) {
+            // The row-sharded W side with the launches around its two collectives fused, as MultUpdate-MSE has it (solver_impl.hpp):
+            // the product reads the rank's rows of the numerator STRAIGHT from the reduce-scatter's output and writes the new rows
+            // STRAIGHT into the rank's chunk of the all-gather buffer (no piece_to_rows / rows_to_piece / gathered_to_full launches),
+            // W'W for the next H solve comes from the rank's own new rows (2 Pc k^2 instead of 2 p k^2 on every rank) and travels with
+            // the in-place all-gather, and one launch unpacks W and takes stop_condition's column sums over all rows.
+            timed("comm_reduce_scatter_numW", 0.0, (double)(P * K) * sizeof(T), [&] {
+                comm->group_start();
+                comm->reduce_scatter(numW_p, rs_out.p, (size_t)Pc * K, CT, stream);
+                if (o.update_H) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
+                comm->group_end();
+            });
+            HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
+            const size_t chunk = (size_t)Pc * K * sizeof(T);
+            T *mine = reinterpret_cast<T *>(ag_recv.p + (size_t)rank * chunk);
+            EpiClampStore<T> e2{mine, Pc};                                     // :102 mul!, :103 projectnn!
+            gemm<KSTRIDED, KSTRIDED>("gemm_XHtInv_clampW", invA, K, K, rs_out.p, Pc, Pc, K, 1, false, e2, done, 2.0 * Pc * K * sizeof(T));
+            if (o.update_H) {
+                const int sg = pick_splits((int)((K / 64) * (K / 64)), Pc);
+                EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
+                force_quarter_tiles = true;
+                gemm<KCONTIG, KCONTIG>("gemm_WtW_rows", mine, Pc, K, mine, Pc, K, Pc, sg, true, eg, done, (double)(Pc * K) * sizeof(T));
+                force_quarter_tiles = false;
+                reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, sg, done);
+            }
+            timed("comm_all_gather_W", 0.0, (double)(P * K) * sizeof(T), [&] {
+                comm->group_start();
+                comm->all_gather(mine, ag_recv.p, chunk, CT_BYTE, stream);
+                if (o.update_H) comm->all_reduce(gramW_p, kk, CT, false, stream);
+                comm->group_end();
+            });
+            gramw_sharded_valid = o.update_H != 0;
+            const bool fuse_check = o.track_objective == 0;
+            const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(64 / nranks, Pc / 1024));
+            timed("gather_W_stats", 0.0, 3.0 * P * K * sizeof(T), [&] {
+                hipLaunchKernelGGL(gather_stats_kernel<T>, dim3((unsigned)(nranks * cpp), (unsigned)K), dim3(256), 0, stream, Wn, Wo, ag_recv.p, chunk, P, Pc, cpp, (int)K,
+                                   stat_part.p, done);
+                hipLaunchKernelGGL(stats_check_kernel<T>, dim3(1), dim3(256), 0, stream, stat_part.p, nranks * cpp, (int)K, wstat.p, ctrl,
+                                   o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done);
+                HIP_TRY(hipGetLastError());
+            });
+            check_fused = fuse_check;
+            wcur ^= 1;
+            return;
+        }
         if (rs) scatter_w_numerator(o.update_H != 0, done, /*with_tail=*/false);
         HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
         const int64_t r0 = rs ? row0 : 0, rows = rs ? Pc : P;

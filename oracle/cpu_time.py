@@ -9,7 +9,7 @@ loaded (bench.py's own process carries torch's OpenMP pool and a second OpenBLAS
     python oracle/cpu_time.py sample.npz            # X (p x ns), W0 (p x k), H0 (k x ns)
 
 Prints ONE JSON object: for every BLAS pool size tried the seconds per call site (each mul!, each element-wise loop,
-the copies, stop_condition), the GEMM phases' GFLOP/s on their own, and the fastest setting.  Round 3 timed the
+the copies, stop_condition's two passes), the GEMM phases' GFLOP/s on their own, and the fastest setting.  Round 3 timed the
 ALLOCATING form of the oracle inside bench.py's process: 1.07 s per sample iteration, of which ~1.0 s were first-touch
 page faults of three fresh p x ns temporaries per iteration (the GPU box is a micro-VM: 0.25 GB/s on fresh pages) --
 work NMF.jl does not do.  The GEMM phases alone were always fast (scripts/cpu_blas_diag.py).
@@ -35,6 +35,7 @@ except Exception:  # noqa: BLE001
 def main():
     d = np.load(sys.argv[1])
     budget_s = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
+    n_full = int(sys.argv[3]) if len(sys.argv) > 3 else None        # columns of the FULL problem the sample stands for
     X, W0, H0 = (np.asfortranarray(d[k]) for k in ("X", "W0", "H0"))
     T = X.dtype.type
     p, ns = X.shape
@@ -57,22 +58,27 @@ def main():
             phases, iters, used = {}, 0, 0.0
             while iters < 6 and used < budget_s:
                 t0 = time.perf_counter()
-                np.copyto(st.preW, Ws)                            # common.jl:66-67
-                np.copyto(st.preH, Hs)
+                np.copyto(st.preW, Ws)                            # common.jl:66
                 t1 = time.perf_counter()
-                st.update(X, Ws, Hs, phases)                      # common.jl:70
+                np.copyto(st.preH, Hs)                            # common.jl:67
                 t2 = time.perf_counter()
-                st.stop_condition(Ws, Hs, tiny)                   # common.jl:73
+                st.update(X, Ws, Hs, phases)                      # common.jl:70
+                st.stop_condition(Ws, Hs, tiny, sequential=False, phases=phases)   # common.jl:73 (np.sum form: see nmf_oracle.py)
                 t3 = time.perf_counter()
-                phases["copyto! preW, preH  common.jl:66-67"] = phases.get("copyto! preW, preH  common.jl:66-67", 0.0) + (t1 - t0)
-                phases["stop_condition      common.jl:92-111"] = phases.get("stop_condition      common.jl:92-111", 0.0) + (t3 - t2)
+                phases["copyto! preW           common.jl:66"] = phases.get("copyto! preW           common.jl:66", 0.0) + (t1 - t0)
+                phases["copyto! preH           common.jl:67"] = phases.get("copyto! preH           common.jl:67", 0.0) + (t2 - t1)
                 used += t3 - t0
                 iters += 1
             per = {n_: round(v / iters, 5) for n_, v in phases.items()}
             gemm_s = sum(v for n_, v in per.items() if n_.startswith("mul!"))
-            trials.append({"blas_threads": c, "iters": iters, "seconds_per_sample_iter": round(used / iters, 5), "phase_seconds": per,
-                           "gemm_seconds": round(gemm_s, 5), "gemm_gflops": round(12.0 * p * ns * k / gemm_s / 1e9, 1),
-                           "non_gemm_seconds": round(used / iters - gemm_s, 5)})
+            # what scales with the number of columns (every mul!, everything that touches H) and what does not (the p x k passes over W)
+            fixed_s = sum(v for n_, v in per.items() if n_.startswith(("W loop", "copyto! preW", "stop_condition W")))
+            tr = {"blas_threads": c, "iters": iters, "seconds_per_sample_iter": round(used / iters, 5), "phase_seconds": per,
+                  "gemm_seconds": round(gemm_s, 5), "gemm_gflops": round(12.0 * p * ns * k / gemm_s / 1e9, 1),
+                  "non_gemm_seconds": round(used / iters - gemm_s, 5), "column_independent_seconds": round(fixed_s, 5)}
+            if n_full:
+                tr["seconds_per_iter_full_est"] = round((used / iters - fixed_s) * (n_full / ns) + fixed_s, 5)
+            trials.append(tr)
         finally:
             if cm is not None:
                 cm.restore_original_limits()

@@ -301,24 +301,41 @@ class _MultMSEState:
         ph("W loop              :112-114", lambda: upd(W, self.XHt, self.WHHt, self.tW, lw))
         ph("mul! WH = W H       :115", lambda: np.matmul(W, H, out=self.WH))
 
-    def stop_condition(self, W, H, tol):
-        """stop_condition(W, preW, H, preH, tol) (src/common.jl:92-111) on the state's preW / preH, no allocations."""
+    def stop_condition(self, W, H, tol, sequential=True, phases=None):
+        """stop_condition(W, preW, H, preH, tol) (src/common.jl:92-111) on the state's preW / preH, no allocations.
+        sequential=True: the strict left-to-right T-precision sums of the Julia loops (np.cumsum), bit-compatible with
+        `stop_condition` above.  sequential=False: the same sums by np.sum (pairwise) -- one pass instead of a serial recurrence,
+        which is what a compiled scalar loop costs; used for TIMING only (bench.py's cpu_baseline), where the emulated recurrence
+        would bill the CPU for the emulation."""
+        import time as _t
         T = self.T
         tol = T(tol)
 
         def sums(a, b, axis, tmp):
             np.subtract(a, b, out=tmp)
             np.multiply(tmp, tmp, out=tmp)
-            np.cumsum(tmp, axis=axis, dtype=T, out=tmp)
-            dev = (tmp[-1, :] if axis == 0 else tmp[:, -1]).copy()
+            if sequential:
+                np.cumsum(tmp, axis=axis, dtype=T, out=tmp)
+                dev = (tmp[-1, :] if axis == 0 else tmp[:, -1]).copy()
+            else:
+                dev = tmp.sum(axis=axis, dtype=T)
             np.add(a, b, out=tmp)
             np.multiply(tmp, tmp, out=tmp)
-            np.cumsum(tmp, axis=axis, dtype=T, out=tmp)
-            sm = (tmp[-1, :] if axis == 0 else tmp[:, -1]).copy()
+            if sequential:
+                np.cumsum(tmp, axis=axis, dtype=T, out=tmp)
+                sm = (tmp[-1, :] if axis == 0 else tmp[:, -1]).copy()
+            else:
+                sm = tmp.sum(axis=axis, dtype=T)
             return dev, sm
 
+        t0 = _t.perf_counter()
         dw, sw = sums(W, self.preW, 0, self.sW)
+        t1 = _t.perf_counter()
         dh, sh = sums(H, self.preH, 1, self.sH)
+        t2 = _t.perf_counter()
+        if phases is not None:
+            phases["stop_condition W sums  common.jl:95-99"] = phases.get("stop_condition W sums  common.jl:95-99", 0.0) + (t1 - t0)
+            phases["stop_condition H sums  common.jl:100-104"] = phases.get("stop_condition H sums  common.jl:100-104", 0.0) + (t2 - t1)
         bad = (np.sqrt(dw) > tol * np.sqrt(sw)) | (np.sqrt(dh) > tol * np.sqrt(sh))
         return not bool(np.any(bad))
 

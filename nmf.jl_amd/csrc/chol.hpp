@@ -379,36 +379,77 @@ __global__ void potrs_prep_kernel(const T *U, const T *Dinv, T *Tm, int64_t ld, 
     }
 }
 
-// One workgroup (4 waves) per panel of NB columns of B, the K x NB panel resident in LDS for both sweeps (S[row][col], row stride
+// One workgroup (8 waves) per panel of NB columns of B, the K x NB panel resident in LDS for both sweeps (S[row][col], row stride
 // NB + 1).  Right-looking: block step i solves its 32 rows against the diagonal block (a wave owns all 32 rows of its 32 / 16
 // columns, so the solve is in place without a barrier), then ALL later block rows take their update  r_j -= Tm_ji y_i  on the matrix
-// cores, (block row, column tile) items dealt round-robin to the 4 waves.  2 barriers per step, K / 32 steps per sweep.
+// cores, (block row, column tile) items dealt round-robin to the waves.  Block column i of Tm (K x 32: every operand of step i) is
+// staged through LDS as TP[l][row] -- coalesced 16-byte loads, fragment reads with the lanes on consecutive rows -- and the NEXT
+// step's block column is requested into registers at the start of a step, so its L2 round trip runs under the step's products
+// (the first version read its fragments straight from global memory: 114 us at 16384 columns, k = 256, a dependent L2 round trip
+// per item; the product form it replaces took 55 us).  DBUF: two TP buffers (one barrier less per step) when the LDS holds them.
 // Epilogue: projectnn! (max(x, 0), NaN passes through, src/utils.jl:34-41) if clamp, store; with `old` != nullptr also
 // stop_condition's sums of every component over the panel's columns (src/common.jl:100-104), partial[(panel * ncomp + a) * 2 + {0, 1}]
 // -- the layout finalize_partials_kernel reduces.  B = sum of nslab slabs (ascending), like the split-K combine it replaces.
-template <typename T, int NB>
-__global__ __launch_bounds__(256) void potrs_panel_kernel(const T *Tm, int64_t ldt, const T *B, int nslab, int64_t slab_stride, int64_t ldb, T *Xout,
-                                                          const T *old, int K, int clamp, double *stat_partial, int ncomp, const int *done) {
+template <typename T, int NB, int POTRS_THREADS>
+__global__ __launch_bounds__(POTRS_THREADS) void potrs_panel_kernel(const T *Tm, int64_t ldt, const T *B, int nslab, int64_t slab_stride, int64_t ldb, T *Xout,
+                                                                    const T *old, int K, int clamp, int dbuf, double *stat_partial, int ncomp, const int *done) {
     NMFX_DONE_GUARD(done);
     using M = Mfma<T>;
-    constexpr int MT = M::MT, KS = M::KS, SUB = 32 / MT, NTN = NB / MT, LDP = NB + 1;
+    constexpr int MT = M::MT, KS = M::KS, SUB = 32 / MT, NTN = NB / MT, LDP = NB + 1, NW = POTRS_THREADS / 64, V = 16 / (int)sizeof(T);
+    constexpr int MAXQ = 8;   // 16-byte chunks of a block column per thread: K * 32 / V / THREADS <= 8, checked by the host
+    using vec_t = typename M::vec_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
-    T *S = reinterpret_cast<T *>(chol_smem);
+    T *TP = reinterpret_cast<T *>(chol_smem);                 // [dbuf ? 2 : 1][32][K]
+    T *S = TP + (size_t)(dbuf ? 2 : 1) * 32 * K;              // [K][LDP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane % MT, ks = lane / MT;
     const int64_t c0 = (int64_t)blockIdx.x * NB;
-    const int nb = K / 32;
+    const int nb = K / 32, nsteps = 2 * nb;
+    const int nq = K * 32 / V / POTRS_THREADS;                // chunks per thread (K is a multiple of 64)
+    auto step_col = [&](int s) { return s < nb ? s : 2 * nb - 1 - s; };
+    vec_t pre[MAXQ];
+    auto tp_load = [&](int s) {                               // block column of step s -> registers (chunk c: column l = c / (K / V), rows V * (c % (K / V)) ..)
+        const int i = step_col(s);
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q)
+            if (q < nq) {
+                const int c = tid + POTRS_THREADS * q, l = c / (K / V), r = V * (c % (K / V));
+                pre[q] = *reinterpret_cast<const vec_t *>(Tm + r + (int64_t)(32 * i + l) * ldt);
+            }
+    };
+    auto tp_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q)
+            if (q < nq) {
+                const int c = tid + POTRS_THREADS * q, l = c / (K / V), r = V * (c % (K / V));
+                *reinterpret_cast<vec_t *>(TP + (size_t)buf * 32 * K + l * K + r) = pre[q];
+            }
+    };
+    tp_load(0);
     // panel in: column c of B is contiguous in the component a
-    for (int e = tid; e < K * NB; e += 256) {
-        const int a = e % K, c = e / K;
-        const int64_t o = a + (c0 + c) * ldb;
-        T v = B[o];
-        for (int q = 1; q < nslab; ++q) v += B[(int64_t)q * slab_stride + o];
-        S[a * LDP + c] = v;
+    for (int e0 = tid; e0 < K * NB; e0 += 8 * POTRS_THREADS) {     // 8 independent loads per trip (K * NB is a multiple of 8 * 512)
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * POTRS_THREADS;
+            v[u] = B[e % K + (c0 + e / K) * ldb];
+        }
+        for (int q = 1; q < nslab; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * POTRS_THREADS;
+                v[u] += B[(int64_t)q * slab_stride + e % K + (c0 + e / K) * ldb];
+            }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * POTRS_THREADS;
+            S[(e % K) * LDP + e / K] = v[u];
+        }
     }
+    tp_store(0);
     __syncthreads();
     auto acc_row = [&](int reg) { return (sizeof(T) == 4) ? ((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) : ((lane >> 4) + 4 * reg); };
     // acc[si] (rows 32 jb + si*MT .., columns nj*MT ..) = sum_l Tm(32 jb + a, 32 ib + l) S(32 ib + l, c);  tri: 0 none, +1 keep a >= l, -1 keep a <= l
-    auto product = [&](typename M::acc_t (&acc)[SUB], int jb, int ib, int nj, int tri) {
+    auto product = [&](typename M::acc_t (&acc)[SUB], const T *tp, int jb, int ib, int nj, int tri) {
 #pragma unroll
         for (int si = 0; si < SUB; ++si)
 #pragma unroll
@@ -420,7 +461,7 @@ __global__ __launch_bounds__(256) void potrs_panel_kernel(const T *Tm, int64_t l
 #pragma unroll
             for (int si = 0; si < SUB; ++si) {
                 const int a = si * MT + li;
-                T v = Tm[(int64_t)(32 * jb + a) + (int64_t)(32 * ib + l) * ldt];
+                T v = tp[l * K + 32 * jb + a];
                 if (tri > 0) v = (a >= l) ? v : (T)0;
                 if (tri < 0) v = (a <= l) ? v : (T)0;
                 af[kk][si] = v;
@@ -432,48 +473,60 @@ __global__ __launch_bounds__(256) void potrs_panel_kernel(const T *Tm, int64_t l
 #pragma unroll
             for (int si = 0; si < SUB; ++si) acc[si] = M::mma(af[kk][si], bf[kk], acc[si]);
     };
-    for (int sweep = 0; sweep < 2; ++sweep) {
-        for (int step = 0; step < nb; ++step) {
-            const int i = sweep == 0 ? step : nb - 1 - step;
-            // diagonal solve, in place: wave w owns column tiles w, w + 4, ...
-            for (int nj = wave; nj < NTN; nj += 4) {
-                typename M::acc_t acc[SUB];
-                product(acc, i, i, nj, sweep == 0 ? 1 : -1);
+    for (int s = 0; s < nsteps; ++s) {
+        const int sweep = s < nb ? 0 : 1, step = s < nb ? s : s - nb, i = step_col(s);
+        const int buf = dbuf ? (s & 1) : 0;
+        const T *tp = TP + (size_t)buf * 32 * K;
+        if (s + 1 < nsteps) tp_load(s + 1);
+        // diagonal solve, in place: wave w owns column tiles w, w + NW, ...
+        for (int nj = wave; nj < NTN; nj += NW) {
+            typename M::acc_t acc[SUB];
+            product(acc, tp, i, i, nj, sweep == 0 ? 1 : -1);
 #pragma unroll
-                for (int si = 0; si < SUB; ++si)
+            for (int si = 0; si < SUB; ++si)
 #pragma unroll
-                    for (int reg = 0; reg < M::NACC; ++reg) S[(32 * i + si * MT + acc_row(reg)) * LDP + nj * MT + li] = acc[si][reg];
-            }
-            __syncthreads();
-            // trailing update of every block row still to be solved in this sweep
-            const int nrem = nb - 1 - step;
-            for (int it = wave; it < nrem * NTN; it += 4) {
-                const int jr = it / NTN, nj = it % NTN;
-                const int j = sweep == 0 ? i + 1 + jr : i - 1 - jr;
-                typename M::acc_t acc[SUB];
-                product(acc, j, i, nj, 0);
-#pragma unroll
-                for (int si = 0; si < SUB; ++si)
-#pragma unroll
-                    for (int reg = 0; reg < M::NACC; ++reg) S[(32 * j + si * MT + acc_row(reg)) * LDP + nj * MT + li] -= acc[si][reg];
-            }
-            __syncthreads();
+                for (int reg = 0; reg < M::NACC; ++reg) S[(32 * i + si * MT + acc_row(reg)) * LDP + nj * MT + li] = acc[si][reg];
         }
+        __syncthreads();
+        // trailing update of every block row still to be solved in this sweep
+        const int nrem = nb - 1 - step;
+        for (int it = wave; it < nrem * NTN; it += NW) {
+            const int jr = it / NTN, nj = it % NTN;
+            const int j = sweep == 0 ? i + 1 + jr : i - 1 - jr;
+            typename M::acc_t acc[SUB];
+            product(acc, tp, j, i, nj, 0);
+#pragma unroll
+            for (int si = 0; si < SUB; ++si)
+#pragma unroll
+                for (int reg = 0; reg < M::NACC; ++reg) S[(32 * j + si * MT + acc_row(reg)) * LDP + nj * MT + li] -= acc[si][reg];
+        }
+        if (s + 1 < nsteps) {
+            if (!dbuf) __syncthreads();                       // single buffer: every fragment read of this step first
+            tp_store(dbuf ? (buf ^ 1) : 0);
+        }
+        __syncthreads();
     }
-    // panel out: thread = component
-    for (int a = tid; a < K; a += 256) {
+    // panel out: thread = component; 8 columns per trip so that the loads of `old` are in flight together (one column per trip
+    // serialised a global round trip per column behind the store of the previous one: 38 of the first version's 103 us)
+    for (int a = tid; a < K; a += POTRS_THREADS) {
         double dev = 0.0, sum = 0.0;
-        for (int c = 0; c < NB; ++c) {
-            T v = S[a * LDP + c];
-            if (clamp) v = (v < (T)0) ? (T)0 : v;
-            const int64_t o = a + (c0 + c) * ldb;
-            if (old != nullptr) {
-                const T ov = old[o];
-                const T d = v - ov, sp = v + ov;
+        for (int cb = 0; cb < NB; cb += 8) {
+            T ov[8], v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ov[u] = (old != nullptr) ? old[a + (c0 + cb + u) * ldb] : (T)0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = S[a * LDP + cb + u];
+                if (clamp) v[u] = (v[u] < (T)0) ? (T)0 : v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) Xout[a + (c0 + cb + u) * ldb] = v[u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const T d = v[u] - ov[u], sp = v[u] + ov[u];
                 dev += (double)(T)(d * d);
                 sum += (double)(T)(sp * sp);
             }
-            Xout[o] = v;
         }
         if (old != nullptr && stat_partial != nullptr) {
             stat_partial[((int64_t)blockIdx.x * ncomp + a) * 2] = dev;

@@ -78,6 +78,7 @@ template <typename T> struct GemmArgs {
     int tail_per = 0;       // k-tiles of one tail piece (one piece per block)
     int tail_main = 0;      // > 0: the grid is `tail_main` blocks SHORT of tiles * splits; the missing (tile, split) items -- the
                             // last ones -- are dealt out as tail pieces instead (a grid that must leave some CUs free)
+    int prio = 0;           // wave priority pattern of the launch (see the kernel): 0 none
 };
 
 // what an epilogue may need to know about the block / wave it runs in
@@ -290,6 +291,13 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
     using LoadB = TileLoader<T, LB, BC, NT>;
 
     if (g.done != nullptr && *reinterpret_cast<const volatile int *>(g.done) != 0) return;
+    // Two blocks share a CU for the whole launch (one wave of each per SIMD).  With equal priorities the SIMD's issue arbiter
+    // alternates between them; raising ONE of the two lets that wave run as if it were alone (an in-order wave keeps the matrix
+    // pipe ~85-90 % busy by itself) while the other fills its gaps.  1: second half of the grid; 2: odd blocks; 3: every block.
+    if (g.prio == 1) { if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(2); }
+    else if (g.prio == 2) { if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2); }
+    else if (g.prio == 3) __builtin_amdgcn_s_setprio(2);
+    else if (g.prio == 4) { if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(2); }
     T xalpha = (T)0;
     if constexpr (AUX != 0) xalpha = (T)*g.alpha_ptr;
     __shared__ __attribute__((aligned(16))) T smem[2 * (BR + BC) * BK];

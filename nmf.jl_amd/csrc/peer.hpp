@@ -230,6 +230,7 @@ struct PeerComm : Comm {
         double tmo_s = 30.0;
         if (const char *e = std::getenv("NMFX_P2P_TIMEOUT_S")) tmo_s = std::max(0.01, std::atof(e));
         timeout_ticks = (unsigned long long)(tmo_s * 1e8);   // wall_clock64: 100 MHz
+        if (const char *e = std::getenv("NMFX_P2P_TINY")) tiny_enabled = std::atoi(e) != 0;
         // uncached: remote stores and local reads both bypass the (non-coherent) L2s; NMFX_P2P_MEM=finegrained|plain for experiments
         const char *kind = std::getenv("NMFX_P2P_MEM");
         hipError_t e;
@@ -295,7 +296,8 @@ struct PeerComm : Comm {
         ck(hipMemcpy(&a, mine + PEER_ABORT_OFF, 4, hipMemcpyDeviceToHost), "hipMemcpy");
         if (a) throw CommError{"peer exchange timed out: a rank did not arrive within NMFX_P2P_TIMEOUT_S (default 30 s)"};
     }
-    bool tiny_capable() const override { return attached; }
+    bool tiny_enabled = true;   // NMFX_P2P_TINY=0: the line-search scalars as ordinary (window) all-reduces of 3 doubles -- A/B of the in-kernel form
+    bool tiny_capable() const override { return attached && tiny_enabled; }
     TinyAR tiny() override {
         TinyAR t;
         t.win = win;

@@ -55,11 +55,13 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
 // clamp = projectnn!; old != nullptr: stop_condition's sums against `old` into stat_part (finalised by stats_h_finalize(N / NB))
 template <typename T> int Solver<T>::spd_solve_left_potrs(const T *Tm, const T *B, T *out, bool clamp, const T *old, const int *done) {
     constexpr int NB = POTRS_NB;
-    const size_t lds = (size_t)K * (NB + 1) * sizeof(T);
+    const size_t s_bytes = (size_t)K * (NB + 1) * sizeof(T), tp_bytes = (size_t)32 * K * sizeof(T);
+    const bool dbuf = s_bytes + 2 * tp_bytes <= (size_t)160 * 1024;
+    const size_t lds = s_bytes + (dbuf ? 2 : 1) * tp_bytes;
     timed("potrs_clampH", 2.0 * (double)K * K * N, 3.0 * K * N * sizeof(T), [&] {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrs_panel_kernel<T, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((potrs_panel_kernel<T, NB>), dim3((unsigned)(N / NB)), dim3(256), lds, stream, Tm, K, B, 1, (int64_t)0, K, out, old, (int)K, clamp ? 1 : 0,
-                           old ? stat_part.p : (double *)nullptr, (int)K, done);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrs_panel_kernel<T, NB, POTRS_NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((potrs_panel_kernel<T, NB, POTRS_NT>), dim3((unsigned)(N / NB)), dim3(POTRS_NT), lds, stream, Tm, K, B, 1, (int64_t)0, K, out, old, (int)K, clamp ? 1 : 0,
+                           dbuf ? 1 : 0, old ? stat_part.p : (double *)nullptr, (int)K, done);
         HIP_TRY(hipGetLastError());
     });
     return (int)(N / NB);
@@ -151,7 +153,11 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // order (its Gram travels inside the one packed all-reduce that follows the product).
     const bool under = chol_slots > 0 && !use_bf16x3() && K % 128 == 0 && (!sharded() || rs);
     if (under) ensure_fstream();
-    const bool subst = potrs_ok();   // H solve by triangular substitution (potrs!) instead of Uinv (Uinv' B)
+    // H solve by triangular substitution (potrs!, the reference's route) instead of Uinv (Uinv' B): opt-in for the ITERATION
+    // (NMFX_POTRS=1) -- a panel's two sweeps are a chain of 2 K / 32 dependent block steps that one workgroup per CU cannot overlap
+    // with anything: 79 us at 16384 columns, k = 256, Float32 against 55 us for the two k x k x n products (scripts/kbench/potrs_bench.hip;
+    // Float64, k = 128: 26 against 28 us).  nmfx_pdsolve, the exported pdsolve!, always takes the substitution route.
+    const bool subst = potrs_iter && potrs_ok();
     auto factor_under = [&](T *G, T lambda, const char *t1, const char *t2, bool with_potri) {
         HIP_TRY(hipEventRecord(ev_fork, stream));
         HIP_TRY(hipStreamWaitEvent(fstream, ev_fork, 0));

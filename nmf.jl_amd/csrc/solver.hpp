@@ -141,7 +141,7 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = std::getenv("NMFX_STREAM_WH")) stream_wh = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
-        if (const char *e = std::getenv("NMFX_POTRS")) potrs_enabled = std::atoi(e) != 0;
+        if (const char *e = std::getenv("NMFX_POTRS")) { potrs_enabled = std::atoi(e) != 0; potrs_iter = std::atoi(e) == 1; }
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
@@ -1089,9 +1089,14 @@ template <typename T> class Solver : public SolverBase {
     void spd_factor(T *A, T lambda, T *Uinv, const char *tag_potrf, const char *tag_trtri, const int *done, T *Tm = nullptr);
     // pdsolve!'s potrs! by blocked triangular substitution (chol.hpp: potrs_panel_kernel): the K x NB panel of the right-hand side lives in
     // one workgroup's LDS; larger k keeps the product form Uinv (Uinv' B).  NMFX_POTRS=0 forces the product form (A/B, tests).
-    static constexpr int POTRS_NB = sizeof(T) == 4 ? 64 : 32;
-    bool potrs_enabled = true;
-    bool potrs_ok() const { return potrs_enabled && K % 32 == 0 && N % POTRS_NB == 0 && (size_t)K * (POTRS_NB + 1) * sizeof(T) <= (size_t)160 * 1024; }
+    static constexpr int POTRS_NB = sizeof(T) == 4 ? 64 : 32, POTRS_NT = 512;
+    bool potrs_enabled = true;            // NMFX_POTRS=0: the product form everywhere (A/B)
+    bool potrs_iter = false;              // NMFX_POTRS=1: ProjectedALS's H solve by substitution as well (default: nmfx_pdsolve only)
+    // the panel (K x (NB + 1)) and one block column of the packed factor (32 x K) in LDS; 16-byte chunks of a block column: <= 8 per thread
+    bool potrs_ok() const {
+        return potrs_enabled && K % 64 == 0 && N % POTRS_NB == 0 && (size_t)K * (POTRS_NB + 1 + 32) * sizeof(T) <= (size_t)160 * 1024 &&
+               K * 32 / (16 / (int64_t)sizeof(T)) / 512 <= 8 && K * 32 / (16 / (int64_t)sizeof(T)) % 512 == 0;
+    }
     int spd_solve_left_potrs(const T *Tm, const T *B, T *out, bool clamp, const T *old, const int *done);
     void spd_solve_left(const T *Uinv, const T *B, T *Y, T *out, bool clamp, const int *done);
     void spd_solve_right(const T *Uinv, T *invA, const T *A, T *out, int64_t rows, bool clamp, const int *done);

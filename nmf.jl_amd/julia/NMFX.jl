@@ -242,4 +242,16 @@ free_local_group(g::Ptr{Cvoid}) = ccall((:nmfx_local_group_destroy, libnmfx), Cv
 attach!(ctx::Context, g::Ptr{Cvoid}, rank::Integer) =
     check(ccall((:nmfx_comm_init_local, libnmfx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), ctx.h, g, rank), ctx.h)
 
+# ---- peer-to-peer exchange (include/nmfx.h nmfx_comm_p2p_*; DESIGN.md section 4): one process per GPU, the handles travel through
+# the host (e.g. MPI.Allgather); `p2p_attach!` after every rank's `p2p_export` and before the X upload.
+p2p_init!(ctx::Context, rank::Integer, nranks::Integer) =
+    check(ccall((:nmfx_comm_init_p2p, libnmfx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx.h, rank, nranks), ctx.h)
+function p2p_export(ctx::Context)
+    h = Vector{UInt8}(undef, 128)
+    check(ccall((:nmfx_comm_p2p_export, libnmfx), Cint, (Ptr{Cvoid}, Ptr{UInt8}), ctx.h, h), ctx.h)
+    h
+end
+p2p_attach!(ctx::Context, handles::Vector{UInt8}) =
+    check(ccall((:nmfx_comm_p2p_attach, libnmfx), Cint, (Ptr{Cvoid}, Ptr{UInt8}), ctx.h, handles), ctx.h)
+
 end # module

@@ -9,7 +9,7 @@
 using namespace nmfx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-static int g_mode = 0, g_stagger = 0;
+static int g_mode = 0, g_stagger = 0, g_prio = 0;
 template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC>
 double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool c_fastest, int reps) {
     // A: R rows, B: C rows; KCONTIG -> ld = Kd, KSTRIDED -> ld = rows
@@ -27,7 +27,7 @@ double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool 
     CK(hipMemcpy(B, h.data(), (size_t)C * Kd * sizeof(T), hipMemcpyHostToDevice));
     GemmArgs<T> g;
     g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.tiles_r = (int)(R / BR); g.tiles_c = (int)(C / BC);
-    g.splits = splits; g.kchunk = (int)(Kd / splits); g.c_fastest = c_fastest; g.done = nullptr; 
+    g.splits = splits; g.kchunk = (int)(Kd / splits); g.c_fastest = c_fastest; g.done = nullptr; g.prio = g_prio;
     EpiStore<T> e{D, C, R * C, nullptr};
     T *D2 = nullptr;
     if (g_stagger && C <= 1024) {   // Gram tail (only meaningful when the small operand is B): extra tiles A2 = B (the small operand), (C/BC)^2 tail tiles
@@ -81,7 +81,21 @@ double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool 
 
 int main(int argc, char **argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 6;
+    const int what = argc > 2 ? atoi(argv[2]) : 0;
     g_mode = 1;
+    if (what == 1) {   // wave-priority patterns on the two big products and their 8-rank shard shapes (A/B inside one process, interleaved)
+        g_stagger = 1;
+        for (int round = 0; round < 3; ++round)
+            for (int pr : {0, 1, 2, 4, 3}) {
+                g_prio = pr;
+                printf("--- prio pattern %d (round %d)\n", pr, round);
+                run<float, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN big (WtX) 128x128", 16384, 256, 16384, 2, true, reps);
+                run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT big (XHt) 128x128", 256, 16384, 16384, 2, false, reps);
+                run<float, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN shard/8 128x128", 2048, 256, 16384, 16, true, reps);
+                run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT shard/8 128x128 no split", 256, 16384, 2048, 1, false, reps);
+            }
+        return 0;
+    }
     for (int st : {0, 1}) {
     printf("--- gram tail %d\n", st);
     g_stagger = st;
@@ -92,12 +106,6 @@ int main(int argc, char **argv) {
     run<float, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN shard/8 128x128", 2048, 256, 16384, 16, true, reps);
     run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT shard/8 128x128", 256, 16384, 2048, 2, false, reps);
     run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT shard/8 128x128 no split", 256, 16384, 2048, 1, false, reps);
-    run<float, KSTRIDED, KSTRIDED, 64, 128, 1, 4>("NT shard/8 64x128 no split", 256, 16384, 2048, 1, false, reps);
-    run<float, KSTRIDED, KSTRIDED, 128, 64, 4, 1>("NT shard/8 128x64 no split", 256, 16384, 2048, 1, false, reps);
-    run<float, KCONTIG, KCONTIG, 128, 64, 4, 1>("TN shard/8 128x64 8 splits", 2048, 256, 16384, 8, true, reps);
-    run<float, KCONTIG, KCONTIG, 64, 128, 1, 4>("TN shard/8 64x128 8 splits", 2048, 256, 16384, 8, true, reps);
-    run<float, KCONTIG, KCONTIG, 256, 64, 4, 1>("TN C2 (k=64) 256x64", 4096, 64, 4096, 8, true, reps);
-    run<float, KSTRIDED, KSTRIDED, 64, 256, 1, 4>("NT C2 (k=64) 64x256", 64, 4096, 4096, 8, false, reps);
     run<double, KCONTIG, KCONTIG, 128, 128, 2, 2>("TN f64 128x128", 8192, 256, 8192, 4, true, reps);
     run<double, KSTRIDED, KSTRIDED, 128, 128, 2, 2>("NT f64 128x128", 256, 8192, 8192, 4, false, reps);
     }

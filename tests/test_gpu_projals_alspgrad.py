@@ -51,6 +51,29 @@ def test_projals_trajectory(built, T, shape):
     assert np.all(Wg >= 0) and np.all(Hg >= 0)
 
 
+@pytest.mark.parametrize("T,shape", [(np.float64, (300, 260, 70)), (np.float32, (300, 260, 70)), (np.float64, (200, 300, 130)), (np.float32, (130, 515, 8))])
+def test_projals_substitution_route(built, T, shape, monkeypatch):
+    """pdsolve! = potrf! + potrs! (src/utils.jl:63-70): with NMFX_POTRS=1 the iteration's H solve runs the two blocked triangular
+    substitutions (chol.hpp: potrs_panel_kernel) instead of Uinv (Uinv' B) -- the same solve to rounding: against the default route
+    and against the oracle (whose pdsolve! is LAPACK's potrs)."""
+    p, n, k = shape
+    X, W0, H0 = planted(p, n, k, T, seed=9 + p, normalize=False, zeroh=True)
+    lam = 0.05
+    alg = nmfx.ProjectedALS(T, maxiter=10, tol=1e-30, lambda_w=lam, lambda_h=lam)
+    Wa, Ha = W0.copy(order="F"), H0.copy(order="F")
+    ra = nmfx.solve(alg, X, Wa, Ha, track_objective=True)
+    monkeypatch.setenv("NMFX_POTRS", "1")
+    Wb, Hb = W0.copy(order="F"), H0.copy(order="F")
+    rb = nmfx.solve(alg, X, Wb, Hb, track_objective=True)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=10, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
+    assert ra.niters == rb.niters == ro.niters == 10
+    tol = 1e-9 if T == np.float64 else 2e-2      # f32: cond(Gram) * eps (4e4 * 1.2e-7 at k = 70), both routes
+    assert rel_trace_err(rb.trace, ra.trace) < tol
+    assert rel_trace_err(rb.trace, ro.trace) < (1e-7 if T == np.float64 else tol)
+    assert np.all(Wb >= 0) and np.all(Hb >= 0)
+
+
 @pytest.mark.parametrize("T,k", [(np.float64, 520), (np.float32, 1160), (np.float64, 640), (np.float32, 1300)])
 def test_projals_k_beyond_one_lds_column(built, T, k):
     """The reference's pdsolve! / pdrsolve! (src/utils.jl:63-84) have no size limit; the blocked triangular inverse used to refuse

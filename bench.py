@@ -292,9 +292,23 @@ def main():
     res, _ = ctx.iterate(algid, opts(a.steps))
     barrier()
     dt = time.perf_counter() - t0
-    wd.disarm()
     prof = ctx.profile_get()
     ctx.profile_enable(0)
+    # the same K steps once more WITHOUT the hipEvent brackets: what the loop costs when nobody watches (on paths with a second
+    # stream -- ProjectedALS -- a bracket on the main stream delays the side stream's ordering events; both numbers go into the line)
+    dt_plain = None
+    if not a.no_events:
+        barrier()
+        t0 = time.perf_counter()
+        res2, _ = ctx.iterate(algid, opts(a.steps))
+        barrier()
+        dt_plain = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt_plain], device=("cpu" if (dev_sim or dev_gloo) else device), dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_plain = float(tt.item())
+    wd.disarm()
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=("cpu" if (dev_sim or dev_gloo) else device), dtype=torch.float64)
@@ -369,6 +383,10 @@ def main():
                                    f"column-sharded over {world} GPU(s)", "p": p, "n": n, "k": k,
                        "parallelism": f"colshard{world}" + (f"+{mode}+{transport}" if (world > 1 or shards > 1) else ""), "precision": a.precision,
                        "check_every": (a.check_every if a.check_every < (1 << 30) else "never (stop rule evaluated on the device only)")},
+            # `value` / `ms_per_step` are the region with the sampled hipEvent brackets (the roofline's launch times come from it);
+            # the same K steps without any bracket right behind it:
+            "ms_per_step_no_events": (round(dt_plain / a.steps * 1e3, 4) if dt_plain is not None else round(ms, 4)),
+            "event_brackets": ("none" if a.no_events else ("every launch" if a.all_events else ("1 launch in 2 of the dominant GEMMs" if a.steps <= 32 else "1 launch in 8 of the dominant GEMMs"))),
             "gflops_algorithmic": round(f_alg * a.steps / dt / 1e9, 1),
             "frac_of_mfma_peak": round(f_alg * a.steps / dt / 1e12 / (((2500.0 / 3.0) if a.precision == "bf16x3" else
                                                                         (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6)) * world), 4),

@@ -426,23 +426,23 @@ __global__ __launch_bounds__(POTRS_THREADS) void potrs_panel_kernel(const T *Tm,
     };
     tp_load(0);
     // panel in: column c of B is contiguous in the component a
-    for (int e0 = tid; e0 < K * NB; e0 += 8 * POTRS_THREADS) {     // 8 independent loads per trip (K * NB is a multiple of 8 * 512)
+    for (int e0 = tid; e0 < K * NB; e0 += 8 * POTRS_THREADS) {     // 8 independent loads per trip
         T v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * POTRS_THREADS;
-            v[u] = B[e % K + (c0 + e / K) * ldb];
+            v[u] = (e < K * NB) ? B[e % K + (c0 + e / K) * ldb] : (T)0;
         }
         for (int q = 1; q < nslab; ++q)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = e0 + u * POTRS_THREADS;
-                v[u] += B[(int64_t)q * slab_stride + e % K + (c0 + e / K) * ldb];
+                if (e < K * NB) v[u] += B[(int64_t)q * slab_stride + e % K + (c0 + e / K) * ldb];
             }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * POTRS_THREADS;
-            S[(e % K) * LDP + e / K] = v[u];
+            if (e < K * NB) S[(e % K) * LDP + e / K] = v[u];
         }
     }
     tp_store(0);

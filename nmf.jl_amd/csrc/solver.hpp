@@ -141,6 +141,7 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = std::getenv("NMFX_STREAM_WH")) stream_wh = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
+        if (const char *e = std::getenv("NMFX_K_GRANULE")) k_granule = (std::atoi(e) == 128) ? 128 : 64;
         if (const char *e = std::getenv("NMFX_POTRS")) { potrs_enabled = std::atoi(e) != 0; potrs_iter = std::atoi(e) == 1; }
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
@@ -156,7 +157,11 @@ template <typename T> class Solver : public SolverBase {
     void layout(int64_t row_mult) {
         P = round_up(p, row_mult);
         N = round_up(n, 256);
-        K = (k <= 64) ? 64 : round_up(k, 128);
+        // K: multiples of 64 (round 4; multiples of 128 above 64 before: k = 129 ... 192 paid for 256 components in every product).
+        // K % 128 == 0 keeps every fused path (Gram riding in the big launches, the persistent W*H kernel, the factorisations under the
+        // products, the fused row-sharded step); the 64-granular sizes in between (192, 320, ...) run the general sequence on
+        // 128 x 64 / 64 x 128 / 64 x 64 tiles.  NMFX_K_GRANULE=128 restores the old padding (A/B).
+        K = (k <= 64) ? 64 : round_up(k, k_granule);
         // the fused epilogues address a wave tile with 32-bit byte offsets (gemm_mfma.hpp, "Epilogue addressing"):
         // 256 rows x leading dimension must stay below 4 GiB.  Leading dimensions are P (W, X, Q) and K (H, Gram).
         if ((uint64_t)std::max(P, K) * sizeof(T) * 256 >= (1ull << 32))
@@ -433,6 +438,7 @@ template <typename T> class Solver : public SolverBase {
 
   private:
     int64_t p, n, k, P, N, K;
+    int64_t k_granule = 64;
     int device, num_cu = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev_beg = nullptr, ev_end = nullptr;
@@ -664,6 +670,16 @@ template <typename T> class Solver : public SolverBase {
                 launch_gemm_cfg<LA, LB, 64, 256, 1, 4, AUX>(g, epi);
             } else if (R == 64 && C == 64) {
                 g.tiles_r = 1; g.tiles_c = 1;
+                launch_gemm_cfg<LA, LB, 64, 64, 2, 2, AUX>(g, epi);
+            } else if (R % 128 == 0 && C % 64 == 0 && seg.tail_tiles == 0) {
+                // one output dimension is a multiple of 64 only (K = 192, 320, ...: the 64-granular component padding): half-width tiles
+                g.tiles_r = (int)(R / 128); g.tiles_c = (int)(C / 64);
+                launch_gemm_cfg<LA, LB, 128, 64, 4, 1, AUX>(g, epi);
+            } else if (R % 64 == 0 && C % 128 == 0 && seg.tail_tiles == 0) {
+                g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 128);
+                launch_gemm_cfg<LA, LB, 64, 128, 1, 4, AUX>(g, epi);
+            } else if (R % 64 == 0 && C % 64 == 0 && seg.tail_tiles == 0) {
+                g.tiles_r = (int)(R / 64); g.tiles_c = (int)(C / 64);
                 launch_gemm_cfg<LA, LB, 64, 64, 2, 2, AUX>(g, epi);
             } else {
                 throw StatusError{NMFX_ERR_UNSUPPORTED, "internal: no tile configuration for this GEMM shape"};

@@ -68,7 +68,7 @@ def test_projals_substitution_route(built, T, shape, monkeypatch):
     Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
     ro = orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=10, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
     assert ra.niters == rb.niters == ro.niters == 10
-    tol = 1e-9 if T == np.float64 else 2e-2      # f32: cond(Gram) * eps (4e4 * 1.2e-7 at k = 70), both routes
+    tol = 1e-6 if T == np.float64 else 2e-2      # cond(Gram) * eps: 4e4 * 1.2e-7 at k = 70 in f32; k = 130 of p = 200 rows: 2e-8 measured in f64
     assert rel_trace_err(rb.trace, ra.trace) < tol
     assert rel_trace_err(rb.trace, ro.trace) < (1e-7 if T == np.float64 else tol)
     assert np.all(Wb >= 0) and np.all(Hb >= 0)

@@ -43,7 +43,7 @@ void Solver<T>::cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<co
         // that of ONE workgroup's rows whatever the number of workgroups (<= one per CU), so it also wins on small problems
         // (measured in Float32, ms per iteration old -> new: 1024^2 k=64 0.131 -> 0.109; 4096^2 k=256 0.469 -> 0.342; 8192 x 2048 k=512
         // 1.755 -> 0.800; 16384^2 k=256 2.611 -> 2.237).  NMFX_CD_BLOCKED=0 keeps the row-chain kernels.
-        const bool shape = (K == 64 || K == 128 || K == 256 || K == 384 || K == 512);
+        const bool shape = (K == 64 || K == 128 || K == 192 || K == 256 || K == 320 || K == 384 || K == 512);
         if (shape && cd_blocked != 0) {
             auto launch = [&](auto KGC, auto ROWSC) {
                 constexpr int KG = decltype(KGC)::value, ROWS = decltype(ROWSC)::value;
@@ -58,12 +58,15 @@ void Solver<T>::cd_sweep(SampleView<const T> Zo, SampleView<T> Zn, SampleView<co
             using R32 = std::integral_constant<int, 32>;
             if (K == 64) launch(std::integral_constant<int, 64 / GR>{}, R64{});
             else if (K == 128) launch(std::integral_constant<int, 128 / GR>{}, R64{});
+            else if (K == 192) launch(std::integral_constant<int, 192 / GR>{}, R64{});
             else if (K == 256) launch(std::integral_constant<int, 256 / GR>{}, R64{});
             else if constexpr (sizeof(T) == 4) {
-                if (K == 384) launch(std::integral_constant<int, 384 / GR>{}, R64{});
+                if (K == 320) launch(std::integral_constant<int, 320 / GR>{}, R64{});
+                else if (K == 384) launch(std::integral_constant<int, 384 / GR>{}, R64{});
                 else launch(std::integral_constant<int, 512 / GR>{}, R64{});
-            } else {                                      // Float64: 64 rows x 384 (512) components no longer fit 160 KiB
-                if (K == 384) launch(std::integral_constant<int, 384 / GR>{}, R32{});
+            } else {                                      // Float64: 64 rows x 320 (384, 512) components no longer fit 160 KiB
+                if (K == 320) launch(std::integral_constant<int, 320 / GR>{}, R32{});
+                else if (K == 384) launch(std::integral_constant<int, 384 / GR>{}, R32{});
                 else launch(std::integral_constant<int, 512 / GR>{}, R32{});
             }
             return;

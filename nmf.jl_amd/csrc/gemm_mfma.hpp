@@ -200,6 +200,55 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
           }
         }
     }
+    // Buffer-load form of load() (plain operands only): the 32-bit byte offsets of a thread's chunks relative to the tile's first
+    // element at k-tile 0 are loop invariant (offsets()), the k-tile's position goes into the scalar base of a buffer descriptor, so a
+    // k-tile costs no vector address arithmetic (the pointer form spends two 64-bit VALU adds per load and a 64-bit VGPR pair).
+    static __device__ __forceinline__ void offsets(uint32_t (&off)[PER_THREAD], int64_t ld, int tid) {
+        if constexpr (LAYOUT == KCONTIG) {
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) {
+                const int s = tid + NTHREADS * i;
+                constexpr int CPR = BK / VEC;
+                const int row = s / CPR, cpos = s % CPR, c = cpos ^ swz8(row);
+                off[i] = (uint32_t)(((int64_t)row * ld + c * VEC) * (int64_t)sizeof(T));
+            }
+        } else if constexpr (kstrided_micro<T, ROWS, NTHREADS>()) {
+            constexpr int RPV = ROWS / VEC;
+#pragma unroll
+            for (int m = 0; m < PER_THREAD / VEC; ++m) {
+                const int mt = tid + NTHREADS * m, kq = mt / RPV, r4 = mt % RPV;
+#pragma unroll
+                for (int ek = 0; ek < VEC; ++ek) off[m * VEC + ek] = (uint32_t)(((int64_t)(kq * VEC + ek) * ld + r4 * VEC) * (int64_t)sizeof(T));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) {
+                const int s = tid + NTHREADS * i;
+                constexpr int CPK = ROWS / VEC;
+                const int kk = s / CPK, r4 = s % CPK;
+                off[i] = (uint32_t)(((int64_t)kk * ld + r4 * VEC) * (int64_t)sizeof(T));
+            }
+        }
+    }
+    // tile base of k-tile k0 (what the descriptor points at)
+    static __device__ __forceinline__ const T *tile_base(const T *base, int64_t ld, int64_t row0, int64_t k0) {
+        if constexpr (LAYOUT == KCONTIG) return base + row0 * ld + k0;
+        else return base + k0 * ld + row0;
+    }
+    // AUX: the operand computed on the fly from two arrays with identical addressing (see load()): `auxtb` = the tile base in the
+    // second array
+    template <bool AUX = false>
+    static __device__ __forceinline__ void load_buf(vec_t (&r)[PER_THREAD], const T *tb, const uint32_t (&off)[PER_THREAD], const T *auxtb = nullptr,
+                                                    T alpha = (T)0) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)tb, 0, -1, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) r[i] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off[i], 0, 0));
+        if constexpr (AUX) {
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)auxtb, 0, -1, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) xform(r[i], __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off[i], 0, 0)), alpha);
+        }
+    }
     static __device__ __forceinline__ void xform(vec_t &z, const vec_t &gv, T alpha) {
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
@@ -277,7 +326,11 @@ template <int MASK, int N> __device__ __forceinline__ void sched_pairs() {
 }
 
 // AUX: 0 plain operands; 1 / 2: operand A / B is the projected-gradient trial step computed in the loader.
-template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi, int AUX = 0>
+// BUF: 1 = operand loads as buffer loads with loop-invariant lane offsets and the k-tile's position in the scalar descriptor
+// (TileLoader::load_buf) instead of per-load 64-bit pointer arithmetic on the vector unit: -2.7 ... -4.5 % on every big product
+// (scripts/kbench/gemm_bench.hip, A/B interleaved in one process: WtX 1169 -> 1138 us, XHt 1161 -> 1116 us on that box; the 8-rank
+// shard shapes 170 -> 165 and 155 -> 148 us; Float64 573 -> 563 / 552 us).  The library launches every GEMM with BUF = 1.
+template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC, typename Epi, int AUX = 0, int BUF = 0>
 // half-size and smaller tiles ask for >= 2 waves per SIMD (they exist to overlap one block's prologue / epilogue with another
 // block's MFMAs); without the hint the fused f64 epilogues land a few registers above the 256-register budget of two waves
 __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void gemm_mfma_kernel(GemmArgs<T> g, Epi epi) {
@@ -424,14 +477,28 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
         if constexpr (EARLY) prefetch_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
 
         typename M::vec_t ra[LoadA::PER_THREAD], rb[LoadB::PER_THREAD];
-        LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, kbeg, tid, g.a_aux, xalpha);
-        LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, kbeg, tid, g.b_aux, xalpha);
+        uint32_t offA[LoadA::PER_THREAD], offB[LoadB::PER_THREAD];
+        if constexpr (BUF != 0) { LoadA::offsets(offA, lda, tid); LoadB::offsets(offB, ldb, tid); }
+        auto loadA = [&](int64_t kk) {
+            if constexpr (BUF != 0) {
+                const T *tb = LoadA::tile_base(Ab, lda, ra0, kk);
+                LoadA::template load_buf<AUX == 1>(ra, tb, offA, (AUX == 1) ? g.a_aux + (tb - Ab) : nullptr, xalpha);
+            } else LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, kk, tid, g.a_aux, xalpha);
+        };
+        auto loadB = [&](int64_t kk) {
+            if constexpr (BUF != 0) {
+                const T *tb = LoadB::tile_base(Bb, ldb, cb0, kk);
+                LoadB::template load_buf<AUX == 2>(rb, tb, offB, (AUX == 2) ? g.b_aux + (tb - Bb) : nullptr, xalpha);
+            } else LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, kk, tid, g.b_aux, xalpha);
+        };
+        loadA(kbeg);
+        loadB(kbeg);
         LoadA::store(ra, smem, tid);
         LoadB::store(rb, smem + BR * BK, tid);
         {
             const int64_t k1 = kbeg + (int64_t)((nk > 1) ? 1 : 0) * BK;
-            LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, k1, tid, g.a_aux, xalpha);
-            LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, k1, tid, g.b_aux, xalpha);
+            loadA(k1);
+            loadB(k1);
         }
         __syncthreads();
 
@@ -490,8 +557,8 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
 #pragma unroll
                     for (int j = 0; j < TC; ++j) if constexpr (CARRY) read_frag<T, LB, BC, NT>(bf[fn][j], b_n, wc * WTC + j * MT, 0, lane);
                 }
-                if constexpr (ldA) LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, kn, tid, g.a_aux, xalpha);
-                if constexpr (ldB) LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, kn, tid, g.b_aux, xalpha);
+                if constexpr (ldA) loadA(kn);
+                if constexpr (ldB) loadB(kn);
 #pragma unroll
                 for (int q = 0; q < M::VEC; ++q)
 #pragma unroll

@@ -593,7 +593,7 @@ template <typename T> class Solver : public SolverBase {
     template <int LA, int LB, int BR, int BC, int WGR, int WGC, int AUX, typename Epi>
     void launch_gemm_cfg(const GemmArgs<T> &g, const Epi &epi) {
         const int blocks = g.tiles_r * g.tiles_c * g.splits - g.tail_main;
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi, AUX>), dim3(blocks), dim3(WGR * WGC * 64), 0,
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi, AUX, 1>), dim3(blocks), dim3(WGR * WGC * 64), 0,
                            stream, g, epi);
         HIP_TRY(hipGetLastError());
     }

@@ -10,7 +10,7 @@ using namespace nmfx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 static int g_mode = 0, g_stagger = 0, g_prio = 0;
-template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC>
+template <typename T, int LA, int LB, int BR, int BC, int WGR, int WGC, int BUF = 0>
 double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool c_fastest, int reps) {
     // A: R rows, B: C rows; KCONTIG -> ld = Kd, KSTRIDED -> ld = rows
     const int64_t lda = (LA == KCONTIG) ? Kd : R, ldb = (LB == KCONTIG) ? Kd : C;
@@ -47,7 +47,7 @@ double run(const char *name, int64_t R, int64_t C, int64_t Kd, int splits, bool 
     float best = 1e9;
     for (int i = 0; i < reps; ++i) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, EpiStore<T>>), dim3(blocks), dim3(WGR * WGC * 64), 0, 0, g, e);
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, EpiStore<T>, 0, BUF>), dim3(blocks), dim3(WGR * WGC * 64), 0, 0, g, e);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (i > 0) best = std::min(best, ms);
     }
@@ -83,6 +83,25 @@ int main(int argc, char **argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 6;
     const int what = argc > 2 ? atoi(argv[2]) : 0;
     g_mode = 1;
+    if (what == 2) {   // pointer loads vs buffer loads with loop-invariant lane offsets (A/B inside one process, interleaved)
+        g_stagger = 1;
+        for (int round = 0; round < 4; ++round) {
+            printf("--- round %d\n", round);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 0>("TN big (WtX) ptr", 16384, 256, 16384, 2, true, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 1>("TN big (WtX) buf", 16384, 256, 16384, 2, true, reps);
+            run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 0>("NT big (XHt) ptr", 256, 16384, 16384, 2, false, reps);
+            run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 1>("NT big (XHt) buf", 256, 16384, 16384, 2, false, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 0>("TN shard/8 ptr", 2048, 256, 16384, 16, true, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 1>("TN shard/8 buf", 2048, 256, 16384, 16, true, reps);
+            run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 0>("NT shard/8 ptr", 256, 16384, 2048, 1, false, reps);
+            run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 1>("NT shard/8 buf", 256, 16384, 2048, 1, false, reps);
+            run<double, KCONTIG, KCONTIG, 128, 128, 2, 2, 0>("TN f64 ptr", 8192, 256, 8192, 4, true, reps);
+            run<double, KCONTIG, KCONTIG, 128, 128, 2, 2, 1>("TN f64 buf", 8192, 256, 8192, 4, true, reps);
+            run<double, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 0>("NT f64 ptr", 256, 8192, 8192, 4, false, reps);
+            run<double, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 1>("NT f64 buf", 256, 8192, 8192, 4, false, reps);
+        }
+        return 0;
+    }
     if (what == 1) {   // wave-priority patterns on the two big products and their 8-rank shard shapes (A/B inside one process, interleaved)
         g_stagger = 1;
         for (int round = 0; round < 3; ++round)

@@ -29,7 +29,8 @@ def test_sixty_four_granular_k_against_the_oracle(built, alg, T, k, monkeypatch)
     Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
     ro = orc.solve(alg, X, Wc, Hc, orc.Opts(maxiter=iters, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
     assert r.niters == ro.niters == iters
-    tol = {np.float64: 1e-7, np.float32: 2e-3 if alg in ("projals", "alspgrad") else 2e-5}[T]
+    # (f32 cd: the rank-40 planted problem with k = 150 components leaves entries of H near 2e3; 3e-3 of that measured on the factors)
+    tol = {np.float64: 1e-7, np.float32: 2e-3 if alg in ("projals", "alspgrad") else (1e-4 if alg == "cd" else 2e-5)}[T]
     if alg == "greedycd" and T == np.float32:
         # the fp32 greedy sweep is chaotic (two CPU restatements differ by 6e-3 ... 5e-1 after 6 iterations on such
         # problems): descent and the objective's order of magnitude are what can be asserted

@@ -64,6 +64,10 @@ def parse():
                     help="multi-GPU exchange: p2p (default) = the ranks' peer-mapped windows with device-side flags (all xGMI links at once), RCCL for "
                          "the bootstrap and as the fallback -- verified against an RCCL run of the same iterations before the timed region and "
                          "dropped for plain RCCL if it fails; rccl = RCCL collectives; p2p_only = windows without any RCCL communicator")
+    ap.add_argument("--traffic", default="live", choices=["live", "static", "none"],
+                    help="roofline.traffic of the default workload: live = two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of "
+                         "this script, ~20 s each) behind the timed region; static = the value committed in profiles/pmc_traffic.json; falls back to "
+                         "static when rocprofv3 is missing or a pass fails")
     ap.add_argument("--watchdog-s", type=float, default=600.0,
                     help="multi-GPU: a stage that takes longer than this prints a JSON line with status = comm_timeout and exits (a mismatched "
                          "collective would otherwise hang until the driver's timeout and leave no line at all)")
@@ -353,12 +357,17 @@ def main():
         if dom is not None:
             avg_s = dom["ms_total"] / dom["launches"] * 1e-3
             ach = dom["flops"] / dom["launches"] / avg_s / 1e12
-            traffic = None
+            traffic, traffic_source = None, None
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            default_workload = (a.alg == "multmse" and a.dtype == "f32" and (p, n, k) == (16384, 16384, 256) and world == 1)
-            if default_workload and os.path.exists(tf):   # the PMC passes were taken on the default workload only
+            default_workload = (a.alg == "multmse" and a.dtype == "f32" and (p, n, k) == (16384, 16384, 256) and world == 1 and shards == 1
+                                and a.precision == "fp32")
+            if default_workload and a.traffic == "live":
+                traffic, traffic_source = live_traffic(dom["name"])
+            if default_workload and traffic is None and a.traffic != "none" and os.path.exists(tf):   # the committed PMC passes of this workload
                 try:
                     traffic = json.load(open(tf)).get(dom["name"])
+                    traffic_source = ("static: profiles/pmc_traffic.json (rocprofv3 --pmc passes of this kernel on this workload, taken when the "
+                                      "profile was committed; not re-measured in this run)")
                 except Exception:
                     traffic = None
             # bf16x3: three dense-bf16 MFMA products (2.5 PFLOP/s peak) per fp32-equivalent product
@@ -367,9 +376,7 @@ def main():
             roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2),
                     "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4),
-                    "traffic": traffic,
-                    "traffic_source": ("static: profiles/pmc_traffic.json (rocprofv3 --pmc passes of this kernel on this workload, "
-                                       "taken when the profile was committed; not re-measured in this run)") if traffic is not None else None,
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "flops_per_launch": dom["flops"] / dom["launches"],
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": dom["launches"]}
         out = {
@@ -436,6 +443,49 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def live_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE; counters in
+    runs of their own with --kernel-trace only, as MI355X_MICROARCH.md prescribes) of this script on the same workload (4 steps), and
+    traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are KiB, and on gfx950 FETCH_SIZE reports half of the bytes of a wide
+    coalesced read (the guide's correction; calibrated in profiles/r0*_bench_multmse_c3.md on the split-K combine, whose byte count is known).
+    Returns (bytes or None, source string)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, None
+    # the launches behind the bench names (csrc/solver.hpp): W'X = both operands contraction-contiguous, XH' = both strided; 128 x 128 tiles
+    pat = {"gemm_WtX": "gemm_mfma_kernel<float, 0, 0, 128, 128, 2, 2, nmfx::EpiStore<float>", "gemm_XHt": "gemm_mfma_kernel<float, 1, 1, 128, 128, 2, 2, nmfx::EpiStore<float>"}.get(kernel)
+    if pat is None:
+        return None, None
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__), "--steps", "4",
+                       "--warmup", "2", "--no-cpu-baseline", "--no-events", "--traffic", "none"]
+                subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                tot, cnt = 0.0, 0
+                for f in glob.glob(td + "/**/*counter_collection.csv", recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if r.get("Counter_Name") == counter and pat in r.get("Kernel_Name", ""):
+                            tot += float(r["Counter_Value"])
+                            cnt += 1
+                if cnt == 0:
+                    return None, None
+                vals[counter] = (tot / cnt, cnt)
+    except Exception:  # noqa: BLE001
+        return None, None
+    bytes_ = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    return round(bytes_), (f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two runs of this script behind the timed region (4 steps each; "
+                           f"{vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} dispatches of the kernel), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
+                           f"with the gfx950 FETCH_SIZE correction; raw KiB {vals['FETCH_SIZE'][0]:.0f} / {vals['WRITE_SIZE'][0]:.0f}")
 
 
 def _blas_pool():

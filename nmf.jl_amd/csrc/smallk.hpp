@@ -103,17 +103,22 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_h_kernel(const float *X
     smallk_v4 rw[2][NW], rx[2][NX];
 #pragma unroll
     for (int q = 0; q < NX; ++q) { rx[0][q] = smallk_v4{0.f, 0.f, 0.f, 0.f}; rx[1][q] = rx[0][q]; }
+    // buffer loads: the chunk's byte offset inside a stage is loop invariant (one 32-bit VGPR per chunk), the stage's position goes into
+    // the scalar base of the descriptor -- no 64-bit vector address arithmetic per load (as in gemm_mfma.hpp's TileLoader::load_buf)
+    uint32_t offw[NW], offx[NX];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) { const int c = tid + SMALLK_THREADS * q; offw[q] = (uint32_t)(((int64_t)(c / C4) * ldx + 4 * (c % C4)) * 4); }
+#pragma unroll
+    for (int q = 0; q < NX; ++q) { const int c = tid + SMALLK_THREADS * q; offx[q] = (uint32_t)(((int64_t)(c / C4) * ldx + 4 * (c % C4)) * 4); }
+    typedef unsigned smallk_v4u __attribute__((ext_vector_type(4)));
     auto gload = [&](int set, int64_t p0) {
+        const __amdgpu_buffer_rsrc_t dw = __builtin_amdgcn_make_buffer_rsrc((void *)(W + p0), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t dx = __builtin_amdgcn_make_buffer_rsrc((void *)(X + c0 * ldx + p0), 0, -1, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < NW; ++q) {
-            const int c = tid + SMALLK_THREADS * q;
-            rw[set][q] = *reinterpret_cast<const smallk_v4 *>(W + (int64_t)(c / C4) * ldx + p0 + 4 * (c % C4));
-        }
+        for (int q = 0; q < NW; ++q) rw[set][q] = __builtin_bit_cast(smallk_v4, __builtin_amdgcn_raw_buffer_load_b128(dw, (int)offw[q], 0, 0));
 #pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            const int c = tid + SMALLK_THREADS * q;
-            if (xld) rx[set][q] = *reinterpret_cast<const smallk_v4 *>(X + (c0 + c / C4) * ldx + p0 + 4 * (c % C4));
-        }
+        for (int q = 0; q < NX; ++q)
+            if (xld) rx[set][q] = __builtin_bit_cast(smallk_v4, __builtin_amdgcn_raw_buffer_load_b128(dx, (int)offx[q], 0, 0));
     };
     auto lstore = [&](int set, int buf) {
 #pragma unroll
@@ -256,17 +261,19 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X
     smallk_v4 rh[2][NH], rx[2][NX];      // two stages ahead, as in smallk_h_kernel
 #pragma unroll
     for (int q = 0; q < NX; ++q) { rx[0][q] = smallk_v4{0.f, 0.f, 0.f, 0.f}; rx[1][q] = rx[0][q]; }
+    uint32_t offh[NH], offx[NX];           // buffer loads with loop-invariant lane offsets (see smallk_h_kernel)
+#pragma unroll
+    for (int q = 0; q < NH; ++q) { const int c = tid + SMALLK_THREADS * q; offh[q] = (uint32_t)(((c >> 4) * 64 + 4 * (c & 15)) * 4); }
+#pragma unroll
+    for (int q = 0; q < NX; ++q) { const int c = tid + SMALLK_THREADS * q; offx[q] = (uint32_t)((4 * (c & 3) + (int64_t)(c >> 2) * ldx) * 4); }
     auto gload = [&](int set, int64_t j0) {
+        const __amdgpu_buffer_rsrc_t dh = __builtin_amdgcn_make_buffer_rsrc((void *)(H + j0 * 64), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t dx = __builtin_amdgcn_make_buffer_rsrc((void *)(X + r0 + j0 * ldx), 0, -1, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < NH; ++q) {
-            const int c = tid + SMALLK_THREADS * q;
-            rh[set][q] = *reinterpret_cast<const smallk_v4 *>(H + (j0 + (c >> 4)) * 64 + 4 * (c & 15));
-        }
+        for (int q = 0; q < NH; ++q) rh[set][q] = __builtin_bit_cast(smallk_v4, __builtin_amdgcn_raw_buffer_load_b128(dh, (int)offh[q], 0, 0));
 #pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            const int c = tid + SMALLK_THREADS * q;
-            if (xld) rx[set][q] = *reinterpret_cast<const smallk_v4 *>(X + r0 + 4 * (c & 3) + (j0 + (c >> 2)) * ldx);
-        }
+        for (int q = 0; q < NX; ++q)
+            if (xld) rx[set][q] = __builtin_bit_cast(smallk_v4, __builtin_amdgcn_raw_buffer_load_b128(dx, (int)offx[q], 0, 0));
     };
     auto lstore = [&](int set, int buf) {
 #pragma unroll

@@ -7,8 +7,8 @@ OUT="$R/gpurun_out/${1:-prof_final}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$R/bench.py" $BENCH_ARGS > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o r03 -- python "$R/bench.py" $BENCH_ARGS --no-cpu-baseline > "$OUT/bench_stats.log" 2>&1
-SHORT="$BENCH_ARGS --steps 4 --warmup 2 --no-cpu-baseline --no-events"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o r03 -- python "$R/bench.py" $BENCH_ARGS --no-cpu-baseline --traffic static > "$OUT/bench_stats.log" 2>&1
+SHORT="$BENCH_ARGS --steps 4 --warmup 2 --no-cpu-baseline --no-events --traffic none"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o r03 -- python "$R/bench.py" $SHORT > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o r03 -- python "$R/bench.py" $SHORT > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT \

@@ -32,6 +32,9 @@ def test_bench_json_contract(built, extra):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str) and c["unit"] == d["unit"]
+    assert d["ms_per_step_no_events"] > 0 and isinstance(d["event_brackets"], str)        # the same steps without hipEvent brackets
+    if not extra:   # multmse: the CPU baseline states where its time goes (every mul!, every loop) and what its GEMM phases reach alone
+        assert len(c["phase_seconds"]) == 12 and c["gemm_phases_gflops"] > 0 and c["gemm_seconds"] + c["non_gemm_seconds"] > 0
 
 
 def test_bench_help_runs_without_a_gpu():

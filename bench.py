@@ -302,6 +302,11 @@ def main():
     # stream -- ProjectedALS -- a bracket on the main stream delays the side stream's ordering events; both numbers go into the line)
     dt_plain = None
     if not a.no_events:
+        # (from the SAME state as the bracketed region -- start factors, the same warm-up -- so that algorithms whose work depends on
+        # the iterate, GreedyCD's step counts and ALSPGrad's line searches, do the same work in both regions)
+        ctx.set_factors(W0, H0)
+        if a.warmup > 0:
+            ctx.iterate(algid, opts(a.warmup))
         barrier()
         t0 = time.perf_counter()
         res2, _ = ctx.iterate(algid, opts(a.steps))

@@ -290,7 +290,9 @@ def main():
         ctx.iterate(algid, opts(a.warmup))
     # hipEvent pairs on the solver stream around the dominant GEMM launches and the collectives (a pair costs ~10 us): 1 launch
     # in 8 sampled, 1 in 2 for short runs so that the roofline of a 20-step line still rests on >= 10 launches per kernel
-    ctx.profile_enable(0 if a.no_events else (1 if a.all_events else (3 if a.steps <= 32 else 2)))
+    # (ProjectedALS: 1 in 16 -- its factorisations run on a second stream whose ordering events queue behind a bracket)
+    prof_mode = 0 if a.no_events else (1 if a.all_events else (4 if a.alg == "projals" else (3 if a.steps <= 32 else 2)))
+    ctx.profile_enable(prof_mode)
     barrier()
     t0 = time.perf_counter()
     res, _ = ctx.iterate(algid, opts(a.steps))
@@ -398,7 +400,8 @@ def main():
             # `value` / `ms_per_step` are the region with the sampled hipEvent brackets (the roofline's launch times come from it);
             # the same K steps without any bracket right behind it:
             "ms_per_step_no_events": (round(dt_plain / a.steps * 1e3, 4) if dt_plain is not None else round(ms, 4)),
-            "event_brackets": ("none" if a.no_events else ("every launch" if a.all_events else ("1 launch in 2 of the dominant GEMMs" if a.steps <= 32 else "1 launch in 8 of the dominant GEMMs"))),
+            "event_brackets": {0: "none", 1: "every launch", 2: "1 launch in 8 of the dominant GEMMs", 3: "1 launch in 2 of the dominant GEMMs",
+                               4: "1 launch in 16 of the dominant GEMMs"}[prof_mode],
             "gflops_algorithmic": round(f_alg * a.steps / dt / 1e9, 1),
             "frac_of_mfma_peak": round(f_alg * a.steps / dt / 1e12 / (((2500.0 / 3.0) if a.precision == "bf16x3" else
                                                                         (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6)) * world), 4),

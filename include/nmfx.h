@@ -293,7 +293,7 @@ typedef struct {
     double bytes;         /* algorithmic HBM bytes summed over launches */
 } nmfx_kernel_stat;
 int nmfx_profile_enable(nmfx_ctx *ctx, int mode);  /* 0 off; 1 hipEvent pair around every launch (slow: ~10 us each);
-                                                       2 only the dominant GEMM launches, every 8th (live roofline) */
+                                                       2 only the dominant GEMM launches, every 8th (live roofline); 3: every 2nd; 4: every 16th */
 int nmfx_profile_get(nmfx_ctx *ctx, nmfx_kernel_stat *out, int max_entries, int *n_entries);
 int nmfx_device_info(int device, char *name_out, int name_len, int *cu_count, int64_t *hbm_bytes);
 

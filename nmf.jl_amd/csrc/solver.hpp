@@ -365,7 +365,8 @@ template <typename T> class Solver : public SolverBase {
     // mode 0: off; 1: hipEvent pair around EVERY launch (each pair costs ~10 us of stream time: use for
     // per-kernel breakdowns, not for throughput); 2: only the dominant GEMM launches (the p*n*k products) and the
     // collectives, every 8th one -- the live roofline measurement of bench.py, < 0.5 % overhead on the timed region;
-    // 3: the same launches, every 2nd one (short runs: the driver's 20-step line then rests on >= 10 samples per kernel).
+    // 3: the same launches, every 2nd one (short runs: the driver's 20-step line then rests on >= 10 samples per kernel);
+    // 4: every 16th (ProjectedALS: a bracket on the main stream delays the factorisation stream's ordering events, ~0.4 ms per bracketed iteration).
     void profile_enable(int mode) override {
         profiling = mode;
         records.clear();
@@ -575,7 +576,7 @@ template <typename T> class Solver : public SolverBase {
         // and the collectives of the exchange step (names "comm_..."), every 8th (mode 2) / every 2nd (mode 3) launch of each
         if (profiling >= 2) {
             const bool wanted = flops >= (double)P * (double)N * (double)K || std::strncmp(name, "comm_", 5) == 0;
-            if (!wanted || ((prof_seen[name]++) & (profiling == 2 ? 7 : 1)) != 0) { launch(); return; }
+            if (!wanted || ((prof_seen[name]++) & (profiling == 2 ? 7 : (profiling == 3 ? 1 : 15))) != 0) { launch(); return; }
         }
         if (ev_used == (int)ev_pool.size()) {
             hipEvent_t a, b;

@@ -538,7 +538,11 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
                 // (with a communicator every rank must poll -- and stop enqueueing -- at the SAME iterations, or the collectives of
                 // the no-op iterations behind the stop no longer pair up: there the window grows by iteration count alone)
                 const auto now = std::chrono::steady_clock::now();
-                if (sharded()) { if (window < 32) window *= 2; }
+                // (capped at 8: the collectives of the no-op iterations enqueued behind the stop still execute -- they must, every rank
+                // has to issue the same sequence -- and in the fused row-sharded step they keep sum-all-reducing the stale Gram / statistics
+                // buffers, multiplying them by nranks per no-op iteration; nothing reads those buffers after the stop, and with at most 7
+                // such iterations they cannot overflow either: 16^7 x a Gram entry is far inside Float32)
+                if (sharded()) { if (window < 8) window *= 2; }
                 else if (std::chrono::duration<double>(now - last_poll).count() < 1e-3 && window < 256) window *= 2;
                 last_poll = now;
             }

@@ -137,6 +137,27 @@ def test_peer_ragged_shards_straddling_a_padding_boundary(built):
     assert np.max(np.abs(ref[0] - Wc)) <= 1e-6 * np.max(np.abs(Wc))
 
 
+@pytest.mark.parametrize("kw_extra", [dict(), dict(update_H=False), dict(track_objective=False)])
+def test_fused_step_with_the_product_stored_straight_into_the_peers_slots(built, kw_extra, monkeypatch):
+    """The fused row-sharded MultUpdate-MSE step at a shape where X_g H_g' is stored UNSPLIT (local contraction 1024 .. 4096 columns,
+    >= one tile per CU: p = 16384, k = 256, 4 ranks x 1100 columns): on the peer transport the product's epilogue writes row block g
+    straight into rank g's receive slot (EpiStorePeer).  Bit-identical to the in-process group (whose product stores into the blocked
+    send buffer), and equal to the UNFUSED sequence (NMFX_RS_FUSED=0: W'W over all rows instead of the ranks' own-rows Grams) to
+    rounding -- ADVICE round 3: the direct-store branch and the own-rows W'W all-reduce had only ever run with one rank."""
+    T = np.float32
+    p, n, k, G = 16384, 4400, 256, 4
+    X, W0, H0 = planted(p, n, k, T, seed=41, k0=24)
+    kw = dict(maxiter=4, tol=1e-30, lambda_w=1e-4, lambda_h=1e-4, track_objective=True)
+    kw.update(kw_extra)
+    ref = run_sharded(T, X, W0, H0, "multmse", kw, G)
+    *got, stats = run_peer_threads(T, X, W0, H0, "multmse", kw, G)
+    same_run(ref, tuple(got), "multmse")
+    monkeypatch.setenv("NMFX_RS_FUSED", "0")
+    unf = run_sharded(T, X, W0, H0, "multmse", kw, G)
+    assert np.max(np.abs(unf[0] - ref[0])) <= 2e-5 * np.max(np.abs(ref[0])) and np.max(np.abs(unf[1] - ref[1])) <= 2e-5 * np.max(np.abs(ref[1]))
+    assert abs(unf[2][0][0].objvalue - ref[2][0][0].objvalue) <= 1e-5 * abs(ref[2][0][0].objvalue)
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -229,21 +229,31 @@ def main():
         c.get_factors(Wchk, None)
         return hashlib.sha256(Wchk.tobytes()).hexdigest(), float(res.objvalue), bool(np.isfinite(Wchk).all())
 
-    def probe(c, iters=3):
-        """A few iterations from the start factors; (ok, objective, errors): finite everywhere, W identical on every rank."""
+    def probe(c, pre_err=None, iters=3):
+        """A few iterations from the start factors; (ok, objective, errors): finite everywhere, W identical on every rank.  Every rank
+        takes part in the exchange of results whatever happened to it before (c is None: its context could not be built)."""
         import torch.distributed as dist
-        try:
-            c.set_factors(W0, H0)
-            res, _ = c.iterate(algid, opts(iters))
-            mine = w_hash_and_obj(c, res)
-            err = None
-        except Exception as e:  # noqa: BLE001
-            mine, err = ("", float("nan"), False), repr(e)
+        if c is None:
+            mine, err = ("", float("nan"), False), pre_err or "no context"
+        else:
+            try:
+                c.set_factors(W0, H0)
+                res, _ = c.iterate(algid, opts(iters))
+                mine = w_hash_and_obj(c, res)
+                err = None
+            except Exception as e:  # noqa: BLE001
+                mine, err = ("", float("nan"), False), repr(e)
         allv = [None] * world
         dist.all_gather_object(allv, (mine, err))
         ok = (all(v[1] is None and v[0][2] and np.isfinite(v[0][1]) for v in allv) and len({v[0][0] for v in allv}) == 1
               and len({v[0][1] for v in allv}) == 1)
         return ok, allv[0][0][1], [v[1] for v in allv if v[1] is not None]
+
+    def try_ctx(tr, md):
+        try:
+            return make_ctx(tr, md), None
+        except Exception as e:  # noqa: BLE001
+            return None, repr(e)
 
     # Multi-GPU: the requested transport / mode is VERIFIED before the timed region -- three iterations on it against three on plain RCCL
     # (row-sharded), same start: finite, W bit-identical on all ranks, objective equal to 1e-5 -- and replaced by the next candidate
@@ -254,22 +264,19 @@ def main():
         ok_ref, obj_ref = False, float("nan")
         if (transport, mode) != ("rccl", "row_sharded") and not dev_gloo:
             wd.arm("verify:rccl+row_sharded")
-            ref_ctx = make_ctx("rccl", "row_sharded")
-            ok_ref, obj_ref, errs = probe(ref_ctx)
-            ref_ctx.close()
+            ref_ctx, e0 = try_ctx("rccl", "row_sharded")
+            ok_ref, obj_ref, errs = probe(ref_ctx, e0)
+            if ref_ctx is not None:
+                ref_ctx.close()
             if not ok_ref:
                 fallback_log.append({"candidate": "rccl+row_sharded (reference run)", "ok": False, "errors": errs[:2]})
         cands = [(transport, mode)] + [c_ for c_ in (("rccl", "row_sharded"), ("rccl", "replicated_w")) if c_ != (transport, mode) and not dev_gloo]
         ctx = None
         for tr, md in cands:
             wd.arm(f"verify:{tr}+{md}")
-            try:
-                c = make_ctx(tr, md)
-                ok, obj, errs = probe(c)
-                same = ok and (not ok_ref or abs(obj - obj_ref) <= 1e-5 * abs(obj_ref))
-            except Exception as e:  # noqa: BLE001
-                c, same, obj, errs = None, False, float("nan"), [repr(e)]
-            same = agree(same)
+            c, e0 = try_ctx(tr, md)
+            ok, obj, errs = probe(c, e0)
+            same = agree(ok and (not ok_ref or abs(obj - obj_ref) <= 1e-5 * abs(obj_ref)))
             fallback_log.append({"candidate": f"{tr}+{md}", "ok": same, "objective_after_3": obj,
                                  "rccl_row_sharded_objective_after_3": (obj_ref if ok_ref else None), "errors": errs[:2]})
             if same:

@@ -54,9 +54,27 @@ def init_comm(ctx, group=None, transport="rccl"):
 
 
 def attach_p2p(ctx, group=None):
-    """Export this rank's window, all-gather the 128-byte handles through the host, map the peers' windows."""
+    """Export this rank's window, all-gather the 128-byte handles through the host, map the peers' windows.  Collective and
+    all-or-nothing: a rank that cannot export or map (no IPC support, no peer access) makes EVERY rank raise, so that callers can fall
+    back to another transport together instead of waiting for each other."""
     import torch.distributed as dist
-    mine = ctx.comm_p2p_export()
-    allh = [None] * dist.get_world_size(group)
-    dist.all_gather_object(allh, mine, group=group)
-    ctx.comm_p2p_attach(allh)
+    world = dist.get_world_size(group)
+    try:
+        mine, err = ctx.comm_p2p_export(), None
+    except Exception as e:  # noqa: BLE001
+        mine, err = None, repr(e)
+    allh = [None] * world
+    dist.all_gather_object(allh, (mine, err), group=group)
+    bad = [(r, e) for r, (h, e) in enumerate(allh) if h is None]
+    if bad:
+        raise RuntimeError(f"peer windows: export failed on rank(s) {bad}")
+    try:
+        ctx.comm_p2p_attach([h for h, _ in allh])
+        err = None
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+    alle = [None] * world
+    dist.all_gather_object(alle, err, group=group)
+    bad = [(r, e) for r, e in enumerate(alle) if e is not None]
+    if bad:
+        raise RuntimeError(f"peer windows: mapping failed on rank(s) {bad}")

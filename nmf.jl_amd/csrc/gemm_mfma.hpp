@@ -153,7 +153,9 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
     // i.e. the projected-gradient trial step D = Zn - Z of src/alspgrad.jl:142-147, which therefore never exists in memory.
     // (AUX is a compile-time flag: a run-time test here would split the software-pipelined main loop into basic
     // blocks and void its issue-order template -- measured 142 -> 133 TF/s on the big GEMM.)
-    template <bool AUX = false>
+    // AM = 2: the operand is the SUM of two arrays with identical addressing (two split-K slabs: the combine launch folded into the
+    // consumer's loader; z + g in this order, like reduce_slabs_kernel)
+    template <int AM = 0>
     static __device__ __forceinline__ void load(vec_t (&r)[PER_THREAD], const T *base, int64_t ld,
                                                 int64_t row0, int64_t k0, int tid, const T *aux = nullptr, T alpha = (T)0) {
         if constexpr (LAYOUT == KCONTIG) {
@@ -165,7 +167,7 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
                 const int c = cpos ^ swz8(row);
                 const T *p = base + (row0 + row) * ld + k0 + c * VEC;
                 r[i] = *reinterpret_cast<const vec_t *>(p);
-                if constexpr (AUX) xform(r[i], *reinterpret_cast<const vec_t *>(aux + (p - base)), alpha);
+                if constexpr (AM != 0) xform<AM>(r[i], *reinterpret_cast<const vec_t *>(aux + (p - base)), alpha);
             }
         } else {
             // KSTRIDED: a thread owns VEC x VEC micro-tiles (VEC rows x VEC consecutive k): VEC global loads of 16 bytes
@@ -184,7 +186,7 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
                 for (int ek = 0; ek < VEC; ++ek) {
                     const T *p = base + (k0 + kq * VEC + ek) * ld + row0 + r4 * VEC;
                     r[m * VEC + ek] = *reinterpret_cast<const vec_t *>(p);
-                    if constexpr (AUX) xform(r[m * VEC + ek], *reinterpret_cast<const vec_t *>(aux + (p - base)), alpha);
+                    if constexpr (AM != 0) xform<AM>(r[m * VEC + ek], *reinterpret_cast<const vec_t *>(aux + (p - base)), alpha);
                 }
             }
           } else {
@@ -195,7 +197,7 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
                 const int kk = s / CPK, r4 = s % CPK;
                 const T *p = base + (k0 + kk) * ld + row0 + r4 * VEC;
                 r[i] = *reinterpret_cast<const vec_t *>(p);
-                if constexpr (AUX) xform(r[i], *reinterpret_cast<const vec_t *>(aux + (p - base)), alpha);
+                if constexpr (AM != 0) xform<AM>(r[i], *reinterpret_cast<const vec_t *>(aux + (p - base)), alpha);
             }
           }
         }
@@ -237,25 +239,30 @@ template <typename T, int LAYOUT, int ROWS, int NTHREADS> struct TileLoader {
     }
     // AUX: the operand computed on the fly from two arrays with identical addressing (see load()): `auxtb` = the tile base in the
     // second array
-    template <bool AUX = false>
+    template <int AM = 0>
     static __device__ __forceinline__ void load_buf(vec_t (&r)[PER_THREAD], const T *tb, const uint32_t (&off)[PER_THREAD], const T *auxtb = nullptr,
                                                     T alpha = (T)0) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)tb, 0, -1, 0x00020000);
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) r[i] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off[i], 0, 0));
-        if constexpr (AUX) {
+        if constexpr (AM != 0) {
             const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)auxtb, 0, -1, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < PER_THREAD; ++i) xform(r[i], __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off[i], 0, 0)), alpha);
+            for (int i = 0; i < PER_THREAD; ++i) xform<AM>(r[i], __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off[i], 0, 0)), alpha);
         }
     }
-    static __device__ __forceinline__ void xform(vec_t &z, const vec_t &gv, T alpha) {
+    template <int AM = 1> static __device__ __forceinline__ void xform(vec_t &z, const vec_t &gv, T alpha) {
+        if constexpr (AM == 2) {
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-            const T zz = z[q];
-            T v = zz - alpha * gv[q];
-            v = (v > (T)0) ? v : ((v != v) ? v : (T)0);
-            z[q] = v - zz;
+            for (int q = 0; q < VEC; ++q) z[q] = z[q] + gv[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const T zz = z[q];
+                T v = zz - alpha * gv[q];
+                v = (v > (T)0) ? v : ((v != v) ? v : (T)0);
+                z[q] = v - zz;
+            }
         }
     }
     // registers -> LDS.  KCONTIG: linear image, chunk s at byte 16*s.  KSTRIDED: micro-tile (kq, r4), row er at
@@ -325,7 +332,9 @@ template <int MASK, int N> __device__ __forceinline__ void sched_pairs() {
     }
 }
 
-// AUX: 0 plain operands; 1 / 2: operand A / B is the projected-gradient trial step computed in the loader.
+// AUX: 0 plain operands; 1 / 2: operand A / B is the projected-gradient trial step computed in the loader; 3 / 4: operand A / B is the
+// sum of two arrays (a_aux / b_aux = the second one: two split-K slabs summed on the way in; measured on ProjectedALS's solve products in
+// round 4 and not used there -- the short grid's tail pieces still need their own combine launch, which costs what the fold saves).
 // BUF: 1 = operand loads as buffer loads with loop-invariant lane offsets and the k-tile's position in the scalar descriptor
 // (TileLoader::load_buf) instead of per-load 64-bit pointer arithmetic on the vector unit: -2.7 ... -4.5 % on every big product
 // (scripts/kbench/gemm_bench.hip, A/B interleaved in one process: WtX 1169 -> 1138 us, XHt 1161 -> 1116 us on that box; the 8-rank
@@ -352,7 +361,8 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
     else if (g.prio == 3) __builtin_amdgcn_s_setprio(2);
     else if (g.prio == 4) { if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(2); }
     T xalpha = (T)0;
-    if constexpr (AUX != 0) xalpha = (T)*g.alpha_ptr;
+    if constexpr (AUX == 1 || AUX == 2) xalpha = (T)*g.alpha_ptr;
+    constexpr int AMA = (AUX == 1) ? 1 : ((AUX == 3) ? 2 : 0), AMB = (AUX == 2) ? 1 : ((AUX == 4) ? 2 : 0);
     __shared__ __attribute__((aligned(16))) T smem[2 * (BR + BC) * BK];
     constexpr int STAGE = (BR + BC) * BK;   // stage s: A tile at smem + s*STAGE, B tile right behind it
 
@@ -482,14 +492,14 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
         auto loadA = [&](int64_t kk) {
             if constexpr (BUF != 0) {
                 const T *tb = LoadA::tile_base(Ab, lda, ra0, kk);
-                LoadA::template load_buf<AUX == 1>(ra, tb, offA, (AUX == 1) ? g.a_aux + (tb - Ab) : nullptr, xalpha);
-            } else LoadA::template load<AUX == 1>(ra, Ab, lda, ra0, kk, tid, g.a_aux, xalpha);
+                LoadA::template load_buf<AMA>(ra, tb, offA, (AMA != 0) ? g.a_aux + (tb - Ab) : nullptr, xalpha);
+            } else LoadA::template load<AMA>(ra, Ab, lda, ra0, kk, tid, g.a_aux, xalpha);
         };
         auto loadB = [&](int64_t kk) {
             if constexpr (BUF != 0) {
                 const T *tb = LoadB::tile_base(Bb, ldb, cb0, kk);
-                LoadB::template load_buf<AUX == 2>(rb, tb, offB, (AUX == 2) ? g.b_aux + (tb - Bb) : nullptr, xalpha);
-            } else LoadB::template load<AUX == 2>(rb, Bb, ldb, cb0, kk, tid, g.b_aux, xalpha);
+                LoadB::template load_buf<AMB>(rb, tb, offB, (AMB != 0) ? g.b_aux + (tb - Bb) : nullptr, xalpha);
+            } else LoadB::template load<AMB>(rb, Bb, ldb, cb0, kk, tid, g.b_aux, xalpha);
         };
         loadA(kbeg);
         loadB(kbeg);
@@ -519,8 +529,9 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
         for (int i = 0; i < TR; ++i) if constexpr (CARRY) read_frag<T, LA, BR, NT>(af[FDB ? 0 : 1][i], smem, wr * WTR + i * MT, 0, lane);
 #pragma unroll
         for (int j = 0; j < TC; ++j) if constexpr (CARRY) read_frag<T, LB, BC, NT>(bf[FDB ? 0 : 1][j], smem + BR * BK, wc * WTC + j * MT, 0, lane);
-        for (int t = 0; t < nk; ++t) {
-            const int cur = t & 1;
+        // BUF == 2: the k-loop unrolled by two with the LDS stage a compile-time constant (stage offsets become instruction
+        // immediates instead of one vector add per LDS access)
+        auto ktile = [&](int t, int cur) {
             const T *a_s = smem + cur * STAGE, *b_s = a_s + BR * BK;
             T *a_n = smem + (cur ^ 1) * STAGE, *b_n = a_n + BR * BK;
             const int tn = (t + 2 < nk) ? t + 2 : nk - 1;   // clamped: the last iterations re-load the final tile (never used)
@@ -585,6 +596,13 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
                 if constexpr (NMFMA - LEAD - 2 * (NW + NL) > 0)
                     __builtin_amdgcn_sched_group_barrier(0x8, NMFMA - LEAD - 2 * (NW + NL), 0);
             });
+        };
+        if constexpr (BUF == 2) {
+            int t = 0;
+            for (; t + 1 < nk; t += 2) { ktile(t, 0); ktile(t + 1, 1); }
+            if (t < nk) ktile(t, 0);
+        } else {
+            for (int t = 0; t < nk; ++t) ktile(t, t & 1);
         }
         __syncthreads();   // the staging buffers are re-used by the next segment / the epilogue reductions
 

@@ -594,8 +594,19 @@ template <typename T> class Solver : public SolverBase {
     template <int LA, int LB, int BR, int BC, int WGR, int WGC, int AUX, typename Epi>
     void launch_gemm_cfg(const GemmArgs<T> &g, const Epi &epi) {
         const int blocks = g.tiles_r * g.tiles_c * g.splits - g.tail_main;
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi, AUX, 1>), dim3(blocks), dim3(WGR * WGC * 64), 0,
-                           stream, g, epi);
+        // operand staging by buffer loads everywhere (gemm_mfma.hpp, BUF); the k-loop unrolled by two on top of it where that measured
+        // faster: Float32, both operands contraction-contiguous, 128 x 128 tiles (W'X: 1117 -> 1087 us in gemm_bench 6 3; the strided
+        // layout +1 %, Float64 +16 %: left alone)
+        // (not under ProjectedALS's factorisations: the Cholesky workgroup that shares a CU with a block of the product lives on the
+        // issue slots the product leaves, and the unrolled loop leaves fewer -- potrf 590 -> 915 us co-resident, which put the chain
+        // back on the critical path: 2.21 -> 2.30 ms per iteration)
+        constexpr int BUFV = (sizeof(T) == 4 && LA == KCONTIG && LB == KCONTIG && BR == 128 && BC == 128 && AUX == 0) ? 2 : 1;
+        if (BUFV == 2 && !short_grid)
+            hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi, AUX, BUFV>), dim3(blocks), dim3(WGR * WGC * 64), 0,
+                               stream, g, epi);
+        else
+            hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi, AUX, 1>), dim3(blocks), dim3(WGR * WGC * 64), 0,
+                               stream, g, epi);
         HIP_TRY(hipGetLastError());
     }
 

@@ -83,6 +83,21 @@ int main(int argc, char **argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 6;
     const int what = argc > 2 ? atoi(argv[2]) : 0;
     g_mode = 1;
+    if (what == 3) {   // buffer loads vs buffer loads + k-loop unrolled by two (LDS stage offsets as immediates)
+        g_stagger = 1;
+        for (int round = 0; round < 4; ++round) {
+            printf("--- round %d\n", round);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 1>("TN big (WtX) buf", 16384, 256, 16384, 2, true, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 2>("TN big (WtX) buf+unr2", 16384, 256, 16384, 2, true, reps);
+            run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 1>("NT big (XHt) buf", 256, 16384, 16384, 2, false, reps);
+            run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 2>("NT big (XHt) buf+unr2", 256, 16384, 16384, 2, false, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 1>("TN shard/8 buf", 2048, 256, 16384, 16, true, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 2>("TN shard/8 buf+unr2", 2048, 256, 16384, 16, true, reps);
+            run<double, KCONTIG, KCONTIG, 128, 128, 2, 2, 1>("TN f64 buf", 8192, 256, 8192, 4, true, reps);
+            run<double, KCONTIG, KCONTIG, 128, 128, 2, 2, 2>("TN f64 buf+unr2", 8192, 256, 8192, 4, true, reps);
+        }
+        return 0;
+    }
     if (what == 2) {   // pointer loads vs buffer loads with loop-invariant lane offsets (A/B inside one process, interleaved)
         g_stagger = 1;
         for (int round = 0; round < 4; ++round) {

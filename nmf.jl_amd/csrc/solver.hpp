@@ -567,6 +567,12 @@ template <typename T> class Solver : public SolverBase {
         int best = 1;
         for (int d = 1; d <= want; ++d)
             if (nkt % d == 0 && nkt / d >= 8) best = d;
+        // short pieces (< 64 k-tiles per block: prologue, first-load latency and epilogue are ~10 % of such a block, and every split is a
+        // slab to write and to combine): back off to the largest split that still gives every CU a block and 64 k-tiles per block
+        // (the 8-rank shard of the headline problem: 16 -> 8 splits, 163 -> 159 us in gemm_bench 6 4, half the slabs to combine)
+        if (nkt / best < 64)
+            for (int d = best - 1; d >= 1; --d)
+                if (nkt % d == 0 && nkt / d >= 64 && (int64_t)tiles * d >= num_cu) { best = d; break; }
         return best;
     }
 

@@ -83,6 +83,21 @@ int main(int argc, char **argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 6;
     const int what = argc > 2 ? atoi(argv[2]) : 0;
     g_mode = 1;
+    if (what == 4) {   // the 8-rank shard shapes: tile shapes / splits with buffer-load staging
+        g_stagger = 1;
+        for (int round = 0; round < 3; ++round) {
+            printf("--- round %d\n", round);
+            run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 1>("NT sh8 128x128 s1", 256, 16384, 2048, 1, false, reps);
+            run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 1>("NT sh8 128x128 s2", 256, 16384, 2048, 2, false, reps);
+            run<float, KSTRIDED, KSTRIDED, 128, 64, 4, 1, 1>("NT sh8 128x64 s1", 256, 16384, 2048, 1, false, reps);
+            run<float, KSTRIDED, KSTRIDED, 64, 128, 1, 4, 1>("NT sh8 64x128 s1", 256, 16384, 2048, 1, false, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 2>("TN sh8 128x128 s16", 2048, 256, 16384, 16, true, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 2>("TN sh8 128x128 s8", 2048, 256, 16384, 8, true, reps);
+            run<float, KCONTIG, KCONTIG, 128, 64, 4, 1, 1>("TN sh8 128x64 s8", 2048, 256, 16384, 8, true, reps);
+            run<float, KCONTIG, KCONTIG, 64, 128, 1, 4, 1>("TN sh8 64x128 s8", 2048, 256, 16384, 8, true, reps);
+        }
+        return 0;
+    }
     if (what == 3) {   // buffer loads vs buffer loads + k-loop unrolled by two (LDS stage offsets as immediates)
         g_stagger = 1;
         for (int round = 0; round < 4; ++round) {

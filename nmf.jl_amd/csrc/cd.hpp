@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "kernels.hpp"
@@ -424,12 +425,80 @@ __global__ __launch_bounds__(ROWS * 4) void cd_sweep_blocked_kernel(SampleView<c
 // recompute S, D;  q = argmax.   Finally W = max(W + Wnew, 0) (:160-161).
 // G arrives as W*P - Z from the GEMM; + lambda (:113-115) is applied on load.
 // ---------------------------------------------------------------------------
+// max(zero(T), t) of the greedy step.  Float32: ONE integer maximum on the bits -- negative values and -0 have the sign bit set (a
+// negative integer) and become +0, positive values and NaN are positive integers and pass (Julia's max(0, NaN) is NaN too; a NaN
+// with the sign bit set would become 0, which changes nothing: its component's G is NaN, so its D is, and NaN components are never
+// picked) -- instead of a comparison, the wait states of its mask, and a select.
+__device__ __forceinline__ float clamp0(float t) { const int b = __float_as_int(t); return __int_as_float(b < 0 ? 0 : b); }
+__device__ __forceinline__ double clamp0(double t) { return (t <= 0.0) ? 0.0 : t; }
+
 template <typename T> __device__ __forceinline__ void greedy_sd(T w, T g, T prr, T den, double rden, T &s, T &d) {
-    T t = op_sub(w, greedy_div(g, den, rden));
-    t = (t <= (T)0) ? (T)0 : t;   // max(zero(T), t): a NaN fails the comparison and passes through like Julia's max (one compare instead of two)
+    const T t = clamp0(op_sub(w, greedy_div(g, den, rden)));   // max(zero(T), .)
     s = op_sub(t, w);
     d = op_sub(op_mul(-g, s), op_mul(op_mul((T)0.5, prr), op_mul(s, s)));
 }
+
+// Float32 single operations as asm statements: exactly one rounded operation each (nothing to contract), and out of reach of the SLP
+// vectoriser, which pairs the slots of the greedy step into v_pk_mul/add_f32 and then spends a v_mov per operand re-pairing them
+// (10 moves per step in the k = 256 form; the plain v_mul/v_add/v_sub issue at 1.1 ns, a v_pk at 1.8: nothing to gain from pairs).
+__device__ __forceinline__ float f32_mul(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float f32_mul_s(float a_uniform, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "s"(a_uniform), "v"(b)); return r; }
+__device__ __forceinline__ float f32_negmul(float a, float b) { float r; asm("v_mul_f32_e64 %0, -%1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }   // (-a) * b
+__device__ __forceinline__ float f32_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float f32_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// S(q) -> a wave-uniform value, and Wnew(q) += S(q) in the owner lane, by a wave-uniform switch over the owner SLOT q / 64: one
+// v_readlane and one v_add under the owner lane's mask (the generic form selects S's slot with KMAX - 1 vector selects and updates
+// Wnew with KMAX adds and KMAX selects: 17 vector instructions of the ~85 of a k = 256 step).  The two scalar instructions between
+// the v_readlane and the v_add are the wait states a VALU read of a VALU-written SGPR needs.
+// (ONE asm statement with its own branches: written as a C++ switch, the merge of the cases comes back as vector moves or selects per
+// slot -- the instructions this form is there to remove.  All paths meet at the last label; exec is restored there.)
+#define NMFX_TAKE_CASE(S, W) "v_readlane_b32 %[sq], " S ", %[ql]\n\ts_nop 1\n\tv_add_f32 " W ", %[sq], " W "\n\t"
+__device__ __forceinline__ float greedy_take(const float (&s)[1], float (&w)[1], int, int ql) {
+    float sq; unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\ts_lshl_b64 exec, 1, %[ql]\n\t" NMFX_TAKE_CASE("%[s0]", "%[w0]") "s_mov_b64 exec, %[sv]"
+                 : [sq] "=&s"(sq), [sv] "=&s"(sv), [w0] "+v"(w[0]) : [s0] "v"(s[0]), [ql] "s"(ql));
+    return sq;
+}
+__device__ __forceinline__ float greedy_take(const float (&s)[2], float (&w)[2], int qm, int ql) {
+    float sq; unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\ts_lshl_b64 exec, 1, %[ql]\n\t"
+                 "s_cmp_eq_u32 %[qm], 0\n\ts_cbranch_scc0 1f\n\t"
+                 NMFX_TAKE_CASE("%[s0]", "%[w0]") "s_branch 4f\n"
+                 "1:\n\t" NMFX_TAKE_CASE("%[s1]", "%[w1]")
+                 "4:\n\ts_mov_b64 exec, %[sv]"
+                 : [sq] "=&s"(sq), [sv] "=&s"(sv), [w0] "+v"(w[0]), [w1] "+v"(w[1]) : [s0] "v"(s[0]), [s1] "v"(s[1]), [qm] "s"(qm), [ql] "s"(ql) : "scc");
+    return sq;
+}
+__device__ __forceinline__ float greedy_take(const float (&s)[3], float (&w)[3], int qm, int ql) {
+    float sq; unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\ts_lshl_b64 exec, 1, %[ql]\n\t"
+                 "s_cmp_lt_u32 %[qm], 2\n\ts_cbranch_scc0 2f\n\t"
+                 "s_cmp_eq_u32 %[qm], 0\n\ts_cbranch_scc0 1f\n\t"
+                 NMFX_TAKE_CASE("%[s0]", "%[w0]") "s_branch 4f\n"
+                 "1:\n\t" NMFX_TAKE_CASE("%[s1]", "%[w1]") "s_branch 4f\n"
+                 "2:\n\t" NMFX_TAKE_CASE("%[s2]", "%[w2]")
+                 "4:\n\ts_mov_b64 exec, %[sv]"
+                 : [sq] "=&s"(sq), [sv] "=&s"(sv), [w0] "+v"(w[0]), [w1] "+v"(w[1]), [w2] "+v"(w[2])
+                 : [s0] "v"(s[0]), [s1] "v"(s[1]), [s2] "v"(s[2]), [qm] "s"(qm), [ql] "s"(ql) : "scc");
+    return sq;
+}
+__device__ __forceinline__ float greedy_take(const float (&s)[4], float (&w)[4], int qm, int ql) {
+    float sq; unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\ts_lshl_b64 exec, 1, %[ql]\n\t"
+                 "s_cmp_lt_u32 %[qm], 2\n\ts_cbranch_scc0 2f\n\t"
+                 "s_cmp_eq_u32 %[qm], 0\n\ts_cbranch_scc0 1f\n\t"
+                 NMFX_TAKE_CASE("%[s0]", "%[w0]") "s_branch 4f\n"
+                 "1:\n\t" NMFX_TAKE_CASE("%[s1]", "%[w1]") "s_branch 4f\n"
+                 "2:\n\ts_cmp_eq_u32 %[qm], 2\n\ts_cbranch_scc0 3f\n\t"
+                 NMFX_TAKE_CASE("%[s2]", "%[w2]") "s_branch 4f\n"
+                 "3:\n\t" NMFX_TAKE_CASE("%[s3]", "%[w3]")
+                 "4:\n\ts_mov_b64 exec, %[sv]"
+                 : [sq] "=&s"(sq), [sv] "=&s"(sv), [w0] "+v"(w[0]), [w1] "+v"(w[1]), [w2] "+v"(w[2]), [w3] "+v"(w[3])
+                 : [s0] "v"(s[0]), [s1] "v"(s[1]), [s2] "v"(s[2]), [s3] "v"(s[3]), [qm] "s"(qm), [ql] "s"(ql) : "scc");
+    return sq;
+}
+#undef NMFX_TAKE_CASE
 
 // Wave-wide maximum by DPP row shifts + row broadcasts (an inclusive scan: the total lands in lane 63) instead of ds_bpermute round
 // trips through the LDS crossbar -- this reduction sits on the dependency chain of EVERY greedy step.  The result is wave-uniform
@@ -488,6 +557,12 @@ template <typename T> __device__ __forceinline__ T wave_max_uniform(T v) {
     return lane63(v);
 }
 
+// max(a, b) / max(a, b, c) that SKIP NaN operands (v_max_f32 / v_max_f64 in IEEE mode return the non-NaN operand)
+__device__ __forceinline__ float max_skip_nan(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max3_skip_nan(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ double max_skip_nan(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double max3_skip_nan(double a, double b, double c) { return max_skip_nan(max_skip_nan(a, b), c); }
+
 template <typename T, int KMAX> struct GreedyRow {
     T w[KMAX], g[KMAX], s[KMAX], d[KMAX], prr[KMAX], den[KMAX];   // den = eps + P(r, r) (greedycd.jl:121, :151)
     double rden[KMAX];                                              // 1 / den (Float32 rows only; dead code for Float64)
@@ -498,7 +573,10 @@ template <typename T, int KMAX> struct GreedyRow {
             const int c = lane + 64 * m;
             const bool ok = (m < km) && (c < k);
             w[m] = ok ? W.at(i, c) : (T)0;
-            g[m] = ok ? G.at(i, c) : (T)0;
+            // a lane without a component (c >= k) carries G = +inf: S = max(0, 0 - inf) - 0 = 0 and D = -inf * 0 - ... = NaN, now and after
+            // every step (its entries of P's rows are the zero padding: inf + S(q) * 0 = inf), and NaN is what the arg-max skips -- the
+            // FULL forms need no validity masks for it
+            g[m] = ok ? G.at(i, c) : (T)INFINITY;
             if (ok && lambda > (T)0) g[m] = op_add(g[m], lambda);
             prr[m] = ok ? P[(int64_t)c * ldp + c] : (T)1;
             den[m] = op_add(epsT, prr[m]);
@@ -509,22 +587,39 @@ template <typename T, int KMAX> struct GreedyRow {
     // arg-max of D with the first index on ties: the VALUE by a DPP max reduction (2 operations per step instead of the 7 of a
     // (value, index) reduction -- this sits on every greedy step's dependency chain), then the index from wave ballots: slots are
     // visited in ascending m and a slot's lowest set lane is its smallest component index c = lane + 64 m
-    // FULL: k == 64 * KMAX -- every (lane, slot) is a live component, no validity masks
+    // FULL: ceil(k / 64) == KMAX -- every slot is live, and the lanes of the last one beyond k hold D = NaN (see load): no validity masks
     template <bool FULL = false> __device__ __forceinline__ void argmax(int k, int km, int lane, T &best, int &q) const {
         best = -INFINITY;
+        if constexpr (FULL) {
+            // `d > best ? d : best` from -inf == the NaN-skipping maximum (v_max: a NaN operand yields the other one), and v_max3 takes
+            // two slots per instruction; signed zeros compare equal everywhere the value is used
 #pragma unroll
-        for (int m = 0; m < KMAX; ++m) {
-            const int c = lane + 64 * m;
-            const bool take = (FULL || ((m < km) && (c < k))) && (d[m] > best);
-            best = take ? d[m] : best;
+            for (int m = 0; m + 1 < KMAX; m += 2) best = max3_skip_nan(best, d[m], d[m + 1]);
+            if constexpr (KMAX & 1) best = max_skip_nan(best, d[KMAX - 1]);
+        } else {
+#pragma unroll
+            for (int m = 0; m < KMAX; ++m) {
+                const int c = lane + 64 * m;
+                const bool take = ((m < km) && (c < k)) && (d[m] > best);
+                best = take ? d[m] : best;
+            }
         }
         best = wave_max_uniform(best);
-        q = 0x7fffffff;
+        if constexpr (FULL) {          // from the last slot down: the lowest slot with a hit wins (s_ff1 of an empty ballot is -1: unused)
+            q = 64 * (KMAX - 1) + (__ffsll((long long)__builtin_amdgcn_ballot_w64(d[KMAX - 1] == best)) - 1);
 #pragma unroll
-        for (int m = 0; m < KMAX; ++m) {
-            const int c = lane + 64 * m;
-            const unsigned long long hit = __builtin_amdgcn_ballot_w64((FULL || ((m < km) && (c < k))) && (d[m] == best));
-            if (hit != 0ull && q == 0x7fffffff) q = 64 * m + (int)__builtin_ctzll(hit);
+            for (int m = KMAX - 2; m >= 0; --m) {
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(d[m] == best);
+                q = (hit != 0ull) ? 64 * m + (int)__builtin_ctzll(hit) : q;
+            }
+        } else {
+            q = 0x7fffffff;
+#pragma unroll
+            for (int m = 0; m < KMAX; ++m) {
+                const int c = lane + 64 * m;
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(((m < km) && (c < k)) && (d[m] == best));
+                if (hit != 0ull && q == 0x7fffffff) q = 64 * m + (int)__builtin_ctzll(hit);
+            }
         }
     }
 };
@@ -557,9 +652,10 @@ __global__ __launch_bounds__(256) void greedy_pinit_kernel(SampleView<const T> W
 }
 
 // pinit[0] = max(part[0..n))  (one block)
-template <typename T> __global__ void greedy_pinit_reduce_kernel(const T *part, int n, T *pinit, const int *done) {
+template <typename T> __global__ void greedy_pinit_reduce_kernel(const T *part, int n, T *pinit, int *queue, const int *done) {
     NMFX_DONE_GUARD(done);
     __shared__ T sm[4];
+    if (queue != nullptr && threadIdx.x < 32) queue[threadIdx.x * 32] = 0;   // the sweep's row counters (GREEDY_NQ x GREEDY_QSTRIDE, declared below)
     T b = (T)-1;
     for (int i = threadIdx.x; i < n; i += blockDim.x) b = (part[i] > b) ? part[i] : b;
     b = wave_max(b);
@@ -581,30 +677,64 @@ __device__ __forceinline__ long long greedy_sweep_row(SampleView<const T> Wold, 
     T wnew[KMAX];
 #pragma unroll
     for (int m = 0; m < KMAX; ++m) wnew[m] = (T)0;
+    T hprr[KMAX];                                   // 0.5 * P(r, r): the first product of  0.5 * P(r, r) * S(r)^2  (:124, :153), loop-invariant
+#pragma unroll
+    for (int m = 0; m < KMAX; ++m) hprr[m] = op_mul((T)0.5, row.prr[m]);
     const T thresh = op_mul((T)0.001, pinit[0]);   // nu * p_init
     T dq; int q;
     row.template argmax<FULL>(k, km, lane, dq, q);
-    const long long max_steps = (long long)k * k;
-    long long step = 0;
+    const int max_steps = k * k;                    // k <= 1024 in this register form
+    int step = 0;
     for (; step < max_steps; ++step) {
         if (dq < thresh) break;                       // wave-uniform (dq, q come out of wave_argmax as scalars)
         // S(q): owned by lane q % 64, slot q / 64
         const int ql = q & 63, qm = q >> 6;
-        T sq_owner = row.s[0];
-#pragma unroll
-        for (int m = 1; m < KMAX; ++m) sq_owner = (m == qm) ? row.s[m] : sq_owner;
-        const T sq = lane_read(sq_owner, ql);
+        constexpr bool TAKE = FULL && KMAX <= 4 && std::is_same<T, float>::value;
+        T sq;
+        T pq[KMAX];
         if constexpr (FULL) {
-            // all KMAX loads of the row P(q, :) in flight at once, then the arithmetic (the per-slot `m < km` test of the general
-            // form below is a branch per slot, each with its own load -> wait -> compute round trip)
-            T pq[KMAX];
+            // all KMAX loads of the row P(q, :) in flight at once, and issued first: their latency runs under the owner-slot switch
+            // (the per-slot `m < km` test of the general form below is a branch per slot, each with its own load -> wait -> compute
+            // round trip)
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) pq[m] = fetch(q, m);
+        }
+        if constexpr (TAKE) {
+            sq = greedy_take(row.s, wnew, qm, ql);
+        } else {
+            T sq_owner = row.s[0];
 #pragma unroll
-            for (int m = 0; m < KMAX; ++m) {
-                wnew[m] = (m == qm && lane == ql) ? op_add(wnew[m], sq) : wnew[m];
-                row.g[m] = op_add(row.g[m], op_mul(sq, pq[m]));
-                greedy_sd(row.w[m], row.g[m], row.prr[m], row.den[m], row.rden[m], row.s[m], row.d[m]);
+            for (int m = 1; m < KMAX; ++m) sq_owner = (m == qm) ? row.s[m] : sq_owner;
+            sq = lane_read(sq_owner, ql);
+        }
+        if constexpr (FULL) {
+            if constexpr (!TAKE) {
+#pragma unroll
+                for (int m = 0; m < KMAX; ++m) wnew[m] = (m == qm && lane == ql) ? op_add(wnew[m], sq) : wnew[m];
+            }
+            T t[KMAX];
+            if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                for (int m = 0; m < KMAX; ++m) {
+                    row.g[m] = f32_add(row.g[m], f32_mul_s(sq, pq[m]));
+                    t[m] = f32_sub(row.w[m], greedy_div(row.g[m], row.den[m], row.rden[m]));
+                }
+#pragma unroll
+                for (int m = 0; m < KMAX; ++m) {
+                    row.s[m] = f32_sub(clamp0(t[m]), row.w[m]);
+                    row.d[m] = f32_sub(f32_negmul(row.g[m], row.s[m]), f32_mul(hprr[m], f32_mul(row.s[m], row.s[m])));
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < KMAX; ++m) {
+                    row.g[m] = op_add(row.g[m], op_mul(sq, pq[m]));
+                    t[m] = op_sub(row.w[m], greedy_div(row.g[m], row.den[m], row.rden[m]));
+                }
+#pragma unroll
+                for (int m = 0; m < KMAX; ++m) {
+                    row.s[m] = op_sub(clamp0(t[m]), row.w[m]);
+                    row.d[m] = op_sub(op_mul(-row.g[m], row.s[m]), op_mul(hprr[m], op_mul(row.s[m], row.s[m])));
+                }
             }
         } else {
 #pragma unroll
@@ -631,19 +761,56 @@ __device__ __forceinline__ long long greedy_sweep_row(SampleView<const T> Wold, 
     return step;
 }
 
-template <typename T, int KMAX>
+// Rows take very different numbers of greedy steps (16384^2, k = 256, settled factors: mean 232, 99th percentile 343, maximum 577), and
+// a launch of one row per wave ends with a few long rows stepping alone at the chain latency (~390 ns per step against the ~110 ns
+// of eight waves sharing a SIMD).  So the launch is PERSISTENT: gridDim.x * 4 waves, as many as are resident at once; wave w starts
+// with row w, and every further row comes from GREEDY_NQ shared counters (contiguous ranges of the remaining rows; a wave drains its
+// home range, then helps with the others).  The counters live 128 bytes apart (atomics on one address serialise at ~30 ns each) and
+// are zeroed by greedy_pinit_reduce_kernel, which always precedes this launch.  Which wave sweeps which row does not change any
+// result: rows are independent.
+constexpr int GREEDY_NQ = 32, GREEDY_QSTRIDE = 32;   // counters, ints between two counters
+__device__ __forceinline__ int64_t greedy_next_row(int *queue, int64_t first_dyn, int64_t nsamples, int home, int lane) {
+    const int64_t per = (nsamples - first_dyn + GREEDY_NQ - 1) / GREEDY_NQ;   // rows per range (the last ones may be short or empty)
+    for (;;) {
+        // lanes 0 .. NQ-1 look at one counter each (plain loads: exhausted ranges cost no atomic)
+        const int64_t lo_l = first_dyn + (int64_t)lane * per;
+        const int64_t len_l = (lane < GREEDY_NQ) ? (nsamples - lo_l < per ? nsamples - lo_l : per) : 0;
+        int cnt = 0x7fffffff;
+        if (lane < GREEDY_NQ && len_l > 0) cnt = __hip_atomic_load(queue + lane * GREEDY_QSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned open = (unsigned)__builtin_amdgcn_ballot_w64((int64_t)cnt < len_l);
+        if (open == 0u) return nsamples;                                        // everything is handed out
+        const unsigned rot = (open >> home) | (open << ((GREEDY_NQ - home) & 31));   // the home range first, then the following ones
+        const int pick = (home + __builtin_ctz(rot)) & (GREEDY_NQ - 1);
+        int r = 0;
+        if (lane == 0) r = atomicAdd(queue + pick * GREEDY_QSTRIDE, 1);
+        r = __builtin_amdgcn_readfirstlane(r);
+        const int64_t lo = first_dyn + (int64_t)pick * per;
+        const int64_t len = nsamples - lo < per ? nsamples - lo : per;
+        if (r < len) return lo + r;                                             // else: lost the race for the range's last rows; look again
+    }
+}
+
+template <typename T, int KMAX, bool FULL>   // FULL: ceil(k / 64) == KMAX (two kernels rather than two forms in one: each stays within 64 registers)
 __global__ __launch_bounds__(256) void greedy_sweep_kernel(SampleView<const T> Wold, SampleView<T> Wout, SampleView<const T> G,
                                                            const T *__restrict__ P, int64_t ldp, int64_t nsamples, int k, T lambda,
-                                                           T epsT, const T *pinit, long long *steps_total, const int *done) {
+                                                           T epsT, const T *pinit, int *queue, long long *steps_total, const int *done) {
     NMFX_DONE_GUARD(done);
     __shared__ long long nsteps[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t first_dyn = (int64_t)gridDim.x * 4;
+    const int home = (int)(blockIdx.x & (GREEDY_NQ - 1));
+    // (uniform row base + a 32-bit lane offset: the saddr form of the load, no 64-bit vector address arithmetic per step)
+    const unsigned ldp32 = (unsigned)ldp, lane32 = (unsigned)lane;
+    auto fetch = [&](int q, int m) { const T *rowp = P + (unsigned)q * ldp32; return rowp[lane32 + 64u * (unsigned)m]; };
     long long steps = 0;
-    if (i < nsamples) {
-        auto fetch = [&](int q, int m) { return P[(int64_t)q * ldp + lane + 64 * m]; };
-        if (k == 64 * KMAX) steps = greedy_sweep_row<T, KMAX, true>(Wold, Wout, G, P, ldp, i, k, lambda, epsT, pinit, lane, fetch);
-        else steps = greedy_sweep_row<T, KMAX, false>(Wold, Wout, G, P, ldp, i, k, lambda, epsT, pinit, lane, fetch);
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < nsamples;
+         i = (first_dyn < nsamples) ? greedy_next_row(queue, first_dyn, nsamples, home, lane) : nsamples) {
+        // an opaque copy of the lane number per row: nothing lane-dependent is hoisted out of the row loop (the 64-bit offsets of the
+        // row's loads and stores, P(r, r), 1 / (eps + P(r, r)): ~40 registers across the launch, i.e. 5 waves per SIMD instead of 8, to
+        // save ~60 instructions per row)
+        int lane_r = lane;
+        asm volatile("" : "+v"(lane_r));
+        steps += greedy_sweep_row<T, KMAX, FULL>(Wold, Wout, G, P, ldp, i, k, lambda, epsT, pinit, lane_r, fetch);
     }
     // executed greedy steps (nmfx_result.inner_iters): one atomic per block, not per row (16384 atomics on one address are
     // serialised at ~30 ns each on this chip)

@@ -17,6 +17,11 @@ template <typename T> template <typename F> void Solver<T>::with_kmax(F &&f) {
     else if (k <= 1024) f(std::integral_constant<int, 16>{});
     else throw StatusError{NMFX_ERR_UNSUPPORTED, "internal: with_kmax beyond the register forms (k > 1024 runs the LDS forms)"};
 }
+// GreedyCD: also 3 slots (k in 129..192) -- its fast form needs every slot live (cd.hpp, FULL)
+template <typename T> template <typename F> void Solver<T>::with_kmax_greedy(F &&f) {
+    if (k > 128 && k <= 192) f(std::integral_constant<int, 3>{});
+    else with_kmax(std::forward<F>(f));
+}
 // k > 1024 (or NMFX_CD_LDS=1): the LDS forms of the sweeps (cd.hpp), one wave per sample row
 template <typename T> bool Solver<T>::cd_use_lds() const { return k > 1024 || cd_force_lds; }
 static inline void cd_lds_check(size_t bytes) {
@@ -212,6 +217,7 @@ void Solver<T>::greedy_side(const char *tag, SampleView<const T> Zo, SampleView<
     // (sized once for BOTH sides: growing it between the W side and the H side would hipFree -- a device-wide synchronisation -- in the
     // middle of an iteration, which deadlocks several in-process ranks whose peers spin on the device for this rank's next flag)
     work[3].ensure((size_t)std::max(P, N) + 16);
+    greedy_queue.ensure((size_t)GREEDY_NQ * GREEDY_QSTRIDE);
     T *part = work[3].p, *pinit = work[3].p + blocks;
     if (cd_use_lds()) {
         const int kp = (int)((k + 63) / 64 * 64);
@@ -224,7 +230,7 @@ void Solver<T>::greedy_side(const char *tag, SampleView<const T> Zo, SampleView<
             if (nsamples > 0)
                 hipLaunchKernelGGL((greedy_pinit_lds_kernel<T>), dim3((unsigned)nsamples), dim3(64), lds, stream, Zo, G, Pm, K, nsamples, (int)k, lambda, epsT,
                                    part1, done);
-            hipLaunchKernelGGL(greedy_pinit_reduce_kernel<T>, dim3(1), dim3(256), 0, stream, part1, (int)nsamples, pinit1, done);
+            hipLaunchKernelGGL(greedy_pinit_reduce_kernel<T>, dim3(1), dim3(256), 0, stream, part1, (int)nsamples, pinit1, (int *)nullptr, done);
             if (sharded_samples && sharded()) comm->all_reduce(pinit1, 1, CT, true, stream);
             if (nsamples > 0)
                 hipLaunchKernelGGL((greedy_sweep_lds_kernel<T>), dim3((unsigned)nsamples), dim3(64), lds, stream, Zo, Zn, G, Pm, K, nsamples, (int)k, lambda,
@@ -234,15 +240,27 @@ void Solver<T>::greedy_side(const char *tag, SampleView<const T> Zo, SampleView<
         return;
     }
     timed(tag, 0.0, 4.0 * (double)nsamples * K * sizeof(T), [&] {
-        with_kmax([&](auto KM) {
+        with_kmax_greedy([&](auto KM) {
             constexpr int KMAX = decltype(KM)::value;
             hipLaunchKernelGGL((greedy_pinit_kernel<T, KMAX>), dim3(blocks), dim3(256), 0, stream, Zo, G, Pm, K, nsamples, (int)k, lambda,
                                epsT, part, done);
-            hipLaunchKernelGGL(greedy_pinit_reduce_kernel<T>, dim3(1), dim3(256), 0, stream, part, (int)blocks, pinit, done);
+            hipLaunchKernelGGL(greedy_pinit_reduce_kernel<T>, dim3(1), dim3(256), 0, stream, part, (int)blocks, pinit, greedy_queue.p, done);
             if (sharded_samples && sharded())   // p_init is the maximum over ALL samples (greedycd.jl:127-132)
                 comm->all_reduce(pinit, 1, CT, true, stream);
-            hipLaunchKernelGGL((greedy_sweep_kernel<T, KMAX>), dim3(blocks), dim3(256), 0, stream, Zo, Zn, G, Pm, K, nsamples, (int)k,
-                               lambda, epsT, pinit, &ctrl->inner_iters, done);
+            // persistent launch: the waves that are resident at once; the rows beyond them are handed out through greedy_queue (cd.hpp)
+            auto launch = [&](auto full) {
+                constexpr bool FULL = decltype(full)::value;
+                static const int per_cu = [] {
+                    int nb = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&greedy_sweep_kernel<T, KMAX, FULL>), 256, 0) != hipSuccess || nb < 1) nb = 1;
+                    return nb;
+                }();
+                const unsigned sweep_blocks = (unsigned)std::min<int64_t>(blocks, (int64_t)per_cu * num_cu);
+                hipLaunchKernelGGL((greedy_sweep_kernel<T, KMAX, FULL>), dim3(sweep_blocks), dim3(256), 0, stream, Zo, Zn, G, Pm, K, nsamples, (int)k,
+                                   lambda, epsT, pinit, greedy_queue.p, &ctrl->inner_iters, done);
+            };
+            if ((k + 63) / 64 == KMAX) launch(std::true_type{});   // every slot live
+            else launch(std::false_type{});
         });
         HIP_TRY(hipGetLastError());
     });

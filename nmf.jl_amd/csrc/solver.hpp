@@ -1138,12 +1138,14 @@ template <typename T> class Solver : public SolverBase {
     void enqueue_cd(const nmfx_opts &o, long long t);
     void enqueue_greedycd(const nmfx_opts &o, long long t);
     template <typename F> void with_kmax(F &&f);
+    template <typename F> void with_kmax_greedy(F &&f);
     bool cd_use_lds() const;
     bool cd_force_lds = false;   // NMFX_CD_LDS=1: the LDS forms of the sweeps also for k <= 1024 (tests: bit-identical to the register forms)
     int cd_blocked = -1;                 // NMFX_CD_BLOCKED=0: CoordinateDescent on the row-chain sweep kernels instead of the blocked one (k <= 512)
     void prepare_cd_permutations(const nmfx_opts &o);
     const int *cd_permutation_window(const nmfx_opts &o, long long t);
     static constexpr long long CD_PERM_WINDOW = 256;
+    DevBuf<int> greedy_queue;   // GreedyCD's sweep: the row counters of the persistent launch (cd.hpp, GREEDY_NQ x GREEDY_QSTRIDE ints)
     DevBuf<int> cd_perm;   // CoordinateDescent(shuffle = true): the component orders of a window of iterations
     std::vector<int> cd_perm_host;
     long long cd_perm_w0 = -1;

@@ -295,11 +295,15 @@ def main():
 
     if a.warmup > 0:
         ctx.iterate(algid, opts(a.warmup))
-    # hipEvent pairs on the solver stream around the dominant GEMM launches and the collectives (a pair costs ~10 us): 1 launch
-    # in 8 sampled, 1 in 2 for short runs so that the roofline of a 20-step line still rests on >= 10 launches per kernel
+    # hipEvent pairs on the solver stream around the dominant GEMM launches and the collectives: 1 launch in 8 sampled, 1 in 4 for
+    # short runs so that the roofline of a 20-step line still rests on 5 launches per kernel (1 in 2 cost 0.075 ms per iteration)
     # (ProjectedALS: 1 in 16 -- its factorisations run on a second stream whose ordering events queue behind a bracket)
     prof_mode = 0 if a.no_events else (1 if a.all_events else (4 if a.alg == "projals" else (3 if a.steps <= 32 else 2)))
     ctx.profile_enable(prof_mode)
+    # Result.objvalue is evaluated AFTER the timed regions (nmfx_objective below): it is not part of an iteration -- nmf_skeleton!
+    # evaluates it once per solve, behind the loop (src/common.jl:85-87) -- and one more p*n*k product inside a K-step call would
+    # count as 1/K of a step (2.5 % at K = 20)
+    ctx.set_final_objective(False)
     barrier()
     t0 = time.perf_counter()
     res, _ = ctx.iterate(algid, opts(a.steps))
@@ -326,6 +330,8 @@ def main():
             tt = torch.tensor([dt_plain], device=("cpu" if (dev_sim or dev_gloo) else device), dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_plain = float(tt.item())
+    ctx.set_final_objective(True)
+    final_objvalue = float(ctx.objective(algid, opts(1)))     # of the factors the last timed region left (collective when sharded)
     wd.disarm()
     if world > 1:
         import torch.distributed as dist
@@ -341,12 +347,12 @@ def main():
         import torch.distributed as dist
         Wchk = np.empty((p, k), dtype=T, order="F")
         ctx.get_factors(Wchk, None)
-        mine = (hashlib.sha256(Wchk.tobytes()).hexdigest(), float(res.objvalue), bool(np.isfinite(Wchk).all()))
+        mine = (hashlib.sha256(Wchk.tobytes()).hexdigest(), final_objvalue, bool(np.isfinite(Wchk).all()))
         allv = [None] * world
         dist.all_gather_object(allv, mine)
         consistency = {"W_identical_on_all_ranks": len({v[0] for v in allv}) == 1,
                        "objective_identical_on_all_ranks": len({v[1] for v in allv}) == 1,
-                       "finite": all(v[2] for v in allv) and bool(np.isfinite(res.objvalue))}
+                       "finite": all(v[2] for v in allv) and bool(np.isfinite(final_objvalue))}
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -407,12 +413,12 @@ def main():
             # `value` / `ms_per_step` are the region with the sampled hipEvent brackets (the roofline's launch times come from it);
             # the same K steps without any bracket right behind it:
             "ms_per_step_no_events": (round(dt_plain / a.steps * 1e3, 4) if dt_plain is not None else round(ms, 4)),
-            "event_brackets": {0: "none", 1: "every launch", 2: "1 launch in 8 of the dominant GEMMs", 3: "1 launch in 2 of the dominant GEMMs",
+            "event_brackets": {0: "none", 1: "every launch", 2: "1 launch in 8 of the dominant GEMMs", 3: "1 launch in 4 of the dominant GEMMs",
                                4: "1 launch in 16 of the dominant GEMMs"}[prof_mode],
             "gflops_algorithmic": round(f_alg * a.steps / dt / 1e9, 1),
             "frac_of_mfma_peak": round(f_alg * a.steps / dt / 1e12 / (((2500.0 / 3.0) if a.precision == "bf16x3" else
                                                                         (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6)) * world), 4),
-            "objvalue": res.objvalue,
+            "objvalue": final_objvalue,   # evaluated after the timed region (see above)
             "roofline": roof,
             # per kernel: average launch time; algorithmic TFLOP/s and algorithmic HBM GB/s where the launch site states them
             "kernels": [dict({"name": s["name"], "launches": s["launches"], "avg_us": round(s["ms_total"] / s["launches"] * 1e3, 2)},

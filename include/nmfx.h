@@ -293,8 +293,12 @@ typedef struct {
     double bytes;         /* algorithmic HBM bytes summed over launches */
 } nmfx_kernel_stat;
 int nmfx_profile_enable(nmfx_ctx *ctx, int mode);  /* 0 off; 1 hipEvent pair around every launch (slow: ~10 us each);
-                                                       2 only the dominant GEMM launches, every 8th (live roofline); 3: every 2nd; 4: every 16th */
+                                                       2 only the dominant GEMM launches, every 8th (live roofline); 3: every 4th; 4: every 16th */
 int nmfx_profile_get(nmfx_ctx *ctx, nmfx_kernel_stat *out, int max_entries, int *n_entries);
+/* on = 1 (default): nmfx_iterate / nmfx_solve evaluate Result.objvalue after the loop, as nmf_skeleton! does (src/common.jl:85-87).
+ * on = 0: they leave it NaN -- for a caller that times K iterations and asks nmfx_objective afterwards (the evaluation is one more
+ * p*n*k product: 1 ms at 16384^2, k = 256, i.e. 2.5 % of a 20-iteration call). */
+int nmfx_set_final_objective(nmfx_ctx *ctx, int on);
 int nmfx_device_info(int device, char *name_out, int name_len, int *cu_count, int64_t *hbm_bytes);
 
 #ifdef __cplusplus

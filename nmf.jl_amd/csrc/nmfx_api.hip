@@ -262,6 +262,11 @@ int nmfx_profile_enable(nmfx_ctx *ctx, int on) {
     return guarded(ctx, [&] { ctx->impl->profile_enable(on); });
 }
 
+int nmfx_set_final_objective(nmfx_ctx *ctx, int on) {
+    if (!ctx) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->set_final_objective(on != 0); });
+}
+
 int nmfx_profile_get(nmfx_ctx *ctx, nmfx_kernel_stat *out, int max_entries, int *n_entries) {
     if (!ctx || !out || !n_entries) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { *n_entries = ctx->impl->profile_get(out, max_entries); });

@@ -90,6 +90,7 @@ struct SolverBase {
     virtual void nndsvd_init(const void *U_host, const void *s_host, const void *V_host, int variant, bool zeroh, uint64_t seed,
                              int64_t n_total) = 0;
     virtual void profile_enable(int mode) = 0;
+    virtual void set_final_objective(bool on) = 0;
     virtual int profile_get(nmfx_kernel_stat *out, int max_entries) = 0;
 };
 
@@ -365,8 +366,12 @@ template <typename T> class Solver : public SolverBase {
     // mode 0: off; 1: hipEvent pair around EVERY launch (each pair costs ~10 us of stream time: use for
     // per-kernel breakdowns, not for throughput); 2: only the dominant GEMM launches (the p*n*k products) and the
     // collectives, every 8th one -- the live roofline measurement of bench.py, < 0.5 % overhead on the timed region;
-    // 3: the same launches, every 2nd one (short runs: the driver's 20-step line then rests on >= 10 samples per kernel);
+    // 3: the same launches, every 4th one (short runs: a 20-step line rests on 5 samples per kernel; every 2nd cost 0.075 ms per iteration);
     // 4: every 16th (ProjectedALS: a bracket on the main stream delays the factorisation stream's ordering events, ~0.4 ms per bracketed iteration).
+    // nmfx_set_final_objective: off = nmfx_iterate leaves Result.objvalue NaN instead of evaluating it after the loop (a caller that
+    // times K iterations -- bench.py -- asks nmfx_objective for it afterwards; the evaluation is one more p*n*k product)
+    bool final_objective = true;
+    void set_final_objective(bool on) override { final_objective = on; }
     void profile_enable(int mode) override {
         profiling = mode;
         records.clear();
@@ -582,7 +587,7 @@ template <typename T> class Solver : public SolverBase {
         // and the collectives of the exchange step (names "comm_..."), every 8th (mode 2) / every 2nd (mode 3) launch of each
         if (profiling >= 2) {
             const bool wanted = flops >= (double)P * (double)N * (double)K || std::strncmp(name, "comm_", 5) == 0;
-            if (!wanted || ((prof_seen[name]++) & (profiling == 2 ? 7 : (profiling == 3 ? 1 : 15))) != 0) { launch(); return; }
+            if (!wanted || ((prof_seen[name]++) & (profiling == 2 ? 7 : (profiling == 3 ? 3 : 15))) != 0) { launch(); return; }
         }
         if (ev_used == (int)ev_pool.size()) {
             hipEvent_t a, b;

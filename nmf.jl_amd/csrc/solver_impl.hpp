@@ -556,7 +556,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     wcur = (int)((w0 + niters) & 1);
     hcur = o.update_H ? (int)((h0 + niters) & 1) : h0;
     if (ctrl_host->status == 0) {
-        if (!track) enqueue_objective(alg, o, obj_final.p, nullptr);       // common.jl:85-87
+        if (!track && final_objective) enqueue_objective(alg, o, obj_final.p, nullptr);       // common.jl:85-87
     }
     HIP_TRY(hipEventRecord(ev_end, stream));
     double objv = std::nan("");
@@ -564,7 +564,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         if (track) {
             HIP_TRY(hipMemcpyAsync(&objv, trace_dev.p + niters, sizeof(double), hipMemcpyDeviceToHost, stream));
             if (trace) HIP_TRY(hipMemcpyAsync(trace, trace_dev.p, ((size_t)o.maxiter + 1) * sizeof(double), hipMemcpyDeviceToHost, stream));
-        } else {
+        } else if (final_objective) {
             HIP_TRY(hipMemcpyAsync(&objv, obj_final.p, sizeof(double), hipMemcpyDeviceToHost, stream));
         }
     }

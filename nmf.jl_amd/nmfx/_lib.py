@@ -22,7 +22,7 @@ P2P_HANDLE_BYTES = 128
 SYMBOLS = [
     "nmfx_create", "nmfx_destroy", "nmfx_last_error", "nmfx_version", "nmfx_set_X", "nmfx_set_X_device",
     "nmfx_set_factors", "nmfx_get_factors", "nmfx_iterate", "nmfx_solve", "nmfx_alspgrad_subsolve",
-    "nmfx_comm_get_unique_id", "nmfx_comm_init", "nmfx_objective", "nmfx_profile_enable", "nmfx_profile_get",
+    "nmfx_comm_get_unique_id", "nmfx_comm_init", "nmfx_objective", "nmfx_profile_enable", "nmfx_profile_get", "nmfx_set_final_objective",
     "nmfx_device_info", "nmfx_check_nonneg", "nmfx_randinit", "nmfx_solve_replicates", "nmfx_nndsvd", "nmfx_get_iter_trace", "nmfx_rsvd_begin", "nmfx_rsvd_finish",
     "nmfx_local_group_create", "nmfx_local_group_destroy", "nmfx_comm_init_local", "nmfx_comm_set_mode", "nmfx_comm_init_sim", "nmfx_comm_init_p2p", "nmfx_comm_p2p_export", "nmfx_comm_p2p_attach", "nmfx_comm_p2p_stats", "nmfx_pdsolve", "nmfx_pdrsolve", "nmfx_spa_init",
 ]
@@ -109,6 +109,7 @@ def load():
     lib.nmfx_rsvd_finish.argtypes = [vp, vp, vp, vp, vp]
     lib.nmfx_get_iter_trace.argtypes = [vp, vp, vp, i32, C.POINTER(i32)]
     lib.nmfx_profile_enable.argtypes = [vp, i32]
+    lib.nmfx_set_final_objective.argtypes = [vp, i32]
     lib.nmfx_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32, C.POINTER(i32)]
     lib.nmfx_device_info.argtypes = [i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64)]
     for s in SYMBOLS:

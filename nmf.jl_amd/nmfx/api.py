@@ -471,6 +471,10 @@ class Context:
         """0 off, 1 every launch (slow), 2 dominant GEMMs sampled 1-in-8 (bench roofline)."""
         self._ck(self.lib.nmfx_profile_enable(self.h, int(mode)))
 
+    def set_final_objective(self, on=True):
+        """False: iterate() leaves Result.objvalue NaN (ask objective() afterwards) -- for callers that time K iterations."""
+        self._ck(self.lib.nmfx_set_final_objective(self.h, int(bool(on))))
+
     def profile_get(self):
         arr = (L.KernelStat * 64)()
         cnt = C.c_int()

@@ -83,6 +83,23 @@ int main(int argc, char **argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 6;
     const int what = argc > 2 ? atoi(argv[2]) : 0;
     g_mode = 1;
+    if (what == 5) {   // alspgrad's Float64 trial-step shapes (C5 shard) with a PLAIN store: what the tilings reach without the fused loader / epilogue
+        for (int round = 0; round < 2; ++round) {
+            printf("--- round %d\n", round);
+            // W side: Gram (512 x 512) x Z' (32768 rows): R = 512, C = 32768, contraction 512, both k-strided
+            run<double, KSTRIDED, KSTRIDED, 128, 64, 4, 1, 1>("f64 W-side 128x64", 512, 32768, 512, 1, false, reps);
+            run<double, KSTRIDED, KSTRIDED, 64, 128, 1, 4, 1>("f64 W-side 64x128", 512, 32768, 512, 1, false, reps);
+            run<double, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 1>("f64 W-side 128x128", 512, 32768, 512, 1, false, reps);
+            run<double, KSTRIDED, KSTRIDED, 64, 64, 2, 2, 1>("f64 W-side 64x64", 512, 32768, 512, 1, false, reps);
+            // H side: Z (512 x 4096) with Gram: R = 4096, C = 512, contraction 512, both k-contiguous
+            run<double, KCONTIG, KCONTIG, 64, 64, 2, 2, 1>("f64 H-side 64x64", 4096, 512, 512, 1, true, reps);
+            run<double, KCONTIG, KCONTIG, 64, 128, 1, 4, 1>("f64 H-side 64x128", 4096, 512, 512, 1, true, reps);
+            run<double, KCONTIG, KCONTIG, 128, 64, 4, 1, 1>("f64 H-side 128x64", 4096, 512, 512, 1, true, reps);
+            // the p*n*k product of the shard for comparison (contraction 4096)
+            run<double, KCONTIG, KCONTIG, 128, 128, 2, 2, 1>("f64 WtX shard", 4096, 512, 32768, 2, true, reps);
+        }
+        return 0;
+    }
     if (what == 4) {   // the 8-rank shard shapes: tile shapes / splits with buffer-load staging
         g_stagger = 1;
         for (int round = 0; round < 3; ++round) {

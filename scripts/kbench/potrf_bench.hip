@@ -38,7 +38,7 @@ template <typename T> int run(int k) {
         CK(hipMemset(dInv, 0, A.size() * sizeof(T)));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3((k + 31) / 32), dim3(64), 0, 0, dU, dInv, (int64_t)K, k, (const int *)nullptr);
-        hipLaunchKernelGGL((trtri_offdiag_kernel<T>), dim3((k + 31) / 32), dim3(256), lds_tri, 0, dU, dInv, (int64_t)K, k, (const int *)nullptr);
+        hipLaunchKernelGGL((trtri_offdiag_kernel<T>), dim3((k + 31) / 32), dim3(256), lds_tri, 0, dU, dInv, (int64_t)K, k, (k + 31) / 32 + 1, (const int *)nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); best_t = std::min(best_t, ms);
     }

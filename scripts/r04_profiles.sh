@@ -35,4 +35,11 @@ scripts/bench_multiproc_1gpu.sh 4 --steps 20 --warmup 5 --p 8192 --n 8192 --no-c
 scripts/bench_multiproc_1gpu.sh 8 --steps 20 --warmup 5 --p 8192 --n 8192 --no-cpu-baseline > "$O/bench_8proc_one_gpu.json" 2> "$O/bench_8proc_one_gpu.err"
 for tiny in 1 0; do NMFX_P2P_TINY=$tiny scripts/bench_multiproc_1gpu.sh 2 --alg alspgrad --dtype f64 --p 8192 --n 8192 --k 256 --steps 2 --warmup 1 --no-cpu-baseline --no-events > "$O/alspgrad_2proc_tiny$tiny.json" 2>/dev/null; done
 (cd scripts/kbench && hipcc --offload-arch=gfx950 -O3 -std=c++17 ipc_probe.hip -o ipc_probe 2>/dev/null; for n in 2 4 8; do timeout 100 ./ipc_probe $n 0; done) > "$O/ipc_probe.log" 2>&1
+# round 4, second half: GreedyCD's sweep (kernel bench on a stored state when present), instruction issue rates, Float64 trial-step shapes, factorisations stand-alone
+(cd scripts/kbench && hipcc --offload-arch=gfx950 -O3 valu_rate_probe.hip -o valu_rate_probe 2>/dev/null && ./valu_rate_probe) > "$O/valu_rate_probe.log" 2>&1
+if [ ! -f scripts/kbench/data/greedy_state.bin ]; then mkdir -p scripts/kbench/data; python scripts/kbench/greedy_state.py scripts/kbench/data/greedy_state.bin 12 > "$O/greedy_state.log" 2>&1; fi
+scripts/kbench/run_greedy_bench.sh > "$O/greedy_bench.log" 2>&1
+(hipcc --offload-arch=gfx950 -O3 -std=c++17 -I nmf.jl_amd/csrc scripts/kbench/gemm_bench.hip -o scripts/kbench/gemm_bench 2>/dev/null; scripts/kbench/gemm_bench 6 5) > "$O/gemm_bench_f64_trial_step_shapes.log" 2>&1
+(hipcc --offload-arch=gfx950 -O3 -std=c++17 -I nmf.jl_amd/csrc scripts/kbench/potrf_bench.hip -o /tmp/potrf_bench 2>/dev/null; /tmp/potrf_bench) > "$O/potrf_bench_standalone.log" 2>&1
+python scripts/fixed_overhead_probe.py 2>&1 | grep -v amdgpu.ids > "$O/iterate_call_overhead.log"
 ls -la "$O"

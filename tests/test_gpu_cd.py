@@ -199,7 +199,7 @@ def _solve_with_env(env, inst, X, W0, H0):
 
 @pytest.mark.parametrize("T", [np.float64, np.float32])
 @pytest.mark.parametrize("alg", ["cd", "greedycd"])
-@pytest.mark.parametrize("shape", [(90, 120, 70), (140, 100, 130), (64, 64, 64), (640, 660, 600)])
+@pytest.mark.parametrize("shape", [(90, 120, 70), (140, 100, 130), (64, 64, 64), (640, 660, 600), (300, 280, 256), (230, 210, 192), (260, 270, 250)])   # every slot count of the all-slots-live greedy form (1..4), full and ragged last slots
 def test_lds_forms_of_the_sweeps_are_bit_identical(built, T, alg, shape):
     """k > 1024 runs the sweeps with the sample row's component vectors in LDS (one wave per row) instead of registers.  Same
     expressions, same accumulation order as the 64-lanes-per-row register kernels: forced at small k (NMFX_CD_LDS=1) the two forms

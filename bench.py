@@ -68,6 +68,10 @@ def parse():
                     help="roofline.traffic of the default workload: live = two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of "
                          "this script, ~20 s each) behind the timed region; static = the value committed in profiles/pmc_traffic.json; falls back to "
                          "static when rocprofv3 is missing or a pass fails")
+    ap.add_argument("--prewarm-ms", type=float, default=80.0,
+                    help="device pre-warm BEFORE the W warm-up steps: untimed iterations worth about this many ms (the first ~50 ms after "
+                         "idle run ~2%% slower while the clocks ramp; with W = 5 warm-up steps = 10 ms the timed region would sit on the ramp). "
+                         "0 disables.  The factors are reset to the start values afterwards; the count is reported as `prewarm_steps`")
     ap.add_argument("--watchdog-s", type=float, default=600.0,
                     help="multi-GPU: a stage that takes longer than this prints a JSON line with status = comm_timeout and exits (a mismatched "
                          "collective would otherwise hang until the driver's timeout and leave no line at all)")
@@ -293,6 +297,26 @@ def main():
     else:
         ctx = make_ctx(transport, mode)
 
+    # device pre-warm (clock ramp), outside the contract's W warm-up steps and K timed steps; every rank runs the same count
+    prewarm_steps = 0
+    ctx.set_final_objective(False)        # (see below: Result.objvalue is evaluated behind the timed regions)
+    if a.prewarm_ms > 0:
+        ctx.iterate(algid, opts(1))       # first call: lazy allocations
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.iterate(algid, opts(2))
+        torch.cuda.synchronize()
+        per = max(1e-6, (time.perf_counter() - t0) / 2)
+        prewarm_steps = int(min(200, a.prewarm_ms * 1e-3 / per))
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([prewarm_steps], device=("cpu" if (dev_sim or dev_gloo) else device), dtype=torch.int64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            prewarm_steps = int(tt.item())
+        if prewarm_steps > 0:
+            ctx.iterate(algid, opts(prewarm_steps))
+        prewarm_steps += 3
+        ctx.set_factors(W0, H0)
     if a.warmup > 0:
         ctx.iterate(algid, opts(a.warmup))
     # hipEvent pairs on the solver stream around the dominant GEMM launches and the collectives: 1 launch in 8 sampled, 1 in 4 for
@@ -413,6 +437,7 @@ def main():
             # `value` / `ms_per_step` are the region with the sampled hipEvent brackets (the roofline's launch times come from it);
             # the same K steps without any bracket right behind it:
             "ms_per_step_no_events": (round(dt_plain / a.steps * 1e3, 4) if dt_plain is not None else round(ms, 4)),
+            "prewarm_steps": prewarm_steps,   # untimed, before the W warm-up steps (clock ramp; --prewarm-ms)
             "event_brackets": {0: "none", 1: "every launch", 2: "1 launch in 8 of the dominant GEMMs", 3: "1 launch in 4 of the dominant GEMMs",
                                4: "1 launch in 16 of the dominant GEMMs"}[prof_mode],
             "gflops_algorithmic": round(f_alg * a.steps / dt / 1e9, 1),

@@ -83,6 +83,19 @@ int main(int argc, char **argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 6;
     const int what = argc > 2 ? atoi(argv[2]) : 0;
     g_mode = 1;
+    if (what == 6) {   // the two big products without split-K: 512 half-size tiles instead of 256 x 2 splits (no slabs to combine)
+        g_stagger = 1;
+        for (int round = 0; round < 3; ++round) {
+            printf("--- round %d\n", round);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 2>("TN big 128x128 s2 unr2", 16384, 256, 16384, 2, true, reps);
+            run<float, KCONTIG, KCONTIG, 128, 64, 4, 1, 1>("TN big 128x64 s1", 16384, 256, 16384, 1, true, reps);
+            run<float, KCONTIG, KCONTIG, 64, 128, 1, 4, 1>("TN big 64x128 s1", 16384, 256, 16384, 1, true, reps);
+            run<float, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 1>("NT big 128x128 s2", 256, 16384, 16384, 2, false, reps);
+            run<float, KSTRIDED, KSTRIDED, 128, 64, 4, 1, 1>("NT big 128x64 s1", 256, 16384, 16384, 1, false, reps);
+            run<float, KSTRIDED, KSTRIDED, 64, 128, 1, 4, 1>("NT big 64x128 s1", 256, 16384, 16384, 1, false, reps);
+        }
+        return 0;
+    }
     if (what == 5) {   // alspgrad's Float64 trial-step shapes (C5 shard) with a PLAIN store: what the tilings reach without the fused loader / epilogue
         for (int round = 0; round < 2; ++round) {
             printf("--- round %d\n", round);

@@ -88,3 +88,33 @@ def test_result_does_not_depend_on_the_poll_interval(built, alg):
     for o in outs[1:]:
         assert o[0] == outs[0][0] and o[1] == outs[0][1] and o[2] == outs[0][2]
         assert np.array_equal(o[3], outs[0][3]) and np.array_equal(o[4], outs[0][4])
+
+
+@pytest.mark.parametrize("alg,algid", [("multmse", 0), ("multdiv", 1), ("projals", 2), ("greedycd", 5)])
+def test_final_objective_can_be_deferred(built, alg, algid):
+    """nmfx_set_final_objective(ctx, 0): nmfx_iterate leaves Result.objvalue NaN (bench.py times K iterations that way) and
+    nmfx_objective afterwards returns what the default call reports; the factors do not depend on the switch."""
+    T = np.float64
+    p, n, k = 70, 90, 6
+    X, W0, H0 = planted(p, n, k, T, seed=23, normalize=(alg != "projals"), zeroh=(alg == "projals"))
+    lam = 0.05 if alg == "projals" else 0.0
+    o = nmfx.make_opts(T, maxiter=7, tol=1e-30, lambda_w=lam, lambda_h=lam, check_every=1000)
+    out = []
+    for deferred in (False, True):
+        with nmfx.Context(T, p, n, k) as ctx:
+            ctx.set_X(X)
+            ctx.set_factors(W0.copy(order="F"), H0.copy(order="F"))
+            if deferred:
+                ctx.set_final_objective(False)
+            res, _ = ctx.iterate(algid, o)
+            objv = res.objvalue
+            if deferred:
+                assert np.isnan(objv)
+                ctx.set_final_objective(True)
+                objv = ctx.objective(algid, o)
+            W, H = np.empty((p, k), T, order="F"), np.empty((k, n), T, order="F")
+            ctx.get_factors(W, H)
+            out.append((objv, W, H, res.niters))
+    assert out[0][3] == out[1][3] == 7
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert out[0][0] == out[1][0] and np.isfinite(out[0][0])

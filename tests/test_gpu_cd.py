@@ -321,3 +321,36 @@ def test_cd_shuffle_reference_kat(built):
         nmfx.solve(nmfx.CoordinateDescent(T, alpha=1e-4, l1ratio=0.5, shuffle=True, maxiter=1000, tol=1e-9), X, W, H)
         assert np.allclose(X, W @ H, atol=1e-2, rtol=0)
 
+
+
+@pytest.mark.parametrize("shape", [(40, 50, 5), (90, 70, 64), (100, 120, 70), (130, 140, 150), (150, 160, 192), (210, 220, 250), (200, 210, 256), (140, 150, 300)])
+@pytest.mark.parametrize("lam", [0.0, 0.25])
+def test_greedy_sweep_arithmetic_is_bit_identical_to_the_oracle(built, shape, lam):
+    """The Float32 trajectories above are compared to a tolerance because the sweep's INPUTS differ in the last bit: G = W*P - Z
+    comes out of MFMA GEMMs that sum in another order than a CPU GEMM, and the sweep is discontinuous in them.  With small-integer
+    X, W0, H0 every product and sum of P = H*H', Z = X*H', G = W*P - Z is exact in Float32 whatever the order, so both sides
+    sweep the SAME numbers -- and then the W side of the first iteration (update_H = false: nothing else runs) must agree BIT FOR
+    BIT with the C restatement of src/greedycd.jl:91-163: the same divisions, the same separately rounded products and sums, the
+    same first-index arg-max, the same number of greedy steps.  Shapes: every slot count of the register forms (k <= 64, 128,
+    192, 256, full and ragged last slots) and the general form beyond."""
+    T = np.float32
+    p, n, k = shape
+    rng = np.random.default_rng(100 + k)
+    X = np.asfortranarray(rng.integers(0, 4, size=(p, n)).astype(T))
+    W0 = np.asfortranarray(rng.integers(0, 3, size=(p, k)).astype(T))
+    H0 = np.asfortranarray(rng.integers(0, 3, size=(k, n)).astype(T))
+    assert 2 * 2 * k * 2 * 2 * n < 2 ** 24        # |W*P| <= k * 2 * (n * 4): exact in Float32
+    o = nmfx.make_opts(T, maxiter=1, tol=1e-30, update_H=False, lambda_w=lam, lambda_h=lam, check_every=1000)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        ctx.set_factors(Wg, Hg)
+        res, _ = ctx.iterate(5, o)
+        ctx.get_factors(Wg, Hg)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = co.solve("greedycd", X, Wc, Hc, orc.Opts(maxiter=1, tol=1e-30, update_H=False, lambda_w=lam, lambda_h=lam))
+    assert res.niters == ro.niters == 1
+    assert np.array_equal(Hg, H0) and np.array_equal(Hc, H0)
+    assert res.inner_iters == ro.counters["inner"] > 0
+    assert np.array_equal(Wg.view(np.uint32), Wc.view(np.uint32)), float(np.max(np.abs(Wg - Wc)))
+    assert not np.array_equal(Wg, W0)

@@ -202,3 +202,29 @@ def test_multdiv_fused_passes_are_bit_identical(built, T, shape, update_H, monke
     assert np.array_equal(ra.trace, rb.trace)
     assert np.array_equal(runs["1"][1], runs["0"][1]) and np.array_equal(runs["1"][2], runs["0"][2])
     assert np.array_equal(ra.info["relchange"][1:], rb.info["relchange"][1:])
+
+
+@pytest.mark.parametrize("shape", [(40, 50, 5), (100, 90, 64), (130, 170, 100), (200, 260, 256)])
+def test_first_h_update_is_bit_identical_on_exact_inputs(built, shape):
+    """MultUpdate-MSE with small-integer X, W0, H0: W'X, W'W and (W'W)H -- the device's association -- and the reference's W'(WH)
+    are all exact in Float32, so the element-wise rule H .*= W'X ./ (W'WH .+ delta) (src/multupd.jl:98-106) receives the same
+    numbers on both sides and H after the first iteration must agree BIT FOR BIT with the oracle (one rounded sum, one division,
+    one product per element, in that order).  W is updated from that H, whose products are no longer exact: tolerance there."""
+    T = np.float32
+    p, n, k = shape
+    rng = np.random.default_rng(7 + k)
+    X = np.asfortranarray(rng.integers(0, 4, size=(p, n)).astype(T))
+    W0 = np.asfortranarray(rng.integers(0, 3, size=(p, k)).astype(T))
+    H0 = np.asfortranarray(rng.integers(0, 3, size=(k, n)).astype(T))
+    assert 2 * 2 * k * p * 2 < 2 ** 24       # |(W'W)H| <= k * (p * 4) * 2
+    o = nmfx.make_opts(T, maxiter=1, tol=1e-30, check_every=1000)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        ctx.set_factors(Wg, Hg)
+        ctx.iterate(0, o)
+        ctx.get_factors(Wg, Hg)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    orc.solve("multmse", X, Wc, Hc, orc.Opts(maxiter=1, tol=1e-30))
+    assert np.array_equal(Hg.view(np.uint32), Hc.view(np.uint32)), float(np.max(np.abs(Hg - Hc)))
+    assert np.max(np.abs(Wg - Wc)) <= 1e-5 * np.max(np.abs(Wc))

@@ -325,7 +325,8 @@ def test_cd_shuffle_reference_kat(built):
 
 @pytest.mark.parametrize("shape", [(40, 50, 5), (90, 70, 64), (100, 120, 70), (130, 140, 150), (150, 160, 192), (210, 220, 250), (200, 210, 256), (140, 150, 300)])
 @pytest.mark.parametrize("lam", [0.0, 0.25])
-def test_greedy_sweep_arithmetic_is_bit_identical_to_the_oracle(built, shape, lam):
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_greedy_sweep_arithmetic_is_bit_identical_to_the_oracle(built, T, shape, lam):
     """The Float32 trajectories above are compared to a tolerance because the sweep's INPUTS differ in the last bit: G = W*P - Z
     comes out of MFMA GEMMs that sum in another order than a CPU GEMM, and the sweep is discontinuous in them.  With small-integer
     X, W0, H0 every product and sum of P = H*H', Z = X*H', G = W*P - Z is exact in Float32 whatever the order, so both sides
@@ -333,7 +334,6 @@ def test_greedy_sweep_arithmetic_is_bit_identical_to_the_oracle(built, shape, la
     BIT with the C restatement of src/greedycd.jl:91-163: the same divisions, the same separately rounded products and sums, the
     same first-index arg-max, the same number of greedy steps.  Shapes: every slot count of the register forms (k <= 64, 128,
     192, 256, full and ragged last slots) and the general form beyond."""
-    T = np.float32
     p, n, k = shape
     rng = np.random.default_rng(100 + k)
     X = np.asfortranarray(rng.integers(0, 4, size=(p, n)).astype(T))
@@ -352,5 +352,37 @@ def test_greedy_sweep_arithmetic_is_bit_identical_to_the_oracle(built, shape, la
     assert res.niters == ro.niters == 1
     assert np.array_equal(Hg, H0) and np.array_equal(Hc, H0)
     assert res.inner_iters == ro.counters["inner"] > 0
-    assert np.array_equal(Wg.view(np.uint32), Wc.view(np.uint32)), float(np.max(np.abs(Wg - Wc)))
+    U = np.uint32 if T == np.float32 else np.uint64
+    assert np.array_equal(Wg.view(U), Wc.view(U)), float(np.max(np.abs(Wg - Wc)))
     assert not np.array_equal(Wg, W0)
+
+
+@pytest.mark.parametrize("shape", [(40, 50, 5), (300, 90, 64), (500, 170, 100), (700, 300, 256), (400, 700, 600)])
+@pytest.mark.parametrize("reg", [(0.0, 0.0), (0.25, 0.5)])
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_cd_sweep_arithmetic_is_bit_identical_when_the_gram_is_diagonal(built, T, shape, reg):
+    """CoordinateDescent's W side (src/coorddesc.jl:107-158) with an H0 whose rows are indicators of distinct columns: P = HH' = I
+    and Z = XH' is a column selection of X, both exact, and every dot product of the sweep has a single non-zero term -- the
+    summation order (butterfly / MFMA block products on the device, left to right in the reference) cannot matter, so the
+    element-wise rule w <- max(0, w - (g + l1) / (P_tt + l2)) must give the oracle's W BIT FOR BIT (update_H = false: nothing
+    else runs).  Covers the 16-lane, 64-lane, blocked and LDS-resident forms by k."""
+    p, n, k = shape
+    rng = np.random.default_rng(17 + k)
+    X = np.asfortranarray(rng.integers(0, 9, size=(p, n)).astype(T))
+    W0 = np.asfortranarray((rng.integers(0, 40, size=(p, k)) / 8.0).astype(T))      # dyadic start values
+    cols = rng.permutation(n)[:k]
+    H0 = np.zeros((k, n), dtype=T, order="F")
+    H0[np.arange(k), cols] = 1
+    l1, l2 = reg
+    o = nmfx.make_opts(T, maxiter=1, tol=1e-30, update_H=False, l1_w=l1, l2_w=l2, l1_h=l1, l2_h=l2, check_every=1000)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        ctx.set_factors(Wg, Hg)
+        ctx.iterate(4, o)
+        ctx.get_factors(Wg, Hg)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    co.solve("cd", X, Wc, Hc, orc.Opts(maxiter=1, tol=1e-30, update_H=False, l1_w=l1, l2_w=l2, l1_h=l1, l2_h=l2))
+    U = np.uint32 if T == np.float32 else np.uint64
+    assert np.array_equal(Wg.view(U), Wc.view(U)), float(np.max(np.abs(Wg - Wc)))
+    assert not np.array_equal(Wg, W0) and np.array_equal(Hg, H0)

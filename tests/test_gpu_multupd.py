@@ -205,12 +205,12 @@ def test_multdiv_fused_passes_are_bit_identical(built, T, shape, update_H, monke
 
 
 @pytest.mark.parametrize("shape", [(40, 50, 5), (100, 90, 64), (130, 170, 100), (200, 260, 256)])
-def test_first_h_update_is_bit_identical_on_exact_inputs(built, shape):
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_first_h_update_is_bit_identical_on_exact_inputs(built, T, shape):
     """MultUpdate-MSE with small-integer X, W0, H0: W'X, W'W and (W'W)H -- the device's association -- and the reference's W'(WH)
     are all exact in Float32, so the element-wise rule H .*= W'X ./ (W'WH .+ delta) (src/multupd.jl:98-106) receives the same
     numbers on both sides and H after the first iteration must agree BIT FOR BIT with the oracle (one rounded sum, one division,
     one product per element, in that order).  W is updated from that H, whose products are no longer exact: tolerance there."""
-    T = np.float32
     p, n, k = shape
     rng = np.random.default_rng(7 + k)
     X = np.asfortranarray(rng.integers(0, 4, size=(p, n)).astype(T))
@@ -226,5 +226,67 @@ def test_first_h_update_is_bit_identical_on_exact_inputs(built, shape):
         ctx.get_factors(Wg, Hg)
     Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
     orc.solve("multmse", X, Wc, Hc, orc.Opts(maxiter=1, tol=1e-30))
-    assert np.array_equal(Hg.view(np.uint32), Hc.view(np.uint32)), float(np.max(np.abs(Hg - Hc)))
-    assert np.max(np.abs(Wg - Wc)) <= 1e-5 * np.max(np.abs(Wc))
+    U = np.uint32 if T == np.float32 else np.uint64
+    assert np.array_equal(Hg.view(U), Hc.view(U)), float(np.max(np.abs(Hg - Hc)))
+    assert np.max(np.abs(Wg - Wc)) <= (1e-5 if T == np.float32 else 1e-13) * np.max(np.abs(Wc))
+
+
+@pytest.mark.parametrize("shape", [(50, 40, 5), (90, 100, 64), (170, 130, 100), (260, 200, 256)])
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_first_w_update_is_bit_identical_on_exact_inputs(built, T, shape):
+    """The same for the W side (update_H = false, so W .*= XH' ./ (W(HH') .+ delta), src/multupd.jl:108-115, is the first thing
+    that runs), and for the objective of the start point (0.5 * sqL2dist of integers: exact in Float64, src/multupd.jl:81)."""
+    p, n, k = shape
+    rng = np.random.default_rng(9 + k)
+    X = np.asfortranarray(rng.integers(0, 4, size=(p, n)).astype(T))
+    W0 = np.asfortranarray(rng.integers(0, 3, size=(p, k)).astype(T))
+    H0 = np.asfortranarray(rng.integers(0, 3, size=(k, n)).astype(T))
+    assert 2 * 2 * k * n * 2 < 2 ** 24
+    o = nmfx.make_opts(T, maxiter=1, tol=1e-30, update_H=False, check_every=1000)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        ctx.set_factors(Wg, Hg)
+        obj0 = ctx.objective(0, o)
+        ctx.iterate(0, o)
+        ctx.get_factors(Wg, Hg)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    orc.solve("multmse", X, Wc, Hc, orc.Opts(maxiter=1, tol=1e-30, update_H=False))
+    U = np.uint32 if T == np.float32 else np.uint64
+    assert np.array_equal(Wg.view(U), Wc.view(U)), float(np.max(np.abs(Wg - Wc)))
+    assert np.array_equal(Hg, H0)
+    R = X.astype(np.float64) - W0.astype(np.float64) @ H0.astype(np.float64)
+    assert obj0 == float(T(0.5 * np.sum(R * R)))
+
+
+@pytest.mark.parametrize("shape", [(40, 50, 5), (200, 90, 64), (300, 170, 100), (800, 260, 256), (8192, 8192, 128)])
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_multdiv_first_h_update_is_bit_identical_on_selection_factors(built, T, shape):
+    """MultUpdate-div (src/multupd.jl:172-179): Q = X ./ (WH .+ delta), H .*= (W'Q) ./ (sum(W, dims=1)' .+ lambda).  With a W0
+    whose column j is the indicator of ONE row r_j, WH is exact (row r_j of it is row j of H0), so Q is the same rounded quotient
+    on both sides, W'Q selects row r_j of Q (sums with a single non-zero term: exact in any order) and the column sums are 1:
+    H after the first iteration must agree BIT FOR BIT with the oracle -- a test of the ratio epilogue's division (the IEEE
+    sequence written out in pieces inside the persistent W*H kernel at the last shape, the block-per-tile kernel before) and of
+    the scaling pass, on non-trivial quotients."""
+    p, n, k = shape
+    if T == np.float64 and p > 4096:
+        pytest.skip("the persistent W*H kernel is Float32 only")
+    rng = np.random.default_rng(13 + k)
+    X = np.asfortranarray(rng.integers(0, 50, size=(p, n)).astype(T))
+    rows = rng.permutation(p)[:k]
+    W0 = np.zeros((p, k), dtype=T, order="F")
+    W0[rows, np.arange(k)] = 1
+    H0 = np.asfortranarray(rng.integers(0, 7, size=(k, n)).astype(T))
+    lam = 0.25
+    o = nmfx.make_opts(T, maxiter=1, tol=1e-30, lambda_w=lam, lambda_h=lam, check_every=1000)
+    Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        ctx.set_factors(Wg, Hg)
+        ctx.iterate(1, o)
+        ctx.get_factors(Wg, Hg)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    orc.solve("multdiv", X, Wc, Hc, orc.Opts(maxiter=1, tol=1e-30, lambda_w=lam, lambda_h=lam))
+    U = np.uint32 if T == np.float32 else np.uint64
+    assert np.array_equal(Hg.view(U), Hc.view(U)), float(np.max(np.abs(Hg - Hc)))
+    assert not np.array_equal(Hg, H0)

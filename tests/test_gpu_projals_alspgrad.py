@@ -273,3 +273,68 @@ def test_alspgrad_f32_counters_near_the_oracle(built):
     ci, cb = ro.counters["inner"], ro.counters["backtracks"]
     assert abs(r.info["inner_iters"] - ci) <= max(2, 0.02 * ci) and abs(r.info["backtracks"] - cb) <= max(4, 0.02 * cb)
     assert rel_trace_err(r.trace, ro.trace) < 2e-3
+
+
+@pytest.mark.parametrize("k", [5, 70, 130, 256])
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_projals_h_solve_is_exact_when_the_arithmetic_is(built, T, k):
+    """ProjectedALS with a W0 whose columns are 0/1 indicators of disjoint row triples and lambda_h = 1: W'W + lambda I = 4 I, so
+    potrf! gives U = 2 I, the solve is a multiplication by 1/4, and H after the first iteration is max(0, W'X / 4) EXACTLY
+    (dyadic rationals) -- on the oracle (LAPACK potrf/potrs) and on the device (blocked potrf, explicit triangular inverse, two
+    MFMA products with the clamp in the epilogue): the product form of pdsolve! (src/utils.jl:63-70) loses nothing where the
+    substitution form loses nothing.  Also with NMFX_POTRS=1 (the substitution kernels)."""
+    import os
+    p, n = 3 * k + 7, 2 * k + 11
+    rng = np.random.default_rng(5 + k)
+    X = np.asfortranarray(rng.integers(0, 4, size=(p, n)).astype(T))
+    W0 = np.zeros((p, k), dtype=T, order="F")
+    for j in range(k):
+        W0[3 * j:3 * j + 3, j] = 1
+    H0 = np.asfortranarray(rng.integers(0, 3, size=(k, n)).astype(T))
+    expect = np.maximum(W0.T.astype(np.float64) @ X.astype(np.float64) / 4.0, 0.0).astype(T)
+    o = nmfx.make_opts(T, maxiter=1, tol=1e-30, lambda_w=1.0, lambda_h=1.0, check_every=1000)
+    for potrs in ("0", "1"):
+        os.environ["NMFX_POTRS"] = potrs
+        try:
+            Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+            with nmfx.Context(T, p, n, k) as ctx:
+                ctx.set_X(X)
+                ctx.set_factors(Wg, Hg)
+                ctx.iterate(2, o)
+                ctx.get_factors(Wg, Hg)
+        finally:
+            del os.environ["NMFX_POTRS"]
+        assert np.array_equal(Hg, expect), (potrs, float(np.max(np.abs(Hg - expect))))
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=1, tol=1e-30, lambda_w=1.0, lambda_h=1.0))
+    assert np.array_equal(Hc, expect)
+    assert np.max(np.abs(Wg - Wc)) <= (2e-4 if T == np.float32 else 1e-11) * max(1.0, np.max(np.abs(Wc)))
+
+
+@pytest.mark.parametrize("side", ["h", "w"])
+@pytest.mark.parametrize("k", [5, 64, 100, 256])
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_alspgrad_first_projected_gradient_step_is_bit_identical_on_exact_inputs(built, T, k, side):
+    """alspgrad_updateh! / alspgrad_updatew! with maxiter = 1 on small-integer X, W, H: the gradient G = W'W H - W'X (resp.
+    W HH' - XH') is exact, so the projected step max(Z - alpha G, 0) (src/alspgrad.jl:142-147, 298-303) is computed from the same
+    numbers on both sides, element by element, as a rounded product and a rounded difference; the back-tracking decisions
+    (sufficient decrease on sums whose last bits do differ) pick the same alpha, and the factor after the one inner iteration is
+    BIT-IDENTICAL to the oracle's."""
+    p, n = 90 + k // 2, 70 + k
+    rng = np.random.default_rng(31 + k)
+    X = np.asfortranarray(rng.integers(0, 4, size=(p, n)).astype(T))
+    W = np.asfortranarray(rng.integers(0, 3, size=(p, k)).astype(T))
+    H = np.asfortranarray(rng.integers(0, 3, size=(k, n)).astype(T))
+    Wg, Hg, Wc, Hc = W.copy(order="F"), H.copy(order="F"), W.copy(order="F"), H.copy(order="F")
+    if side == "h":
+        ng = nmfx.alspgrad_updateh(X, Wg, Hg, maxiter=1, tolg=1e-30)
+        nc = orc.alspgrad_updateh(X, Wc, Hc, maxiter=1, tolg=1e-30)
+        got, ref, start = Hg, Hc, H
+    else:
+        ng = nmfx.alspgrad_updatew(X, Wg, Hg, maxiter=1, tolg=1e-30)
+        nc = orc.alspgrad_updatew(X, Wc, Hc, maxiter=1, tolg=1e-30)
+        got, ref, start = Wg, Wc, W
+    assert ng == nc
+    U = np.uint32 if T == np.float32 else np.uint64
+    assert np.array_equal(got.view(U), ref.view(U)), float(np.max(np.abs(got - ref)))
+    assert not np.array_equal(got, start)

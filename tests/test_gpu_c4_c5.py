@@ -202,3 +202,32 @@ def test_c5_aspect_downscaled_counters(built, shape):
     assert r.info["backtracks"] == ro.counters["backtracks"]
     assert rel_trace_err(r.trace, ro.trace) < 1e-9
     assert np.max(np.abs(Wg - Wc)) <= 1e-7 * np.max(np.abs(Wc))
+
+
+def test_c4_projals_cold_start_h_solve_is_exact_at_full_size(built):
+    """C4 at full size from a COLD start on which the answer is known exactly (no warm start, no sampling): W0 = indicators of
+    disjoint row triples, lambda = 1, integer X generated on the device.  W'W + lambda I = 4 I, so the first H-side solve is
+    H = max(0, W'X / 4) in exact arithmetic AND in Float32 (sums of three small integers, divisions by powers of two): all
+    256 x 131072 entries of the device's H -- Gram launch, split-K product of 16384 x 131072 x 256 with its slab combine, blocked
+    potrf, triangular inverse, two solve products with the clamp -- must equal the closed form bit for bit."""
+    T = np.float32
+    p, n, k = 16384, 131072, 256
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    Xt = torch.randint(0, 4, (n, p), generator=g, device=dev, dtype=torch.int32).to(torch.float32)   # n x p row-major == X column-major
+    W0 = np.zeros((p, k), dtype=T, order="F")
+    for j in range(k):
+        W0[3 * j:3 * j + 3, j] = 1
+    H0 = np.zeros((k, n), dtype=T, order="F")
+    expect_t = (Xt[:, :3 * k].reshape(n, k, 3).sum(dim=2) / 4.0).cpu().numpy()                        # H' (n x k)
+    o = nmfx.make_opts(T, maxiter=1, tol=1e-30, lambda_w=1.0, lambda_h=1.0, check_every=1000)
+    H = np.empty((k, n), dtype=T, order="F")
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X_device(Xt.data_ptr(), p)
+        ctx.set_factors(W0, H0)
+        res, _ = ctx.iterate(2, o)
+        ctx.get_factors(None, H)
+    assert res.niters == 1 and np.isfinite(res.objvalue)
+    assert np.array_equal(H.T, expect_t)
+    assert float(H.max()) > 0

@@ -216,3 +216,46 @@ def test_c2_coordinate_descent_pieces(built, alg):
         # exact coordinate minimisation never increases the objective
         res, tr2 = ctx.solve(algid, nmfx.make_opts(T, maxiter=4, tol=1e-30, track_objective=True), W1, H1)
         assert np.all(np.diff(tr2[: res.niters + 1]) <= 1e-12 * tr2[0])
+
+
+def test_c3_updates_are_bit_identical_on_exact_inputs(built):
+    """C3 at full size (16384 x 16384, k = 256, f32) on inputs whose GEMMs are exact: X in {0..3}, W0 and H0 in {0, 1}.  Then
+    W'X <= 49152, W'W <= 16384 and (W'W)H <= 2^22 are exact in Float32 in any summation order (split-K slabs, Gram tail
+    pieces, MFMA accumulation), and H after the first iteration must equal  H0 .* (W'X) ./ ((W'W)H0 .+ delta)  evaluated
+    element-wise in Float32 from exact integer operands, BIT FOR BIT, for all 256 x 16384 entries; likewise W with
+    update_H = false.  (src/multupd.jl:98-115; the operands are formed in Float64 by torch -- plumbing -- and checked to be
+    integers.)"""
+    T = np.float32
+    p = n = 16384
+    k = 256
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    Xt = torch.randint(0, 4, (n, p), generator=g, device=dev, dtype=torch.int32).to(torch.float32)     # n x p row-major == X column-major
+    rng = np.random.default_rng(11)
+    W0 = np.asfortranarray(rng.integers(0, 2, size=(p, k)).astype(T))
+    H0 = np.asfortranarray(rng.integers(0, 2, size=(k, n)).astype(T))
+    X64 = Xt.t().to(torch.float64)                                                                      # p x n view, fp64 copy (2 GiB)
+    W64 = torch.from_numpy(np.ascontiguousarray(W0)).to(dev, torch.float64)
+    H64 = torch.from_numpy(np.ascontiguousarray(H0)).to(dev, torch.float64)
+    delta = T(np.sqrt(np.finfo(T).eps))
+    def rule(z0, num64, den64):
+        num, den = num64.cpu().numpy(), den64.cpu().numpy()
+        assert np.array_equal(num, np.rint(num)) and np.array_equal(den, np.rint(den)) and den.max() < 2 ** 24 and num.max() < 2 ** 24
+        return (z0 * (num.astype(T) / (den.astype(T) + delta))).astype(T)                              # one rounding per operation, in T
+    expect_H = rule(H0, W64.t() @ X64, (W64.t() @ W64) @ H64)
+    expect_W = rule(W0, X64 @ H64.t(), W64 @ (H64 @ H64.t()))
+    del X64
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X_device(Xt.data_ptr(), p)
+        for update_H, expect in ((True, expect_H), (False, expect_W)):
+            ctx.set_factors(W0, H0)
+            o = nmfx.make_opts(T, maxiter=1, tol=1e-30, update_H=update_H, check_every=1000)
+            res, _ = ctx.iterate(0, o)
+            W, H = np.empty((p, k), T, order="F"), np.empty((k, n), T, order="F")
+            ctx.get_factors(W, H)
+            assert res.niters == 1
+            got = H if update_H else W
+            assert np.array_equal(got.view(np.uint32), np.asfortranarray(expect).view(np.uint32)), float(np.max(np.abs(got - expect)))
+            if not update_H:
+                assert np.array_equal(H, H0)

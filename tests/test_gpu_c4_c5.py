@@ -231,3 +231,40 @@ def test_c4_projals_cold_start_h_solve_is_exact_at_full_size(built):
     assert res.niters == 1 and np.isfinite(res.objvalue)
     assert np.array_equal(H.T, expect_t)
     assert float(H.max()) > 0
+
+
+def test_c5_alspgrad_first_projected_gradient_step_is_bit_identical_at_full_size(built):
+    """C5 at full size (32768 x 32768, k = 512, f64) on small-integer X, W, H: W'W, W'X and the gradient G = W'W H - W'X are exact
+    in Float64, so the first inner iteration of alspgrad_updateh! (resp. updatew!) -- trial points max(Z - alpha G, 0), the
+    back-tracking on sums whose last bits may differ, the accepted step -- must leave the factor BIT-IDENTICAL to the oracle's
+    `_pgrad_subsolve` run on the exact Gram and B (src/alspgrad.jl:86-191, 242-347)."""
+    T = np.float64
+    p = n = 32768
+    k = 512
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    Xt = torch.randint(0, 4, (n, p), generator=g, device=dev, dtype=torch.int32).to(torch.float64)     # n x p row-major == X column-major
+    rng = np.random.default_rng(5)
+    W0 = np.asfortranarray(rng.integers(0, 3, size=(p, k)).astype(T))
+    H0 = np.asfortranarray(rng.integers(0, 3, size=(k, n)).astype(T))
+    tolg = 1e-30
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X_device(Xt.data_ptr(), p)
+        Wd, Hd = torch.from_numpy(W0).to(dev), torch.from_numpy(H0).to(dev)
+        WtW = (Wd.t() @ Wd).cpu().numpy()
+        WtX = np.asfortranarray((Xt @ Wd).t().cpu().numpy())        # k x n
+        HHt = (Hd @ Hd.t()).cpu().numpy()
+        XHt = np.asfortranarray((Hd @ Xt).t().cpu().numpy())        # p x k
+        for a in (WtW, WtX, HHt, XHt):
+            assert np.array_equal(a, np.rint(a)) and np.abs(a).max() < 2 ** 50
+        for side, Gram, B, Z0 in ((0, WtW, WtX, H0), (1, HHt, XHt, W0)):
+            Zc = Z0.copy(order="F")
+            cnt = {"inner": 0, "backtracks": 0}
+            t_or = orc._pgrad_subsolve(Zc, Gram, B, side == 0, 1, 20, T(tolg), 0.2, 0.01, T, cnt)
+            Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+            r = ctx.subsolve(side, nmfx.make_opts(T, maxsubiter=1, tolg=tolg), Wg, Hg)
+            got = Hg if side == 0 else Wg
+            assert r.niters == t_or == 1 and r.backtracks == cnt["backtracks"], (r.niters, t_or, r.backtracks, cnt)
+            assert np.array_equal(got.view(np.uint64), Zc.view(np.uint64)), float(np.max(np.abs(got - Zc)))
+            assert not np.array_equal(got, Z0)

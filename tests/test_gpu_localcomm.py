@@ -321,3 +321,41 @@ def test_sharded_cd_shuffle(built):
     ro = orc.solve("cd", X, Wc, Hc, orc.Opts(maxiter=5, tol=1e-30, track_objective=True, perm_source=lambda c: philox_ref.cd_permutation(k, 31, c)))
     assert rel_trace_err(rr[0][1], ro.trace) < 1e-9
     assert np.max(np.abs(Ws - Wc)) <= 1e-7 * np.max(np.abs(Wc)) and np.max(np.abs(Hs - Hc)) <= 1e-7 * np.max(np.abs(Hc))
+
+
+@pytest.mark.parametrize("case", ["multmse_h", "multmse_w", "greedycd_w", "cd_w"])
+@pytest.mark.parametrize("G", [2, 4])
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_sharded_first_update_is_bit_identical_to_the_oracle_on_exact_inputs(built, case, G, T):
+    """The sharded formulation against the ORACLE, bit for bit, on inputs whose products and sums are exact in T (small integers;
+    for CoordinateDescent an H0 of indicator rows, so that the Gram is the identity): per-rank partial products, the
+    reduce-scatter's sums across ranks, the row-sharded update and the all-gather change the ORDER of exact sums only, so the
+    first update must reproduce the oracle's factor exactly -- the multi-rank step has no arithmetic of its own."""
+    import c_oracle as co
+    p, n, k = 300, 530, 70                                          # ragged column shards; p padded to 128*G rows
+    rng = np.random.default_rng(3 + k)
+    X = np.asfortranarray(rng.integers(0, 4, size=(p, n)).astype(T))
+    W0 = np.asfortranarray(rng.integers(0, 3, size=(p, k)).astype(T))
+    H0 = np.asfortranarray(rng.integers(0, 3, size=(k, n)).astype(T))
+    alg, side = case.split("_")
+    kw = dict(maxiter=1, tol=1e-30, update_H=(side == "h"))
+    if alg == "cd":
+        H0 = np.zeros((k, n), dtype=T, order="F")
+        H0[np.arange(k), rng.permutation(n)[:k]] = 1
+        W0 = np.asfortranarray((rng.integers(0, 40, size=(p, k)) / 8.0).astype(T))
+        kw.update(l1_w=0.25, l2_w=0.5, l1_h=0.25, l2_h=0.5)
+    Ws, Hs, rr, Wall = run_sharded(T, X, W0, H0, alg, kw, G)
+    for Wr in Wall[1:]:
+        assert np.array_equal(Wr, Wall[0])
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    oo = orc.Opts(**kw)
+    ro = (co.solve if alg in ("cd", "greedycd") else orc.solve)(alg, X, Wc, Hc, oo)
+    U = np.uint32 if T == np.float32 else np.uint64
+    if side == "h":
+        assert np.array_equal(Hs.view(U), Hc.view(U)), float(np.max(np.abs(Hs - Hc)))
+        assert not np.array_equal(Hs, H0)
+    else:
+        assert np.array_equal(Ws.view(U), Wc.view(U)), float(np.max(np.abs(Ws - Wc)))
+        assert np.array_equal(Hs, H0) and not np.array_equal(Ws, W0)
+    if alg == "greedycd":
+        assert sum(res.inner_iters for res, _ in rr) == ro.counters["inner"]

@@ -457,7 +457,7 @@ __device__ __forceinline__ float f32_sub(float a, float b) { float r; asm("v_sub
 __device__ __forceinline__ float greedy_take(const float (&s)[1], float (&w)[1], int, int ql) {
     float sq; unsigned long long sv;
     asm volatile("s_mov_b64 %[sv], exec\n\ts_lshl_b64 exec, 1, %[ql]\n\t" NMFX_TAKE_CASE("%[s0]", "%[w0]") "s_mov_b64 exec, %[sv]"
-                 : [sq] "=&s"(sq), [sv] "=&s"(sv), [w0] "+v"(w[0]) : [s0] "v"(s[0]), [ql] "s"(ql));
+                 : [sq] "=&s"(sq), [sv] "=&s"(sv), [w0] "+v"(w[0]) : [s0] "v"(s[0]), [ql] "s"(ql) : "scc");
     return sq;
 }
 __device__ __forceinline__ float greedy_take(const float (&s)[2], float (&w)[2], int qm, int ql) {

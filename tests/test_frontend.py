@@ -296,3 +296,28 @@ def test_nnmf_reference_defaults(built):
     Xneg[3, 4] = -0.5
     with pytest.raises(nmfx.ArgumentError, match="non-negative"):
         nmfx.nnmf(Xneg, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+@pytest.mark.parametrize("variant", ["std", "a"])
+@pytest.mark.parametrize("shape", [(40, 60, 5), (300, 129, 20), (130, 700, 64)])
+def test_nndsvd_is_bit_identical_on_dyadic_singular_vectors(built, T, variant, shape):
+    """_nndsvd! (src/initialization.jl:26-72) from "singular vectors" with dyadic entries: the sums of squares of posnegnorm
+    (:103-115) are exact in T in any order (the device sums them in Float64, the reference left to right in T), and what follows
+    -- two square roots, the products s_j * mp, the quotients ss / xp, one product per element, the mean of an integer X for
+    variant :a -- is correctly rounded element-wise arithmetic: W and H must equal the oracle's BIT FOR BIT."""
+    import nmf_oracle as orc
+    import nmfx
+    p, n, k = shape
+    rng = np.random.default_rng(p + k)
+    X = np.asfortranarray(rng.integers(0, 8, size=(p, n)).astype(T))
+    U = np.asfortranarray((rng.integers(-6, 7, size=(p, k)) / 8.0).astype(T))
+    V = np.asfortranarray((rng.integers(-6, 7, size=(n, k)) / 8.0).astype(T))
+    s = np.sort(rng.integers(1, 40, size=k)).astype(T)[::-1].copy()
+    for zeroh in (False, True):
+        W, H = nmfx.nndsvd(X, k, zeroh=zeroh, variant=variant, initdata=(U, s, V))
+        Wo, Ho = orc.nndsvd(X, k, zeroh=zeroh, variant=variant, initdata=(U, s, V))
+        Ui = np.uint32 if T == np.float32 else np.uint64
+        assert np.array_equal(W.view(Ui), Wo.view(Ui)), float(np.max(np.abs(W - Wo)))
+        assert np.array_equal(H.view(Ui), Ho.view(Ui)), float(np.max(np.abs(H - Ho)))

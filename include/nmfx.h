@@ -110,7 +110,9 @@ typedef struct {
     int32_t converged;        /* Result.converged */
     int32_t status;           /* nmfx_status of the solve (NOT_POSDEF / ALPHA_NONFINITE raised on device) */
     double objvalue;          /* Result.objvalue, already rounded to T (src/common.jl:33) */
-    double seconds_loop;      /* device time of the iteration loop (hipEvent), excludes H2D/D2H */
+    double seconds_loop;      /* device time of the iteration loop (hipEvent), excludes H2D/D2H; iterations are enqueued a poll
+                                 window ahead of the host, so after a stop it includes up to one window of no-op launches
+                                 (with a communicator also their collectives; window <= 8 there) */
     int64_t inner_iters;      /* alspgrad: executed sub-solver iterations (H and W sides); greedycd: executed greedy steps */
     int64_t backtracks;       /* alspgrad: executed back-tracking steps */
     double final_tolg;        /* alspgrad: tolg after decay */

@@ -1,5 +1,9 @@
+"""Development aid (GPU box): wall time and device-loop time of nmfx_iterate for 1 ... 100 iterations of the headline workload, and the
+first call after 2 s of idle -- the per-call overhead and the clock ramp behind bench.py's `--prewarm-ms` and the deferred final
+objective (profiles/r04_iterate_call_overhead.log)."""
 import os, sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/nmf.jl_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "nmf.jl_amd"))
 import numpy as np, torch, nmfx, bench
 p = n = 16384; k = 256
 dev = torch.device("cuda:0")

@@ -144,9 +144,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "NMFX_BENCH_DEVICE" in os.environ:      # development aid: several ranks on one device (plumbing check on a 1-GPU box)
         local_rank = int(os.environ["NMFX_BENCH_DEVICE"])
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a.gpus))     # plain `python bench.py --gpus N`: become N ranks (one process per GPU)
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or plain `python bench.py --gpus N`)")
     import nmfx
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -394,6 +395,7 @@ def main():
             # W side (2 p k^2 each) is not reported by the device counters, so both are priced at the mean of the two
             per_small = float(k) * k * (p + n)
             f_alg = 4.0 * p * n * k + 2.0 * k * k * (p + n) + per_small * (res.inner_iters + res.backtracks) / a.steps
+        sim_div = float(shards) if shards != world else 1.0
         # dominant kernel = the GEMM family with the largest summed time
         gemms = [s for s in prof if s["flops"] > 0]
         dom = max(gemms, key=lambda s: s["ms_total"]) if gemms else None
@@ -440,9 +442,10 @@ def main():
             "prewarm_steps": prewarm_steps,   # untimed, before the W warm-up steps (clock ramp; --prewarm-ms)
             "event_brackets": {0: "none", 1: "every launch", 2: "1 launch in 8 of the dominant GEMMs", 3: "1 launch in 4 of the dominant GEMMs",
                                4: "1 launch in 16 of the dominant GEMMs"}[prof_mode],
-            "gflops_algorithmic": round(f_alg * a.steps / dt / 1e9, 1),
-            "frac_of_mfma_peak": round(f_alg * a.steps / dt / 1e12 / (((2500.0 / 3.0) if a.precision == "bf16x3" else
-                                                                        (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6)) * world), 4),
+            # (--sim-ranks G times ONE rank of G on one GPU: that rank's share of the flops, so the fraction stays a fraction)
+            "gflops_algorithmic": round(f_alg / sim_div * a.steps / dt / 1e9, 1),
+            "frac_of_mfma_peak": round(f_alg / sim_div * a.steps / dt / 1e12 / (((2500.0 / 3.0) if a.precision == "bf16x3" else
+                                                                                  (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 78.6)) * world), 4),
             "objvalue": final_objvalue,   # evaluated after the timed region (see above)
             "roofline": roof,
             # per kernel: average launch time; algorithmic TFLOP/s and algorithmic HBM GB/s where the launch site states them
@@ -489,6 +492,25 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` typed as it stands (no launcher): re-run this script as N ranks under torch.distributed.run on this
+    node -- rendezvous on 127.0.0.1 at a free port, the caller's arguments unchanged -- and hand back its exit code.  Rank 0 of the
+    child job prints the one JSON line on the inherited stdout.  With the development back ends (NMFX_BENCH_BACKEND=gloo-p2p / gloo-sim)
+    on a box with fewer than N devices every rank is placed on device 0."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if env.get("NMFX_BENCH_BACKEND") in ("gloo-p2p", "gloo-sim") and "NMFX_BENCH_DEVICE" not in env and torch.cuda.device_count() < n:
+        env["NMFX_BENCH_DEVICE"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def live_traffic(kernel):

@@ -12,6 +12,7 @@ module NMFX
 
 using NMF
 import LinearAlgebra
+using Printf: @printf
 using LinearAlgebra: PosDefException
 
 const libnmfx = get(ENV, "NMFX_LIB", joinpath(@__DIR__, "..", "lib", "libnmfx.so"))
@@ -91,21 +92,39 @@ mutable struct Context{T}
     end
 end
 
-function run!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, H::Matrix{T}) where T
+# the verbose table of nmf_skeleton! (src/common.jl:54-59, 76-82): header, the t = 0 line (elapsed 0, objective of the start
+# factors), then per iteration t: elapsed seconds, objective, its change, and stop_condition's devmax -- printed after the solve from
+# the per-iteration records the device kept (objective trace of nmfx_solve, time stamps / devmax of nmfx_get_iter_trace)
+function print_verbose_table(io::IO, niters::Integer, objv::Vector{Float64}, elapsed::Vector{Float64}, relchange::Vector{Float64}, ::Type{T}) where T
+    @printf(io, "%-5s    %-13s    %-13s    %-13s    %-13s\n", "Iter", "Elapsed time", "objv", "objv.change", "(W & H).relchange")
+    @printf(io, "%5d    %13.6e    %13.6e\n", 0, 0.0, T(objv[1]))
+    for t in 1:niters
+        @printf(io, "%5d    %13.6e    %13.6e    %13.6e    %13.6e\n", t, elapsed[t + 1], T(objv[t + 1]), T(objv[t + 1]) - T(objv[t]), T(relchange[t + 1]))
+    end
+end
+
+function run!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, H::Matrix{T}; verbose::Bool=false, io::IO=stdout) where T
     (size(W) == (ctx.p, ctx.k) && size(H) == (ctx.k, ctx.n)) ||
         throw(DimensionMismatch("Dimensions of X, W, and H are inconsistent."))   # nmf_checksize, src/common.jl:5-16
     res = Ref{CResult}()
+    # verbose = true: the objective is evaluated at t = 0 and after every iteration (src/common.jl:56, :79) -- track_objective = 1,
+    # and nmfx_solve fills a (maxiter + 1)-vector with it
+    trace = verbose ? fill(NaN, Int(o.maxiter) + 1) : Float64[]
     st = ccall((:nmfx_solve, libnmfx), Cint,
                (Ptr{Cvoid}, Cint, Ref{COpts}, Ptr{T}, Ptr{T}, Ref{CResult}, Ptr{Float64}),
-               ctx.h, alg, o, W, H, res, C_NULL)
+               ctx.h, alg, o, W, H, res, verbose ? trace : C_NULL)
     check(st, ctx.h)
     r = res[]
+    if verbose
+        el, rc = iter_trace(ctx, Int(r.niters))
+        print_verbose_table(io, Int(r.niters), trace, el, rc, T)
+    end
     return NMF.Result{T}(W, H, Int(r.niters), r.converged != 0, T(r.objvalue))     # src/common.jl:21-35
 end
 
 opts(T; maxiter, tol, update_H, lambda_w=0.0, lambda_h=0.0, maxsubiter=200, tolg=eps(T)^(1/4),
-     l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision=0, cd_shuffle=0) =
-    COpts(maxiter, update_H, 0, maxsubiter, 20, 0, tol, lambda_w, lambda_h, sqrt(eps(T)), tolg, T(0.2), T(0.01),
+     l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision=0, cd_shuffle=0, verbose=false) =
+    COpts(maxiter, update_H, verbose ? 1 : 0, maxsubiter, 20, 0, tol, lambda_w, lambda_h, sqrt(eps(T)), tolg, T(0.2), T(0.01),
           l1_w, l2_w, l1_h, l2_h, precision, cd_shuffle)
 
 # ---- solve! methods: same signatures as src/multupd.jl:45, src/projals.jl:37, src/alspgrad.jl:381, with a
@@ -113,16 +132,16 @@ opts(T; maxiter, tol, update_H, lambda_w=0.0, lambda_h=0.0, maxsubiter=200, tolg
 function solve!(ctx::Context{T}, alg::NMF.MultUpdate{T}, W::Matrix{T}, H::Matrix{T}) where T
     a = alg.obj == :mse ? ALG_MULTMSE : ALG_MULTDIV
     run!(ctx, a, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
-                      lambda_w=alg.lambda_w, lambda_h=alg.lambda_h), W, H)
+                      lambda_w=alg.lambda_w, lambda_h=alg.lambda_h, verbose=alg.verbose), W, H; verbose=alg.verbose)
 end
 
 solve!(ctx::Context{T}, alg::NMF.ProjectedALS{T}, W::Matrix{T}, H::Matrix{T}) where T =
     run!(ctx, ALG_PROJALS, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
-                                lambda_w=alg.lambda_w, lambda_h=alg.lambda_h), W, H)
+                                lambda_w=alg.lambda_w, lambda_h=alg.lambda_h, verbose=alg.verbose), W, H; verbose=alg.verbose)
 
 solve!(ctx::Context{T}, alg::NMF.ALSPGrad{T}, W::Matrix{T}, H::Matrix{T}) where T =
     run!(ctx, ALG_ALSPGRAD, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
-                                 maxsubiter=alg.maxsubiter, tolg=alg.tolg), W, H)
+                                 maxsubiter=alg.maxsubiter, tolg=alg.tolg, verbose=alg.verbose), W, H; verbose=alg.verbose)
 
 # CoordinateDescent (src/coorddesc.jl:54-56): the l1/l2 pairs are resolved exactly like CoordinateDescentUpd's constructor
 # (src/coorddesc.jl:62-82).  shuffle = true: the component orders come from the library's documented Philox generator
@@ -132,13 +151,13 @@ function solve!(ctx::Context{T}, alg::NMF.CoordinateDescent{T}, W::Matrix{T}, H:
     u = NMF.CoordinateDescentUpd{T}(alg.α, alg.l₁ratio, alg.regularization, alg.shuffle, alg.update_H)
     key = alg.shuffle ? Int32(rand(1:typemax(Int32))) : Int32(0)
     run!(ctx, ALG_CD, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
-                           l1_w=u.l₁W, l2_w=u.l₂W, l1_h=u.l₁H, l2_h=u.l₂H, cd_shuffle=key), W, H)
+                           l1_w=u.l₁W, l2_w=u.l₂W, l1_h=u.l₁H, l2_h=u.l₂H, cd_shuffle=key, verbose=alg.verbose), W, H; verbose=alg.verbose)
 end
 
 # GreedyCD (src/greedycd.jl:34-35)
 solve!(ctx::Context{T}, alg::NMF.GreedyCD{T}, W::Matrix{T}, H::Matrix{T}) where T =
     run!(ctx, ALG_GREEDYCD, opts(T; maxiter=alg.maxiter, tol=alg.tol, update_H=alg.update_H,
-                                 lambda_w=alg.lambda_w, lambda_h=alg.lambda_h), W, H)
+                                 lambda_w=alg.lambda_w, lambda_h=alg.lambda_h, verbose=alg.verbose), W, H; verbose=alg.verbose)
 
 function solve!(alg::Union{NMF.MultUpdate{T},NMF.ProjectedALS{T},NMF.ALSPGrad{T},NMF.CoordinateDescent{T},NMF.GreedyCD{T}},
                 X::Matrix{T}, W::Matrix{T}, H::Matrix{T}; device::Integer=0) where T

@@ -40,3 +40,43 @@ def test_bench_json_contract(built, extra):
 def test_bench_help_runs_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_its_own_ranks(built):
+    """`python bench.py --gpus 2` typed as it stands (no torch.distributed.run in front, WORLD_SIZE unset) becomes two ranks by itself;
+    on this 1-GPU box both sit on device 0 and exchange through the peer windows (NMFX_BENCH_BACKEND=gloo-p2p).  One JSON line, from
+    rank 0, with n_gpus = 2 and the ranks holding the same W bits."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NMFX_BENCH_DEVICE")}
+    env["NMFX_BENCH_BACKEND"] = "gloo-p2p"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--p", "2048", "--n", "2048", "--k", "128",
+           "--prewarm-ms", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
+    assert d["multi_gpu_consistency"] == {"W_identical_on_all_ranks": True, "objective_identical_on_all_ranks": True, "finite": True}
+    assert "cpu_baseline" not in d      # rank 0 at N = 1 only
+
+
+def test_bench_gpus_n_without_a_launcher_spawns_torch_distributed_run(monkeypatch):
+    """CPU: the self-launch builds a torch.distributed.run command for N ranks on 127.0.0.1 with the caller's arguments."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    monkeypatch.setenv("NMFX_BENCH_BACKEND", "gloo-p2p")
+    monkeypatch.delenv("NMFX_BENCH_DEVICE", raising=False)
+    assert bench.self_launch(4) == 0
+    c = seen["cmd"]
+    assert c[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in c and "127.0.0.1" in c
+    assert c[-4:] == ["--gpus", "4", "--steps", "7"] and c[-5].endswith("bench.py")
+    assert seen["env"]["NMFX_BENCH_DEVICE"] == "0"       # fewer than 4 devices here: every rank on device 0

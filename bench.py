@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="do not bracket launches with hipEvents (no roofline object)")
     ap.add_argument("--all-events", action="store_true", help="hipEvent pair around every launch (per-kernel table; slows the loop ~4%%)")
     ap.add_argument("--cpu-sample-cols", type=int, default=2048)
+    ap.add_argument("--cpu-full-iters", type=int, default=2,
+                    help="multmse: after the bounded column sample, also time this many iterations of the CPU port on the FULL problem (own process, "
+                         "state pre-touched); 0 = scaled sample only")
     ap.add_argument("--check-every", type=int, default=1 << 30,
                     help="iterations between the host's polls of the device stop flag (default: never inside the timed region; the "
                          "API default is 0 = adaptive -- small problems pay a host round trip per poll)")
@@ -478,7 +481,7 @@ def main():
             out["sim_ranks"] = shards
             out["metric"] += f"_SIMULATED_rank0_of_{shards}_compute_only"
         if world == 1 and shards == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = (cpu_baseline(p, n, k, T, Xt, W0, H0, a.cpu_sample_cols) if a.alg == "multmse" else
+            out["cpu_baseline"] = (cpu_baseline(p, n, k, T, Xt, W0, H0, a.cpu_sample_cols, a.cpu_full_iters) if a.alg == "multmse" else
                                    cpu_baseline_generic(a.alg, p, n, k, T, Xt, W0, H0, a.cpu_sample_cols, lam, a.maxsubiter))
         if a.alg == "greedycd":
             out["greedy_steps_per_step"] = res.inner_iters / a.steps
@@ -572,7 +575,7 @@ def _blas_pool():
     return cap, desc
 
 
-def cpu_baseline(p, n, k, T, Xt, W0, H0, ns):
+def cpu_baseline(p, n, k, T, Xt, W0, H0, ns, full_iters=2):
     """NMF.jl's CPU path = the oracle's restatement of the reference's operation sequence with prepare_state's arrays allocated
     ONCE (oracle/nmf_oracle.py::_MultMSEState, like MultUpdMSE_State, src/multupd.jl:63-80), on the first `ns` columns of the same X
     (per-iteration cost is linear in n); value is scaled to the full problem.
@@ -616,8 +619,54 @@ def cpu_baseline(p, n, k, T, Xt, W0, H0, ns):
            "non_gemm_seconds": best["non_gemm_seconds"], "column_independent_seconds": best.get("column_independent_seconds"),
            "thread_trials": [{k_: t[k_] for k_ in ("blas_threads", "iters", "seconds_per_sample_iter", "gemm_gflops", "non_gemm_seconds")} for t in d["thread_trials"]],
            "blas": d["blas"]}
+    # ... and the FULL problem, measured (SURVEY.md section 8d "time >= 3 iterations at each config"): the same child process on all n
+    # columns -- X handed over as an uncompressed .npy, the state pre-touched by prepare_state and one warm-up iteration, the BLAS pool
+    # pinned to the sample's fastest setting, `full_iters` timed iterations.  When it succeeds THIS is `value`; the scaled sample stays
+    # beside it as `scaled_sample_value`.
+    out["measured_full_size"] = False
+    if full_iters > 0 and ns < n:
+        full = cpu_full_size(p, n, k, Xt, W0, H0, used, full_iters)
+        out["full_size_run"] = full
+        if full.get("seconds_per_iter") is not None:
+            out["scaled_sample_value"] = out["value"]
+            out["value"] = round(1.0 / full["seconds_per_iter"], 5)
+            out["measured_full_size"] = True
+            out["gflops_reference_equiv"] = round(12.0 * p * n * k / full["seconds_per_iter"] / 1e9, 1)
+            out["sample"] = (f"FULL problem, measured: all {n} columns of the same X (p={p}, k={k}), {full['iters']} timed pure outer iterations (update_wh! + "
+                             f"preW/preH copies + stop_condition) of oracle/nmf_oracle.py::_MultMSEState after prepare_state and one untimed warm-up "
+                             f"iteration, own process, BLAS pool pinned to {used} threads (the fastest setting of the column sample).  The scaled "
+                             f"column sample (`scaled_sample_value`): " + out["sample"])
+    elif ns >= n:
+        out["measured_full_size"] = True      # the sample IS the problem
     out["julia_reference"] = julia_reference(p, ns, k, T)
     return out
+
+
+def cpu_full_size(p, n, k, Xt, W0, H0, threads, iters):
+    """`iters` full-size iterations of the CPU port in a process of its own; {"seconds_per_iter": ..., ...} or {"error": ...}."""
+    import subprocess
+    import tempfile
+    t_all = time.perf_counter()
+    try:
+        tmp_root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        with tempfile.TemporaryDirectory(dir=tmp_root) as td:
+            Xh = Xt.cpu().numpy()                                   # (n, p) row-major == p x n column-major
+            np.save(os.path.join(td, "X.npy"), Xh.T)                # Fortran-order .npy of the p x n matrix (no copy: .T of a C array)
+            del Xh
+            np.savez(os.path.join(td, "f.npz"), W0=np.asfortranarray(W0), H0=np.asfortranarray(H0))
+            env = {k_: v for k_, v in os.environ.items() if k_ not in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+            cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_time.py"), os.path.join(td, "f.npz"), "0.0", str(n), "--x-npy", os.path.join(td, "X.npy"),
+                   "--min-iters", str(iters), "--max-iters", str(iters)] + (["--threads", str(threads)] if threads else [])
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode != 0:
+            return {"seconds_per_iter": None, "error": (r.stderr or r.stdout)[-400:]}
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        b = d["best"]
+        return {"seconds_per_iter": b["seconds_per_sample_iter"], "iters": b["iters"], "blas_threads": b["blas_threads"], "columns": d["ns"],
+                "gemm_seconds": b["gemm_seconds"], "gemm_gflops": b["gemm_gflops"], "non_gemm_seconds": b["non_gemm_seconds"],
+                "phase_seconds": b["phase_seconds"], "wall_seconds_incl_setup": round(time.perf_counter() - t_all, 1)}
+    except Exception as e:  # noqa: BLE001
+        return {"seconds_per_iter": None, "error": repr(e)}
 
 
 def cpu_baseline_generic(alg, p, n, k, T, Xt, W0, H0, ns, lam, maxsubiter):

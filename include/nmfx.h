@@ -101,8 +101,20 @@ typedef struct {
      * Philox4x32-10(counter = (i, c, 4, 0), key = cd_shuffle)[0], i = 0..k-1 (ties by index) -- documented, reproducible,
      * identical on every rank of a sharded run. */
     int32_t cd_shuffle;
+    /* ALSPGrad: how the gradient of an inner iteration is formed.  The reference recomputes G = Gram*Z - B by a full product at the
+     * top of EVERY inner iteration (src/alspgrad.jl:124-127, 280-283).  1 = exactly that ("exact").  n > 1: the running form
+     * G += Gram*D(accepted step) -- Gram*D is what the accepted trial step just computed (alspgrad.jl:150-152) -- with a full product
+     * every n-th inner iteration to bound the rounding drift of the running sum (one product less per inner iteration).
+     * 0 = the library default: 64 for Float64 (counters and iterates equal to the exact form's in every test), 1 (exact) for
+     * Float32 (the running form moves Float32 line-search decisions). */
+    int32_t pg_refresh;
+    /* ProjectedALS: how H = (W'W + lambda I) \ W'X is solved after potrf! (src/utils.jl:63-70).  NMFX_HSOLVE_AUTO (0): the library
+     * default; NMFX_HSOLVE_PRODUCT (1): Uinv (Uinv' B), two products with the inverted factor; NMFX_HSOLVE_POTRS (2): forward and back
+     * substitution with the factor itself, the reference's potrs! route (csrc/chol.hpp: potrs_panel_kernel). */
+    int32_t h_solve;
 } nmfx_opts;
 enum { NMFX_PREC_FP32 = 0, NMFX_PREC_BF16X3 = 1 };
+enum { NMFX_HSOLVE_AUTO = 0, NMFX_HSOLVE_PRODUCT = 1, NMFX_HSOLVE_POTRS = 2 };
 
 /* NMF.Result{T} minus the matrices (src/common.jl:21-27), plus measurement fields */
 typedef struct {
@@ -254,11 +266,14 @@ int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode);
  *                         its handle (NMFX_P2P_HANDLE_BYTES).  The communicator the context already has becomes the FALLBACK for
  *                         collectives the windows cannot serve (the pipelined mode's second stream).
  *   nmfx_comm_p2p_attach  all_handles = the nranks handles in rank order (the host ships them by any means, like the unique id):
- *                         maps the peers' windows; from here on the exchange runs over them.
+ *                         maps the peers' windows; from here on the exchange runs over them.  all_handles = NULL detaches:
+ *                         the windows are unmapped and every collective goes to the wrapped transport again (what every rank
+ *                         must do when mapping failed on ANY rank, so that the ranks keep routing by the same rule).
  *   nmfx_comm_init_p2p    a communicator with NO other transport (then export + attach as above): no RCCL involved; also works
  *                         with several processes on ONE device, where RCCL refuses duplicate GPUs (tests/test_gpu_peer.py).
  * Waits are bounded (NMFX_P2P_TIMEOUT_S, default 30): a rank that never arrives turns into NMFX_ERR_RCCL ("peer exchange timed
- * out") at the end of the solve instead of a hung GPU.  nmfx_comm_p2p_stats: collectives served by the windows / by the fallback. */
+ * out") at the end of the solve instead of a hung GPU -- on EVERY rank: the rank whose wait expires raises the abort word in all
+ * mapped windows.  The state is sticky: destroy the contexts and build a new communicator.  nmfx_comm_p2p_stats: collectives served by the windows / by the fallback. */
 #define NMFX_P2P_HANDLE_BYTES 128
 int nmfx_comm_init_p2p(nmfx_ctx *ctx, int rank, int nranks);
 int nmfx_comm_p2p_export(nmfx_ctx *ctx, void *handle_out /* NMFX_P2P_HANDLE_BYTES */);

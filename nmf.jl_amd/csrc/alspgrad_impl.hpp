@@ -90,7 +90,9 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     };
     // A full product G = Gram*Z - B every REFRESH inner iterations bounds the rounding drift of the running sum
     // (the first iteration of a sub-solve always: Gram and B are new)
-    const int REFRESH = (sizeof(T) == 4) ? 16 : 64;
+    // nmfx_opts.pg_refresh: 1 = the reference's form (a full product at the top of every inner iteration, src/alspgrad.jl:124-127,
+    // 280-283); 0 = the library default
+    const int REFRESH = pg_refresh_opt > 0 ? pg_refresh_opt : ((sizeof(T) == 4) ? PG_REFRESH_F32_DEFAULT : 64);
     auto fetch = [&]() {
         HIP_TRY(hipMemcpyAsync(pg_host, pg_state, sizeof(PgState), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -192,6 +194,7 @@ template <typename T> long long Solver<T>::w_subsolve(T *Wc, const T *Hc, const 
 
 template <typename T> void Solver<T>::subsolve(int which, const nmfx_opts &o, nmfx_result *out) {
     precision = o.precision;
+    pg_refresh_opt = o.pg_refresh;
     rsvd_ready = 0;
     require_ready();
     HIP_TRY(hipSetDevice(device));
@@ -223,6 +226,7 @@ template <typename T> void Solver<T>::run_alspgrad(const nmfx_opts &o, nmfx_resu
         HIP_TRY(hipStreamSynchronize(stream));
     }
     pg_backtracks = 0;
+    pg_refresh_opt = o.pg_refresh;
     long long inner = 0;
     T tolg = (T)o.tolg;                                                    // fresh ALSPGradUpd per solve! (:381-383)
     begin_iter_trace(o);

@@ -733,12 +733,32 @@ template <typename T, int STATS> struct EpiMultUpdate {
     rsrc_t rnum, rold, rout;
     LaneAddr<T> la;
     int64_t tile_off;
+    // STATS == 2 (Float32): the new factor is ALSO written transposed -- element (r, c) at outT[r + c * ldT] -- so that the X*H' product
+    // of the W side finds H' contraction-contiguous (Solver::times_ht with the X' image).  The four consecutive rows a lane owns per
+    // accumulator group (C/D layout: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) leave as TWO 8-byte stores.
+    // NOT one 16-byte store: `buffer_store_dwordx4 v[a:a+3], voff, s[desc], sN offen` with the scalar offset in an SGPR, followed directly by
+    // a VALU write of v[a:a+1] (the registers are dead behind the store and the allocator hands them to the next v_cvt_f64_f32), stored
+    // the NEW contents of v[a:a+1] on gfx950 -- sporadically, under load from other queues (found with four ranks sharing the GPU:
+    // 64-384 of 327 680 elements per launch carried halves of the statistics' Float64 temporaries).  LLVM inserts the wait states of the
+    // ">64-bit store data, then VALU write of the data registers" hazard only when the scalar offset is NOT a register (the rule of
+    // earlier chips); with an immediate offset it puts two VALU instructions between and those stores were never wrong.  8-byte
+    // stores are outside the hazard class altogether.
+    T *outT = nullptr;
+    int64_t ldT = 0;
+    rsrc_t routT;
+    uint32_t lbT, pitchT;
+    f32x4 tv;
     __device__ __forceinline__ void setup(int, const TileCtx &t) {
         rnum = tile_rsrc(num, ld, t);
         rold = tile_rsrc(old, ld, t);
         rout = tile_rsrc(out, ld, t);
         tile_off = t.cw0 + t.rw0 * ld;
         la.init(t, ld);
+        if constexpr (STATS == 2) {
+            routT = __builtin_amdgcn_make_buffer_rsrc((void *)(outT + (t.rw0 + t.cw0 * ldT)), 0, -1, 0x00020000);
+            lbT = (uint32_t)(((int64_t)t.rl + (int64_t)t.cl * ldT) * (int64_t)sizeof(T));
+            pitchT = (uint32_t)(ldT * (int64_t)sizeof(T));
+        }
     }
     __device__ __forceinline__ void begin() {
         if constexpr (STATS != 0) {
@@ -771,6 +791,16 @@ template <typename T, int STATS> struct EpiMultUpdate {
         const T ov = pre.ov;
         const T nv = ov * (t / (v + delta));
         buf_st(rout, la.lb, la.soff(ro, co), nv);
+        if constexpr (STATS == 2) {
+            static_assert(STATS != 2 || sizeof(T) == 4, "transposed copy: Float32 only");
+            tv[ro & 1] = nv;
+            if ((ro & 1) == 1) {
+                typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+                typedef float v2f_t __attribute__((ext_vector_type(2)));
+                const v2f_t pr = {tv[0], tv[1]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, pr), routT, (int)lbT, (int)((uint32_t)(ro - 1) * (uint32_t)sizeof(T) + (uint32_t)co * pitchT), 0);
+            }
+        }
         if constexpr (STATS != 0) {
             const T d = nv - ov, sp = nv + ov;
             dev[jt] += (double)(T)(d * d);

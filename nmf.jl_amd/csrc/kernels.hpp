@@ -110,6 +110,23 @@ __global__ __launch_bounds__(256) void reduce_pair_kernel(T *dst1, const T *src1
 }
 
 // A[i + i*ld] += a for i < m  (adddiag!, src/utils.jl:15-24)
+// dst (cols x rows, ld ldd) = src' for src (rows x cols, ld lds), both column-major; rows, cols multiples of 64 (padded sizes).
+// 64 x 64 tiles through LDS (+1 padding): 256-byte coalesced segments on both sides.  Used ONCE per uploaded X (the second,
+// contraction-contiguous image of X for the X*H' product) and once per solve for the start H; never inside an iteration.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(T *dst, int64_t ldd, const T *src, int64_t lds, int64_t rows, int64_t cols, const int *done) {
+    if (done != nullptr && *reinterpret_cast<const volatile int *>(done) != 0) return;
+    __shared__ T tile[64][65];
+    const int64_t tr = rows / 64;
+    const int64_t r0 = (int64_t)(blockIdx.x % tr) * 64, c0 = (int64_t)(blockIdx.x / tr) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) { const int j = ty + 4 * jj; tile[j][tx] = src[(c0 + j) * lds + r0 + tx]; }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) { const int j = ty + 4 * jj; dst[(r0 + j) * ldd + c0 + tx] = tile[tx][j]; }
+}
+
 template <typename T>
 __global__ void adddiag_kernel(T *A, int64_t ld, int m, T a, const int *done) {
     NMFX_DONE_GUARD(done);

@@ -178,8 +178,8 @@ int nmfx_comm_p2p_export(nmfx_ctx *ctx, void *handle_out) {
 }
 
 int nmfx_comm_p2p_attach(nmfx_ctx *ctx, const void *all_handles) {
-    if (!ctx || !all_handles) return NMFX_ERR_BAD_ARG;
-    return guarded(ctx, [&] { ctx->impl->p2p_attach(all_handles); });
+    if (!ctx) return NMFX_ERR_BAD_ARG;
+    return guarded(ctx, [&] { ctx->impl->p2p_attach(all_handles); });   // all_handles = NULL: detach (back to the wrapped transport)
 }
 
 int nmfx_comm_p2p_stats(nmfx_ctx *ctx, int64_t *served_by_windows, int64_t *served_by_base) {

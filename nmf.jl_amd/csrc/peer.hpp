@@ -10,7 +10,12 @@
 //
 // Every rank owns a WINDOW (device memory exported with hipIpcGetMemHandle; peers in the same process use the pointer itself):
 //   header   flag[q]   (u32) = sequence number of the last collective whose data from rank q has completely arrived HERE
-//            abort     (u32) = a wait of this rank timed out: every later wait returns at once, the host raises an error
+//            abort     (u32) = a wait of SOME rank timed out.  The rank that times out stores 1 into the abort word of EVERY mapped
+//                              window (system scope), so all ranks fail together: from then on every wait returns at once, pushes and
+//                              signals are skipped (a rank that runs ahead must not overwrite the parity slots of peers that are
+//                              still reading), and the host raises a communicator error at its next synchronisation point
+//                              (health()).  The word is STICKY: a context whose exchange timed out keeps failing -- destroy it and
+//                              build a new communicator (the peers' state is unknown after a time-out; nothing here could resync it).
 //            tiny inbox      : { value, tag } granules of the in-kernel all-reduce (TinyAR)
 //   data     2 parities x nranks slots of slot_bytes: collective s uses parity s & 1, slot q receives rank q's contribution
 // A collective (or a group of them: PeerComm::group_start / group_end) with sequence number s is
@@ -64,6 +69,15 @@ constexpr int PEER_AUX = 17;   // gfx940+: bit 0 = sc0, bit 4 = sc1
 
 __device__ __forceinline__ unsigned peer_load_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void peer_store_u32(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// a wait timed out: every rank must fail, not only this one (a peer that was merely slow would otherwise find later flags and sum
+// slot data of later collectives with its own abort word still 0)
+__device__ __forceinline__ void peer_abort_all(const PeerWin &w, int n) {
+    for (int q = 0; q < n; ++q)
+        if (w.p[q]) peer_store_u32(reinterpret_cast<unsigned *>(w.p[q] + PEER_ABORT_OFF), 1u);
+}
+__device__ __forceinline__ bool peer_aborted(const unsigned char *mine) {
+    return peer_load_u32(reinterpret_cast<const unsigned *>(mine + PEER_ABORT_OFF)) != 0;
+}
 
 // The in-kernel all-reduce (sum) of nval <= PEER_TINY_MAX doubles, called by ALL threads of ONE block (blockDim >= 64) with the
 // block's values in vals[] (every thread holds the same values, or at least thread j holds vals[j]): each value goes to every
@@ -74,6 +88,15 @@ __device__ __forceinline__ void peer_store_u32(unsigned *p, unsigned v) { __hip_
 // already over, an inner iteration behind a converged one) do not consume a tag, so the tags of the calls that do run are
 // consecutive on every rank and two inbox parities suffice -- rank A can be at most one call ahead of rank B, because finishing
 // call c needs B's granule of call c, which B stores only after it finished call c - 1.
+// The granule is self-validating: its tag word carries the call count (low half) AND a hash of the value's bits (high half).  The
+// 16-byte store / load is observed untorn on gfx950, but the memory model only promises single-copy atomicity up to 8 bytes: a reader
+// that saw the new tag beside the value of call c - 2 would feed a wrong sum into one rank's line-search decision and the ranks would
+// diverge silently -- with the hash such a granule simply does not match yet.
+__device__ __forceinline__ unsigned long long tiny_tag(unsigned long long count, double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned h = ((unsigned)b ^ (unsigned)(b >> 32)) * 0x9E3779B1u + 0x7F4A7C15u;
+    return (count & 0xffffffffull) | ((unsigned long long)h << 32);
+}
 __device__ __forceinline__ bool tiny_allreduce(const TinyAR &t, double *vals, int nval, double *sm /* >= PEER_TINY_MAX doubles of LDS */) {
     if (t.n <= 1) return true;
     const int tid = threadIdx.x;
@@ -91,7 +114,7 @@ __device__ __forceinline__ bool tiny_allreduce(const TinyAR &t, double *vals, in
     const int par = (int)(tag & 1);
     for (int e = tid; e < t.n * nval; e += blockDim.x) {
         const int q = e / nval, j = e % nval;
-        TinyGran g{vals[j], tag};
+        TinyGran g{vals[j], tiny_tag(tag, vals[j])};
         TinyGran *dst = reinterpret_cast<TinyGran *>(t.win.p[q] + PEER_TINY_OFF) + ((par * LOCAL_MAX_RANKS + t.rank) * PEER_TINY_MAX + j);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, g), peer_rsrc(dst), 0, 0, PEER_AUX);
     }
@@ -105,10 +128,10 @@ __device__ __forceinline__ bool tiny_allreduce(const TinyAR &t, double *vals, in
             int spins = 0;
             while (true) {
                 const TinyGran g = __builtin_bit_cast(TinyGran, __builtin_amdgcn_raw_buffer_load_b128(peer_rsrc(src), 0, 0, PEER_AUX));
-                if (g.tag == tag) { s += g.v; break; }
+                if (g.tag == tiny_tag(tag, g.v)) { s += g.v; break; }   // (a torn granule -- new tag, old value -- fails the check and is polled again)
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 255) == 0 && (peer_load_u32(abortw) != 0 || wall_clock64() - t0 > t.timeout_ticks)) {
-                    peer_store_u32(const_cast<unsigned *>(abortw), 1u);
+                    peer_abort_all(t.win, t.n);
                     ok_sm = 0;
                     break;
                 }
@@ -125,7 +148,8 @@ __device__ __forceinline__ bool tiny_allreduce(const TinyAR &t, double *vals, in
 
 // ---- collective kernels ------------------------------------------------------------------------------------------------
 // push: bytes [q * src_stride, q * src_stride + bytes) of src  ->  window q at dst_off   (blockIdx.y = destination rank)
-__global__ __launch_bounds__(256) void peer_push_kernel(PeerWin w, size_t dst_off, const unsigned char *src, size_t bytes, size_t src_stride) {
+__global__ __launch_bounds__(256) void peer_push_kernel(PeerWin w, size_t dst_off, const unsigned char *src, size_t bytes, size_t src_stride, int rank) {
+    if (peer_aborted(w.p[rank])) return;   // after a time-out nothing is pushed any more (the peers may still read the slots)
     const int q = blockIdx.y;
     const unsigned char *s = src + (size_t)q * src_stride;
     unsigned char *d = w.p[q] + dst_off;
@@ -143,13 +167,15 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PeerWin w, size_t dst_of
 }
 // signal: "everything this rank pushed for collective `seq` has left" -> flag[rank] = seq in every window (lane q -> rank q)
 __global__ void peer_signal_kernel(PeerWin w, int rank, int n, unsigned seq) {
+    if (peer_aborted(w.p[rank])) return;   // ... and nothing is signalled: a peer that has not failed yet times out on this rank's flag
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     const int q = threadIdx.x;
     if (q < n) peer_store_u32(reinterpret_cast<unsigned *>(w.p[q] + PEER_FLAG_OFF) + rank, seq);
 }
 // wait (ONE block): until every rank's flag has reached seq; bounded by the wall clock (100 MHz ticks)
-__global__ void peer_wait_kernel(unsigned char *mine, int n, unsigned seq, unsigned long long timeout_ticks) {
+__global__ void peer_wait_kernel(PeerWin w, int rank, int n, unsigned seq, unsigned long long timeout_ticks) {
     const int q = threadIdx.x;
+    unsigned char *mine = w.p[rank];
     unsigned *abortw = reinterpret_cast<unsigned *>(mine + PEER_ABORT_OFF);
     if (q < n) {
         const unsigned *f = reinterpret_cast<const unsigned *>(mine + PEER_FLAG_OFF) + q;
@@ -158,7 +184,7 @@ __global__ void peer_wait_kernel(unsigned char *mine, int n, unsigned seq, unsig
         while ((int)(peer_load_u32(f) - seq) < 0) {
             __builtin_amdgcn_s_sleep(4);
             if ((++spins & 63) == 0 && (peer_load_u32(abortw) != 0 || wall_clock64() - t0 > timeout_ticks)) {
-                peer_store_u32(abortw, 1u);
+                peer_abort_all(w, n);
                 break;
             }
         }
@@ -287,6 +313,17 @@ struct PeerComm : Comm {
         }
         attached = true;
     }
+    // Back to the wrapped transport: unmap the peers' windows, every later collective goes to `base`.  For the case where mapping
+    // failed on SOME rank (no IPC support, no peer access): the ranks where it succeeded must not keep routing through windows the
+    // others do not use -- their collectives would no longer pair up.  The caller makes this collective (nmfx/dist.py::attach_p2p).
+    void detach() {
+        for (int q = 0; q < nranks; ++q) {
+            if (opened[q] && win.p[q]) (void)hipIpcCloseMemHandle(win.p[q]);
+            opened[q] = false;
+            if (q != rank) win.p[q] = nullptr;
+        }
+        attached = false;
+    }
     static void ck(hipError_t e, const char *what) {
         if (e != hipSuccess) throw CommError{std::string(what) + ": " + hipGetErrorString(e)};
     }
@@ -351,17 +388,17 @@ struct PeerComm : Comm {
             const size_t es = ct_size(o.ct);
             if (o.kind == 0) {          // all-reduce: the whole buffer to every rank
                 const size_t b = o.count * es;
-                hipLaunchKernelGGL(peer_push_kernel, dim3(grid_for(b / 16 + 1), n), dim3(256), 0, s, win, dst, reinterpret_cast<const unsigned char *>(o.buf), b, (size_t)0);
+                hipLaunchKernelGGL(peer_push_kernel, dim3(grid_for(b / 16 + 1), n), dim3(256), 0, s, win, dst, reinterpret_cast<const unsigned char *>(o.buf), b, (size_t)0, rank);
             } else if (o.kind == 1) {   // reduce-scatter: piece q to rank q
                 const size_t b = o.count * es;
-                hipLaunchKernelGGL(peer_push_kernel, dim3(grid_for(b / 16 + 1), n), dim3(256), 0, s, win, dst, reinterpret_cast<const unsigned char *>(o.send), b, b);
+                hipLaunchKernelGGL(peer_push_kernel, dim3(grid_for(b / 16 + 1), n), dim3(256), 0, s, win, dst, reinterpret_cast<const unsigned char *>(o.send), b, b, rank);
             } else if (o.kind == 2) {   // all-gather: the chunk to every rank
                 const size_t b = o.count * es;
-                hipLaunchKernelGGL(peer_push_kernel, dim3(grid_for(b / 16 + 1), n), dim3(256), 0, s, win, dst, reinterpret_cast<const unsigned char *>(o.send), b, (size_t)0);
+                hipLaunchKernelGGL(peer_push_kernel, dim3(grid_for(b / 16 + 1), n), dim3(256), 0, s, win, dst, reinterpret_cast<const unsigned char *>(o.send), b, (size_t)0, rank);
             }                           // kind 3: pushed by the producer itself (direct_* below)
         }
         hipLaunchKernelGGL(peer_signal_kernel, dim3(1), dim3(64), 0, s, win, rank, n, sq);
-        if (!sim) hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, mine, n, sq, timeout_ticks);
+        if (!sim) hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, win, rank, n, sq, timeout_ticks);
         for (const Op &o : ops) {
             const size_t src = reg + o.off;
             if (o.kind == 0 || o.kind == 1) {
@@ -382,9 +419,19 @@ struct PeerComm : Comm {
         group_off = 0;
     }
 
+    // One sequence counter and two parities are only safe on ONE stream (header: "every rank runs every collective in the same order
+    // on one stream").  The windows therefore serve the stream of their FIRST collective -- the solver's main stream (`home`;
+    // Solver::attach sets it explicitly) -- and nothing else: a collective on any other stream (the pipelined mode's second stream)
+    // goes to `base`, grouped or not.
+    hipStream_t home = nullptr;
+    bool home_set = false;
+    bool on_home(hipStream_t s) {
+        if (!home_set) { home = s; home_set = true; }
+        return s == home;
+    }
     void all_reduce(void *buf, size_t count, int ct, bool max_op, hipStream_t s) override {
         const size_t es = ct_size(ct);
-        if (!attached || (grouping && group_stream && group_stream != s)) { to_base_begin(); base->all_reduce(buf, count, ct, max_op, s); return; }
+        if (!attached || !on_home(s)) { to_base_begin(); base->all_reduce(buf, count, ct, max_op, s); return; }
         if (fits(count * es)) {
             group_stream = s;
             enqueue(Op{0, buf, nullptr, count, ct, max_op, 0}, count * es, s);
@@ -401,12 +448,12 @@ struct PeerComm : Comm {
         }
     }
     void reduce_scatter(const void *send, void *recv, size_t recvcount, int ct, hipStream_t s) override {
-        if (!fits(recvcount * ct_size(ct)) || (grouping && group_stream && group_stream != s)) { to_base_begin(); base->reduce_scatter(send, recv, recvcount, ct, s); return; }
+        if (!fits(recvcount * ct_size(ct)) || !on_home(s)) { to_base_begin(); base->reduce_scatter(send, recv, recvcount, ct, s); return; }
         group_stream = s;
         enqueue(Op{1, recv, send, recvcount, ct, false, 0}, recvcount * ct_size(ct), s);
     }
     void all_gather(const void *send, void *recv, size_t sendcount, int ct, hipStream_t s) override {
-        if (!fits(sendcount * ct_size(ct)) || (grouping && group_stream && group_stream != s)) { to_base_begin(); base->all_gather(send, recv, sendcount, ct, s); return; }
+        if (!fits(sendcount * ct_size(ct)) || !on_home(s)) { to_base_begin(); base->all_gather(send, recv, sendcount, ct, s); return; }
         group_stream = s;
         enqueue(Op{2, recv, send, sendcount, ct, false, 0}, sendcount * ct_size(ct), s);
     }

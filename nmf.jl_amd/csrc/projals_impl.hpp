@@ -157,7 +157,8 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // (NMFX_POTRS=1) -- a panel's two sweeps are a chain of 2 K / 32 dependent block steps that one workgroup per CU cannot overlap
     // with anything: 79 us at 16384 columns, k = 256, Float32 against 55 us for the two k x k x n products (scripts/kbench/potrs_bench.hip;
     // Float64, k = 128: 26 against 28 us).  nmfx_pdsolve, the exported pdsolve!, always takes the substitution route.
-    const bool subst = potrs_iter && potrs_ok();
+    // nmfx_opts.h_solve picks the route of the H solve (NMFX_POTRS=1 in the environment still forces substitution: A/B runs)
+    const bool subst = (o.h_solve == NMFX_HSOLVE_POTRS || (o.h_solve == NMFX_HSOLVE_AUTO && potrs_iter)) && potrs_ok();
     auto factor_under = [&](T *G, T lambda, const char *t1, const char *t2, bool with_potri) {
         HIP_TRY(hipEventRecord(ev_fork, stream));
         HIP_TRY(hipStreamWaitEvent(fstream, ev_fork, 0));

@@ -144,6 +144,7 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = std::getenv("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
         if (const char *e = std::getenv("NMFX_K_GRANULE")) k_granule = (std::atoi(e) == 128) ? 128 : 64;
         if (const char *e = std::getenv("NMFX_POTRS")) { potrs_enabled = std::atoi(e) != 0; potrs_iter = std::atoi(e) == 1; }
+        if (const char *e = std::getenv("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
@@ -208,6 +209,7 @@ template <typename T> class Solver : public SolverBase {
         obj_final.alloc(1);
         for (auto &w : work) w.release();
         Q.release(); Wbest.release(); Hbest.release();
+        Xt.release(); Ht[0].release(); Ht[1].release(); xt_valid = false;
         have_X = have_F = false;
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -249,6 +251,7 @@ template <typename T> class Solver : public SolverBase {
                                  on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         have_X = true;
+        xt_valid = false;
     }
 
     void set_factors(const void *Wsrc, const void *Hsrc) override {
@@ -307,6 +310,7 @@ template <typename T> class Solver : public SolverBase {
         if (!pc) {
             Comm *b = comm;
             pc = new PeerComm(b, device, p2p_slot_bytes());   // (throws before taking ownership of b only if the window cannot be allocated)
+            pc->home = stream; pc->home_set = true;           // the windows serve the main stream's collectives only (peer.hpp)
             comm = pc;
         }
         pc->export_handle(handle_out);
@@ -315,6 +319,7 @@ template <typename T> class Solver : public SolverBase {
         HIP_TRY(hipSetDevice(device));
         PeerComm *pc = dynamic_cast<PeerComm *>(comm);
         if (!pc) throw StatusError{NMFX_ERR_STATE, "nmfx_comm_p2p_attach: call nmfx_comm_p2p_export first"};
+        if (!all_handles) { HIP_TRY(hipStreamSynchronize(stream)); pc->detach(); return; }
         pc->attach(all_handles);
     }
     void p2p_stats(long long *w, long long *b) override {
@@ -453,6 +458,32 @@ template <typename T> class Solver : public SolverBase {
         return (size_t)(32 * 32 + 32 * kps) * sizeof(T);
     }
     DevBuf<T> X, Q, W[2], H[2], hside, slabs, svec, pack;
+    // Second image of X, transposed (N x P, ld N), and of the current H (N x K, ld N): with them the X*H' product of the W side
+    // (src/multupd.jl:109) contracts over the CONTIGUOUS index of both operands, like W'X does, and runs on the same kernel
+    // instantiation (contraction-contiguous staging, k-loop unrolled by two) instead of the row-contiguous one, whose register
+    // transposes cost ~50 % more issued instructions (profiles/r04_bench_multmse_c3.md: 118.9 M vs 79.0 M) and 4-5 % of time.
+    // X' is built once per uploaded X (one transpose pass, + p*n elements of HBM: 1 GiB of 288 at the headline shape); H' is written by
+    // the H update's own epilogue (EpiMultUpdate<T, 2>).  Float32, MultUpdate-MSE (general path); NMFX_XT=0 keeps the old product.
+    DevBuf<T> Xt, Ht[2];
+    bool xt_enabled = true, xt_valid = false, ht_active = false;
+    bool want_xt() const { return xt_enabled && sizeof(T) == 4 && !use_bf16x3(); }
+    void ensure_xt() {
+        if (xt_valid || !want_xt()) return;
+        if (Xt.count < (size_t)P * N) {
+            T *q = nullptr;
+            if (hipMalloc(reinterpret_cast<void **>(&q), (size_t)P * N * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); xt_enabled = false; return; }   // no room: keep the row-contiguous product
+            Xt.release(); Xt.p = q; Xt.count = (size_t)P * N;
+        }
+        hipLaunchKernelGGL(transpose_kernel<T>, dim3((unsigned)((P / 64) * (N / 64))), dim3(256), 0, stream, Xt.p, N, X.p, P, P, N, (const int *)nullptr);
+        HIP_TRY(hipGetLastError());
+        xt_valid = true;
+    }
+    // H' of the current H (start of a solve; afterwards the update epilogue keeps it current)
+    void refresh_ht() {
+        for (auto &h : Ht) h.ensure((size_t)N * K);
+        hipLaunchKernelGGL(transpose_kernel<T>, dim3((unsigned)((K / 64) * (N / 64))), dim3(256), 0, stream, Ht[hcur].p, N, H[hcur].p, K, K, N, (const int *)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
     T *numH_p = nullptr, *gramW_p = nullptr;
     T *numW_p = nullptr, *gramH_p = nullptr, *sH_p = nullptr;
     DevBuf<T> potrf_panel;   // potrf's row panel when it does not fit the LDS (k > 1248 f32 / 608 f64)
@@ -947,8 +978,19 @@ template <typename T> class Solver : public SolverBase {
     // slab = [ numW (ld P) | gramH (ld K) ] = the layout of the packed all-reduce buffer.
     int w_nslab = 1;
     int64_t w_stride = 0;
-    void times_ht(const T *Amat, const T *Hp, bool with_gram, const int *done, bool keep_slabs = false) {
+    void times_ht(const T *Amat, const T *Hp, bool with_gram, const int *done, bool keep_slabs = false, const T *HtP = nullptr) {
         T *reg = slabs.p + slab_w_off;
+        // HtP = H' (N x K, ld N) of the same H: the product contracts over the contiguous index of X' and H' (see Xt above)
+        const bool xt = HtP != nullptr && Amat == X.p && xt_valid && !use_bf16x3();
+        auto big = [&](int splits, const auto &e, double bytes, const Seg &sg_in, double extra) {
+            if (xt) {
+                Seg sg = sg_in;
+                if (sg.B2 != nullptr) { sg.B2 = HtP; sg.ldb2 = N; }
+                gemm<KCONTIG, KCONTIG>("gemm_XHt", HtP, N, K, Xt.p, N, P, N, splits, false, e, done, bytes, sg, extra);
+            } else {
+                gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, splits, false, e, done, bytes, sg_in, extra);
+            }
+        };
         if (use_bf16x3()) {
             w_nslab = s_w; w_stride = (int64_t)P * K;
             {
@@ -984,14 +1026,12 @@ template <typename T> class Solver : public SolverBase {
                 for (int g = 0; g < EPI_MAX_PIECES; ++g) e.piece[g] = (g < nranks) ? peer_dst->num[g] : nullptr;
                 e.piece_rows = Pc;
                 e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = (int64_t)K * K; e.r_off = 0; e.c_off = P;
-                gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, sw, false, e, done,
-                                         (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
+                big(sw, e, (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
             } else {
             EpiStore<T> e{direct ? numW_p : reg, direct ? Pc : P, w_stride, nullptr};
             if (direct) { e.piece_rows = Pc; e.piece_stride = (int64_t)K * Pc; }
             e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = (int64_t)K * K; e.r_off = 0; e.c_off = P;
-            gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, sw, false, e, done,
-                                     (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
+            big(sw, e, (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
             }
             w_direct = direct;
             if (w_defer_combine) { w_pieces = pieces; w_in_slabs = false; return; }   // the caller's combine launch sums both
@@ -1025,8 +1065,7 @@ template <typename T> class Solver : public SolverBase {
             }
             reduce_pieces("reduce_XHt_pieces", reg + (int64_t)(s_w - 1) * w_stride + r0, P, slabs.p + gram_slab_off, K, rows, shg.pieces, done);
         } else
-        gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done,
-                                 (double)(P * N + K * N) * sizeof(T));
+        big(s_w, e, (double)(P * N + K * N) * sizeof(T), Seg(), 0.0);
         const bool pair = with_gram && !w_blocked && (!keep_slabs || w_nslab > 2);   // both combines in one launch
         if (!pair) finish_w_slabs(keep_slabs, done);
         if (with_gram) {
@@ -1216,6 +1255,8 @@ template <typename T> class Solver : public SolverBase {
     long long pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int maxiter, int traceiter, T tolg, T beta, T sigma,
                           long long *inner_total);
     struct PgState *pg_state = nullptr, *pg_host = nullptr;
+    int pg_refresh_opt = 0;             // nmfx_opts.pg_refresh of the running solve
+    static constexpr int PG_REFRESH_F32_DEFAULT = 16;
     int pg_spec_hint[2] = {3, 3};   // speculative line-search steps per enqueued inner iteration (H side, W side), alspgrad_impl.hpp
     DevBuf<double> pg_part;
     long long pg_backtracks = 0;

@@ -148,8 +148,17 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
         h_reduce_pair = fusedrs;
         wt_times(Wp, X.p, !have_gram, done, /*keep_slabs=*/true);
         h_reduce_pair = false;
+        if constexpr (sizeof(T) == 4) {
+            if (ht_active) {   // the new H also transposed, for the X*H' product below
+                EpiMultUpdate<T, 2> e{h_num(), h_num_nslab(), h_stride, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};  // :99-103
+                e.outT = Ht[hcur ^ 1].p; e.ldT = N;
+                gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (4.0 + h_num_nslab()) * K * N * sizeof(T));
+            }
+        }
+        if (!ht_active) {
         EpiMultUpdate<T, 1> e{h_num(), h_num_nslab(), h_stride, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};  // :99-103
         gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (3.0 + h_num_nslab()) * K * N * sizeof(T));
+        }
         h_stat_chunks = last_tiles_r;
         if (!fusedrs) stats_h_finalize(last_tiles_r, done);   // fused row-sharded step: finalised by the W side's combine launch
         hcur ^= 1;
@@ -158,10 +167,11 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
     if (rs_fused()) { multmse_w_rows_fused(o, t); return; }
+    const T *HtP = ht_active ? Ht[hcur].p : nullptr;
     if (row_sharded()) {
         // sharded: X_g H_g' partial sums -> reduce-scatter by row blocks -> this rank updates ITS Pc rows -> all-gather
         w_blocked = true;
-        times_ht(X.p, Hp, true, done);
+        times_ht(X.p, Hp, true, done, false, HtP);
         w_blocked = false;
         scatter_w_numerator(o.update_H != 0, done);
         EpiMultUpdate<T, 0> e{numW_p + row0, 1, 0, Wo + row0, Wn + row0, P, (T)o.lambda_w, (T)o.delta, nullptr, 0};   // :110-114
@@ -174,7 +184,7 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
     // :109 XH': single GPU -> slabs are consumed by the update GEMM's epilogue; replicated-W mode -> reduce into the packed
     // buffer first, because the all-reduce needs the rank-local sum
     const bool w_slabs = !sharded();
-    times_ht(X.p, Hp, true, done, /*keep_slabs=*/w_slabs);
+    times_ht(X.p, Hp, true, done, /*keep_slabs=*/w_slabs, HtP);
     allreduce_w_side(o.update_H != 0, done);
     EpiMultUpdate<T, 0> e{w_num(), w_num_nslab(), w_stride, Wo, Wn, P, (T)o.lambda_w, (T)o.delta, nullptr, 0};   // :110-114
     gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo, P, P, K, 1, false, e, done, 3.0 * P * K * sizeof(T));
@@ -199,7 +209,7 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
     w_blocked = true; w_defer_combine = true;
-    times_ht(X.p, Hp, true, done);
+    times_ht(X.p, Hp, true, done, false, ht_active ? Ht[hcur].p : nullptr);
     w_blocked = false; w_defer_combine = false;
     const unsigned nb1 = w_direct ? 0u : (unsigned)(P / 256 * K), nb2 = (unsigned)((K * K + 63) / 64), nb3 = o.update_H ? (unsigned)((2 * K + 3) / 4) : 0u;
     timed("combine_W", 0.0, ((double)P * K * (w_nslab + 1) + (double)K * K * (w_pieces + 1)) * sizeof(T), [&] {
@@ -277,7 +287,7 @@ template <typename T> void Solver<T>::multmse_w_rows_fused_peer(const nmfx_opts 
     }
     const unsigned char *s_num = pc->direct_src(0, o_num), *s_gram = pc->direct_src(0, o_gram), *s_hs = pc->direct_src(0, o_hs);
     w_blocked = true; w_defer_combine = true; peer_dst = &pd;
-    times_ht(X.p, Hp, true, done);
+    times_ht(X.p, Hp, true, done, false, ht_active ? Ht[hcur].p : nullptr);
     w_blocked = false; w_defer_combine = false; peer_dst = nullptr;
     {
         const unsigned nb1 = w_direct ? 0u : (unsigned)(P / 256 * K), nb2 = (unsigned)((K * K + 63) / 64), nb3 = o.update_H ? (unsigned)((2 * K + 3) / 4) : 0u;
@@ -317,10 +327,10 @@ template <typename T> void Solver<T>::multmse_w_rows_fused_peer(const nmfx_opts 
     timed("push_W_rows", 0.0, (double)G * (Pc * K) * sizeof(T), [&] {
         // (the pushes carry no `done` guard: behind the stop they re-send the last rows, which nobody reads)
         hipLaunchKernelGGL(peer_push_kernel, dim3(PeerComm::grid_for(piece_b / 16 + 1), G), dim3(256), 0, stream, pc->win, pc->direct_off(o_w), reinterpret_cast<const unsigned char *>(mine),
-                           piece_b, (size_t)0);
+                           piece_b, (size_t)0, rank);
         if (o.update_H)
             hipLaunchKernelGGL(peer_push_kernel, dim3(PeerComm::grid_for(gram_b / 16 + 1), G), dim3(256), 0, stream, pc->win, pc->direct_off(o_gw),
-                               reinterpret_cast<const unsigned char *>(gramW_p), gram_b, (size_t)0);
+                               reinterpret_cast<const unsigned char *>(gramW_p), gram_b, (size_t)0, rank);
         HIP_TRY(hipGetLastError());
     });
     timed("comm_p2p_flag_wait_W", 0.0, (double)(P * K) * sizeof(T), [&] { pc->group_end(); });
@@ -474,6 +484,8 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     }
     if (alg < 0 || alg > NMFX_ALG_GREEDYCD) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid algorithm."};
     if (o.precision != NMFX_PREC_FP32 && o.precision != NMFX_PREC_BF16X3) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for precision."};
+    if (o.pg_refresh < 0) throw StatusError{NMFX_ERR_BAD_ARG, "pg_refresh must be non-negative."};
+    if (o.h_solve < NMFX_HSOLVE_AUTO || o.h_solve > NMFX_HSOLVE_POTRS) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for h_solve."};
     precision = o.precision;
     pipe_pending = false;
     check_fused = false;
@@ -503,6 +515,12 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         std::vector<double> nanv((size_t)o.maxiter + 1, std::nan(""));
         HIP_TRY(hipMemcpyAsync(trace_dev.p, nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+    }
+    // MultUpdate-MSE, general path, Float32: the X*H' product on the transposed images (solver.hpp: Xt)
+    ht_active = false;
+    if (alg == NMFX_ALG_MULTMSE && !smallk_ok() && !pipelined() && want_xt()) {
+        ensure_xt();
+        if (xt_valid) { refresh_ht(); ht_active = true; }
     }
     if (alg == NMFX_ALG_CD && o.cd_shuffle != 0) prepare_cd_permutations(o);
     const int w0 = wcur, h0 = hcur;

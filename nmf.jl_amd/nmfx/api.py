@@ -117,21 +117,27 @@ class ProjectedALS:
 
 
 class ALSPGrad:
-    """ALSPGrad{T}(; maxiter, maxsubiter, tol, tolg, update_H, verbose)  (src/alspgrad.jl:352-373)."""
+    """ALSPGrad{T}(; maxiter, maxsubiter, tol, tolg, update_H, verbose)  (src/alspgrad.jl:352-373).
+    gradient (no reference counterpart): "exact" = G = Gram*Z - B by a full product every inner iteration, the reference's form
+    (src/alspgrad.jl:124-127); an integer n > 1 = running gradient with a full product every n-th inner iteration; None = the
+    library default (include/nmfx.h: nmfx_opts.pg_refresh)."""
 
-    def __init__(self, T, maxiter=100, maxsubiter=200, tol=None, tolg=None, update_H=True, verbose=False):
+    def __init__(self, T, maxiter=100, maxsubiter=200, tol=None, tolg=None, update_H=True, verbose=False, gradient=None):
         T = np.dtype(T).type
         self.T, self.maxiter, self.maxsubiter = T, int(maxiter), int(maxsubiter)
         self.tol = float(T(np.cbrt(_eps(T)) if tol is None else tol))
         self.tolg = float(T(_eps(T) ** 0.25 if tolg is None else tolg))
         self.update_H, self.verbose = bool(update_H), bool(verbose)
+        if gradient is not None and gradient != "exact" and not (isinstance(gradient, int) and gradient >= 1):
+            raise ValueError("gradient must be None, 'exact' or an integer >= 1")
+        self.pg_refresh = 0 if gradient is None else (1 if gradient == "exact" else int(gradient))
 
     def _alg(self):
         return L.ALG_ALSPGRAD
 
     def _opts(self):
         return dict(maxiter=self.maxiter, tol=self.tol, update_H=self.update_H, maxsubiter=self.maxsubiter,
-                    tolg=self.tolg)
+                    tolg=self.tolg, pg_refresh=self.pg_refresh)
 
 
 class CoordinateDescent:
@@ -233,7 +239,7 @@ class Result:
 
 def make_opts(T, maxiter=100, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.0, delta=None, maxsubiter=200,
               traceiter=20, tolg=None, beta=0.2, sigma=0.01, track_objective=False, check_every=0,
-              l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision="fp32", cd_shuffle=0) -> L.Opts:
+              l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision="fp32", cd_shuffle=0, pg_refresh=0, h_solve="auto") -> L.Opts:
     T = np.dtype(T).type
     return L.Opts(int(maxiter), int(bool(update_H)), int(bool(track_objective)), int(maxsubiter), int(traceiter),
                   int(check_every),
@@ -241,7 +247,8 @@ def make_opts(T, maxiter=100, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.
                   float(T(math.sqrt(_eps(T))) if delta is None else delta),
                   float(T(_eps(T) ** 0.25) if tolg is None else tolg), float(T(beta)), float(T(sigma)),
                   float(l1_w), float(l2_w), float(l1_h), float(l2_h),
-                  {"fp32": L.PREC_FP32, "bf16x3": L.PREC_BF16X3}[precision], int(cd_shuffle))
+                  {"fp32": L.PREC_FP32, "bf16x3": L.PREC_BF16X3}[precision], int(cd_shuffle), int(pg_refresh),
+                  {"auto": 0, "product": 1, "potrs": 2}[h_solve])
 
 
 def nmf_checksize(X, W, H):
@@ -451,7 +458,11 @@ class Context:
         return buf.raw
 
     def comm_p2p_attach(self, handles):
-        """Map every rank's window (handles: the nranks exported handles in rank order) and switch the exchange to them."""
+        """Map every rank's window (handles: the nranks exported handles in rank order) and switch the exchange to them.
+        handles = None detaches: every collective goes to the wrapped transport again."""
+        if handles is None:
+            self._ck(self.lib.nmfx_comm_p2p_attach(self.h, None))
+            return
         blob = b"".join(handles)
         buf = C.create_string_buffer(blob, len(blob))
         self._ck(self.lib.nmfx_comm_p2p_attach(self.h, buf))

@@ -41,6 +41,8 @@ def init_comm(ctx, group=None, transport="rccl"):
     communicator at all (also works with several ranks on ONE device, where RCCL refuses duplicate GPUs)."""
     import torch.distributed as dist
     from .api import comm_unique_id
+    if transport not in ("rccl", "p2p", "p2p_only"):      # before any collective work: a typo must not leave a half-built communicator
+        raise ValueError(f"unknown transport {transport!r}")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if transport == "p2p_only":
         ctx.comm_init_p2p(rank, world)
@@ -49,8 +51,6 @@ def init_comm(ctx, group=None, transport="rccl"):
         ctx.comm_init(uid, rank, world)
     if transport in ("p2p", "p2p_only"):
         attach_p2p(ctx, group)
-    elif transport != "rccl":
-        raise ValueError(f"unknown transport {transport!r}")
 
 
 def attach_p2p(ctx, group=None):
@@ -77,4 +77,10 @@ def attach_p2p(ctx, group=None):
     dist.all_gather_object(alle, err, group=group)
     bad = [(r, e) for r, e in enumerate(alle) if e is not None]
     if bad:
-        raise RuntimeError(f"peer windows: mapping failed on rank(s) {bad}")
+        # all-or-nothing: the ranks where mapping succeeded detach again, so that a caller who falls back to the wrapped transport
+        # on the same context finds every rank routing by the same rule (windows on some ranks, RCCL on others would never pair up)
+        try:
+            ctx.comm_p2p_attach(None)
+        except Exception:  # noqa: BLE001
+            pass
+        raise RuntimeError(f"peer windows: mapping failed on rank(s) {bad}; every rank is back on the wrapped transport")

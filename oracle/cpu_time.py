@@ -33,10 +33,24 @@ except Exception:  # noqa: BLE001
 
 
 def main():
-    d = np.load(sys.argv[1])
-    budget_s = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
-    n_full = int(sys.argv[3]) if len(sys.argv) > 3 else None        # columns of the FULL problem the sample stands for
-    X, W0, H0 = (np.asfortranarray(d[k]) for k in ("X", "W0", "H0"))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("sample")                                      # .npz: X (p x ns), W0 (p x k), H0 (k x ns); with --x-npy: W0, H0 only
+    ap.add_argument("budget_s", nargs="?", type=float, default=4.0)
+    ap.add_argument("n_full", nargs="?", type=int, default=None)   # columns of the FULL problem the sample stands for
+    ap.add_argument("--x-npy", default=None, help="X as an uncompressed .npy (the FULL problem: too large for an .npz round trip)")
+    ap.add_argument("--threads", default=None, help="comma-separated BLAS pool sizes to try (default: the pool's cap and 1/2 ... 1/16 of it)")
+    ap.add_argument("--min-iters", type=int, default=1, help="timed iterations per setting, at least (the budget only stops the loop beyond it)")
+    ap.add_argument("--max-iters", type=int, default=6)
+    a = ap.parse_args()
+    d = np.load(a.sample)
+    budget_s, n_full = a.budget_s, a.n_full
+    if a.x_npy:
+        X = np.load(a.x_npy, mmap_mode="r")
+        X = np.array(X, order="F")             # a private copy: this process's own pages, touched here and not in the timed loop
+        W0, H0 = (np.asfortranarray(d[k]) for k in ("W0", "H0"))
+    else:
+        X, W0, H0 = (np.asfortranarray(d[k]) for k in ("X", "W0", "H0"))
     T = X.dtype.type
     p, ns = X.shape
     k = W0.shape[1]
@@ -48,6 +62,8 @@ def main():
     cands = [None]
     if cap and threadpool_limits:
         cands = sorted({c for c in (cap, cap // 2, cap // 4, cap // 8, cap // 16) if c >= 1}, reverse=True)
+        if a.threads:
+            cands = [min(cap, max(1, int(c))) for c in a.threads.split(",")]
     trials = []
     for c in cands:
         cm = threadpool_limits(limits=c, user_api="blas") if (c and threadpool_limits) else None
@@ -56,7 +72,7 @@ def main():
             st = orc._MultMSEState(T, o, X, Ws, Hs)               # prepare_state: NOT timed
             st.update(X, Ws, Hs)                                   # warm-up (BLAS threads, first touch of the state)
             phases, iters, used = {}, 0, 0.0
-            while iters < 6 and used < budget_s:
+            while iters < a.max_iters and (used < budget_s or iters < a.min_iters):
                 t0 = time.perf_counter()
                 np.copyto(st.preW, Ws)                            # common.jl:66
                 t1 = time.perf_counter()

@@ -100,13 +100,19 @@ def test_peer_other_modes(built, alg, mode):
     """replicated_w: the packed all-reduce is larger than a slot and travels in slot-sized pieces.  pipelined: its collectives run
     on a second stream -- the windows cannot order those, the wrapped in-process group serves them."""
     T = np.float64
-    p, n, k = 260, 410, 5
+    # (the pipelined exchange exists for K % 128 == 0 and whole 128-row tiles per rank and super-chunk: p = 512, k = 100 on 2 ranks;
+    # smaller shapes run the plain row-sharded step whatever the mode says)
+    p, n, k = (512, 600, 100) if mode == "pipelined" else (260, 410, 5)
     X, W0, H0 = planted(p, n, k, T, seed=23, normalize=(alg != "projals"))
     lam = lam_for(alg, T)
     kw = dict(maxiter=6, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True)
     ref = run_sharded(T, X, W0, H0, alg, kw, 2, mode=mode)
     *got, stats = run_peer_threads(T, X, W0, H0, alg, kw, 2, mode=mode, wrap_local=(mode == "pipelined"))
     same_run(ref, tuple(got), alg)
+    if mode == "pipelined":
+        # the windows serve the main stream only (one sequence counter, two parities: safe on ONE stream); the reduce-scatters and
+        # all-gathers of the second stream are handed to the wrapped transport -- both counters must have moved
+        assert all(s[0] > 0 and s[1] > 0 for s in stats), stats
 
 
 def test_peer_stop_rule_and_update_h_false(built):
@@ -238,3 +244,43 @@ def test_peer_timeout_is_an_error_not_a_hang(built):
                 a.solve(ALG["multmse"], nmfx.make_opts(T, maxiter=2, tol=1e-30), W, H)      # rank 1 never runs
     finally:
         del os.environ["NMFX_P2P_TIMEOUT_S"]
+
+
+def test_peer_timeout_fails_every_rank_including_one_that_was_only_slow(built):
+    """a rank whose wait times out raises the abort word in EVERY mapped window.  Rank 1 here is merely late (it starts
+    its solve well after rank 0 gave up): without the propagation it would find rank 0's later flags, sum slot data of later
+    collectives and return NMFX_OK with corrupted factors.  Both solves must end with the communicator error."""
+    import time
+    T = np.float32
+    p, n, k = 256, 300, 4
+    X, W0, H0 = planted(p, n, k, T, seed=5)
+    os.environ["NMFX_P2P_TIMEOUT_S"] = "1.0"
+    errs = [None, None]
+    try:
+        with nmfx.Context(T, p, 150, k) as a, nmfx.Context(T, p, 150, k) as b:
+            a.comm_init_p2p(0, 2)
+            b.comm_init_p2p(1, 2)
+            hs = [a.comm_p2p_export(), b.comm_p2p_export()]
+            a.comm_p2p_attach(hs)
+            b.comm_p2p_attach(hs)
+            a.set_X(np.asfortranarray(X[:, :150]))
+            b.set_X(np.asfortranarray(X[:, 150:]))
+
+            def run(ctx, r, delay, c0, c1):
+                time.sleep(delay)
+                W, H = W0.copy(order="F"), np.asfortranarray(H0[:, c0:c1].copy())
+                try:
+                    ctx.solve(ALG["multmse"], nmfx.make_opts(T, maxiter=6, tol=1e-30), W, H)
+                    errs[r] = "returned without an error"
+                except Exception as e:  # noqa: BLE001
+                    errs[r] = repr(e)
+
+            th = [threading.Thread(target=run, args=(a, 0, 0.0, 0, 150)), threading.Thread(target=run, args=(b, 1, 4.0, 150, 300))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join(120)
+    finally:
+        del os.environ["NMFX_P2P_TIMEOUT_S"]
+    assert errs[0] is not None and "timed out" in errs[0], errs
+    assert errs[1] is not None and "timed out" in errs[1], errs

@@ -338,3 +338,29 @@ def test_alspgrad_first_projected_gradient_step_is_bit_identical_on_exact_inputs
     U = np.uint32 if T == np.float32 else np.uint64
     assert np.array_equal(got.view(U), ref.view(U)), float(np.max(np.abs(got - ref)))
     assert not np.array_equal(got, start)
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_alspgrad_exact_gradient_mode(built, T):
+    """nmfx_opts.pg_refresh = 1 (ALSPGrad(gradient="exact")): G = Gram*Z - B by a full product at the top of EVERY inner iteration, the
+    reference's own formulation (src/alspgrad.jl:124-127, 280-283), against the oracle -- and against the running form with a refresh
+    period (same iterates up to rounding; in Float64 the same counters)."""
+    p, n, k = 512, 640, 12
+    X, W0, H0 = planted(p, n, k, T, seed=77)
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    ro = orc.solve("alspgrad", X, Wc, Hc, orc.Opts(maxiter=6, tol=1e-30, track_objective=True))
+    out = {}
+    for g in ("exact", 16):
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        r = nmfx.solve(nmfx.ALSPGrad(T, maxiter=6, tol=1e-30, gradient=g), X, W, H, track_objective=True)
+        out[g] = (r, W, H)
+        assert r.niters == 6 and np.all(W >= 0) and np.all(H >= 0)
+    r = out["exact"][0]
+    ci, cb = ro.counters["inner"], ro.counters["backtracks"]
+    if T == np.float64:
+        for g in ("exact", 16):
+            assert out[g][0].info["inner_iters"] == ci and out[g][0].info["backtracks"] == cb
+            assert rel_trace_err(out[g][0].trace, ro.trace) < 1e-7
+    else:
+        assert abs(r.info["inner_iters"] - ci) <= max(2, 0.02 * ci) and abs(r.info["backtracks"] - cb) <= max(4, 0.02 * cb)
+        assert rel_trace_err(r.trace, ro.trace) < TOL[T]

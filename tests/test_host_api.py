@@ -122,3 +122,13 @@ def test_greedy_division_identity():
     q1 = g / den
     q2 = (g.astype(np.float64) * (1.0 / den.astype(np.float64))).astype(np.float32)
     assert np.array_equal(q1.view(np.uint32), q2.view(np.uint32))
+
+
+def test_alspgrad_gradient_option_validation():
+    with pytest.raises(ValueError):
+        nmfx.ALSPGrad(np.float32, gradient="fast")
+    with pytest.raises(ValueError):
+        nmfx.ALSPGrad(np.float32, gradient=0)
+    assert nmfx.ALSPGrad(np.float32, gradient="exact")._opts()["pg_refresh"] == 1
+    assert nmfx.ALSPGrad(np.float32, gradient=32)._opts()["pg_refresh"] == 32
+    assert nmfx.ALSPGrad(np.float32)._opts()["pg_refresh"] == 0

@@ -78,7 +78,8 @@ def parse():
     ap.add_argument("--watchdog-s", type=float, default=600.0,
                     help="multi-GPU: a stage that takes longer than this prints a JSON line with status = comm_timeout and exits (a mismatched "
                          "collective would otherwise hang until the driver's timeout and leave no line at all)")
-    return ap.parse_args()
+    # (ranks started by self_launch() find the original command line in NMFX_BENCH_ARGV)
+    return ap.parse_args(json.loads(os.environ["NMFX_BENCH_ARGV"]) if ("NMFX_BENCH_ARGV" in os.environ and len(sys.argv) == 1) else None)
 
 
 class Watchdog:
@@ -511,8 +512,11 @@ def self_launch(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if env.get("NMFX_BENCH_BACKEND") in ("gloo-p2p", "gloo-sim") and "NMFX_BENCH_DEVICE" not in env and torch.cuda.device_count() < n:
         env["NMFX_BENCH_DEVICE"] = "0"
+    # the caller's arguments travel in the environment: torch.distributed.run's own parser trips over script options that are
+    # prefixes of its own (`--n` "could match --nnodes, --nproc-per-node, ...") even behind the script name
+    env["NMFX_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__)]
     return subprocess.call(cmd, env=env)
 
 

@@ -105,8 +105,12 @@ typedef struct {
      * top of EVERY inner iteration (src/alspgrad.jl:124-127, 280-283).  1 = exactly that ("exact").  n > 1: the running form
      * G += Gram*D(accepted step) -- Gram*D is what the accepted trial step just computed (alspgrad.jl:150-152) -- with a full product
      * every n-th inner iteration to bound the rounding drift of the running sum (one product less per inner iteration).
-     * 0 = the library default: 64 for Float64 (counters and iterates equal to the exact form's in every test), 1 (exact) for
-     * Float32 (the running form moves Float32 line-search decisions). */
+     * 0 = the library default: 64 for Float64, 16 for Float32.  Measured against the CPU oracle on six seeded problems per element
+     * type (scripts/alspgrad_gradient_modes.py, profiles/r05_alspgrad_gradient_modes.jsonl): the inner-iteration and back-tracking
+     * counters are the oracle's in every mode, and the exact form is NOT closer to the oracle's objective than the running form
+     * (Float32: max relative deviation 2.1e-4 exact, 1.4e-4 period 16, 2.1e-4 period 64; Float64: <= 8.4e-13 all) -- the Float32
+     * deviation is the products' summation order, not the gradient's form -- while it costs 11 % (Float32, 8192^2, k = 256) to 25 %
+     * (the Float64 C5 shard) more time per outer iteration. */
     int32_t pg_refresh;
     /* ProjectedALS: how H = (W'W + lambda I) \ W'X is solved after potrf! (src/utils.jl:63-70).  NMFX_HSOLVE_AUTO (0): the library
      * default; NMFX_HSOLVE_PRODUCT (1): Uinv (Uinv' B), two products with the inverted factor; NMFX_HSOLVE_POTRS (2): forward and back
@@ -241,6 +245,14 @@ int nmfx_spa_init(nmfx_ctx *ctx, int warm_sweeps, int64_t *anchors_out, int64_t 
  *       c's reduce-scatter on a second stream under chunk c+1's X_g H_g' launch, its all-gather under the next iteration's
  *       W'X split-K part of chunk c+1.  MultUpdate-MSE only (other algorithms run as ROW_SHARDED); same results bit for bit
  *       up to the split-K grouping of the two big products.
+ *   NMFX_COMM_REPLICAS: NOT a sharding of one solve but the fan-out of solve_replicates! (src/interf.jl:85-101) over the ranks.
+ *       Every context holds the FULL X (n_local = n) and full W, H; nmfx_iterate / nmfx_solve run as on one GPU (no collective).
+ *       nmfx_solve_replicates becomes collective: rank g runs the replicates r = g + 1, g + 1 + nranks, ... (replicate 1 -- the
+ *       caller's W, H -- on rank 0; the others from randinit(seed + r - 1), the same Philox streams as the sequential loop), the
+ *       objective values of all replicates are all-gathered, every rank replays the reference's scan (`if minobjv >
+ *       tmp.objvalue`, in replicate order: ties and NaNs decide exactly as they do sequentially), and the winner's W, H are broadcast
+ *       from the rank that computed them: every rank returns the same *out, *best_replicate and factors, bit-identical to the
+ *       one-GPU call with the same seed (tests/test_gpu_localcomm.py).  Set the mode right after nmfx_comm_init*.
  * Two transports behind the same code path:
  *   one process per GPU (production, bench.py): RCCL over xGMI.  Rank 0 calls nmfx_comm_get_unique_id, the host
  *       broadcasts the 128 bytes by any means, every rank calls nmfx_comm_init.  nranks == 1 is valid.
@@ -250,7 +262,7 @@ int nmfx_spa_init(nmfx_ctx *ctx, int warm_sweeps, int64_t *anchors_out, int64_t 
  *       hand-written kernels reading the peers' buffers, ordered by hipEvents; reductions add in rank order.
  * nmfx_comm_init* must precede nmfx_set_X when p is not a multiple of lcm(256, 128*nranks) (the row padding changes). */
 #define NMFX_UNIQUE_ID_BYTES 128
-enum { NMFX_COMM_ROW_SHARDED = 0, NMFX_COMM_REPLICATED_W = 1, NMFX_COMM_PIPELINED = 2 };
+enum { NMFX_COMM_ROW_SHARDED = 0, NMFX_COMM_REPLICATED_W = 1, NMFX_COMM_PIPELINED = 2, NMFX_COMM_REPLICAS = 3 };
 typedef struct nmfx_local_group nmfx_local_group;
 int nmfx_comm_get_unique_id(void *out_bytes /* NMFX_UNIQUE_ID_BYTES */);
 int nmfx_comm_init(nmfx_ctx *ctx, const void *unique_id_bytes, int rank, int nranks);

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -61,6 +62,8 @@ struct Comm {
     virtual void reduce_scatter(const void *send, void *recv, size_t recvcount, int ct, hipStream_t s) = 0;
     // recv[q*sendcount + i] = send_q[i]
     virtual void all_gather(const void *send, void *recv, size_t sendcount, int ct, hipStream_t s) = 0;
+    // buf of rank `root` -> buf of every rank, bit for bit (the winner of solve_replicates! travelling to every GPU)
+    virtual void broadcast(void *buf, size_t bytes, int root, hipStream_t s) = 0;
     virtual void group_start() {}
     virtual void group_end() {}
 };
@@ -99,6 +102,9 @@ struct RcclComm : Comm {
     void all_gather(const void *send, void *recv, size_t sendcount, int ct, hipStream_t s) override {
         NMFX_RCCL(ncclAllGather(send, recv, sendcount, dt(ct), comm, s));
     }
+    void broadcast(void *buf, size_t bytes, int root, hipStream_t s) override {
+        NMFX_RCCL(ncclBroadcast(buf, buf, bytes, ncclInt8, root, comm, s));
+    }
     void group_start() override { NMFX_RCCL(ncclGroupStart()); }
     void group_end() override { NMFX_RCCL(ncclGroupEnd()); }
 };
@@ -107,6 +113,15 @@ struct RcclComm : Comm {
 // "Rank r of n" with NO peers: every collective moves the bytes it would receive device-locally (reduce-scatter: own chunk;
 // all-gather: own chunk into every slot; all-reduce: nothing).  Numerically meaningless -- it exists so that the per-rank
 // COMPUTE of the sharded path at an n-rank shard shape can be timed on a 1-GPU box (bench.py --sim-ranks).
+// dst[q * nvec + i] = src[i] for every q != skip: the all-gather stand-in as ONE launch (a collective is one launch; the 7 separate
+// hipMemcpyAsync calls this used to be cost 19 us of launch latency at the 8-rank shard shape for 14 MB of copies)
+__global__ __launch_bounds__(256) void sim_replicate_kernel(uint4 *dst, const uint4 *src, size_t nvec, int n, int skip) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nvec * (size_t)n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t q = e / nvec, i = e % nvec;
+        if ((int)q != skip) dst[e] = src[i];
+    }
+}
+
 struct SimComm : Comm {
     SimComm(int rank_, int nranks_) { rank = rank_; nranks = nranks_; }
     const char *transport() const override { return "sim"; }
@@ -117,11 +132,21 @@ struct SimComm : Comm {
     }
     void all_gather(const void *send, void *recv, size_t sendcount, int ct, hipStream_t s) override {
         const size_t b = sendcount * ct_size(ct);
+        const char *own = reinterpret_cast<const char *>(send);
+        const char *r0 = reinterpret_cast<const char *>(recv);
+        if (b % 16 == 0 && ((uintptr_t)send % 16) == 0 && ((uintptr_t)recv % 16) == 0) {
+            const int skip = (own >= r0 && own < r0 + b * (size_t)nranks && (size_t)(own - r0) % b == 0) ? (int)((size_t)(own - r0) / b) : -1;   // in-place: the own chunk is already there
+            const size_t nvec = b / 16, items = nvec * (size_t)nranks;
+            const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((items + 255) / 256, 2048));
+            hipLaunchKernelGGL(sim_replicate_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<uint4 *>(recv), reinterpret_cast<const uint4 *>(send), nvec, nranks, skip);
+            return;
+        }
         for (int q = 0; q < nranks; ++q) {
             char *dst = reinterpret_cast<char *>(recv) + (size_t)q * b;
             if (dst != send) (void)hipMemcpyAsync(dst, send, b, hipMemcpyDeviceToDevice, s);   // in-place all-gather: the own chunk is already there
         }
     }
+    void broadcast(void *, size_t, int, hipStream_t) override {}
 };
 
 // "rank r of n" with NO transport of its own: the base of a PeerComm that must serve every collective from its windows
@@ -133,6 +158,7 @@ struct NoComm : Comm {
     void all_reduce(void *, size_t, int, bool, hipStream_t) override { fail(); }
     void reduce_scatter(const void *, void *, size_t, int, hipStream_t) override { fail(); }
     void all_gather(const void *, void *, size_t, int, hipStream_t) override { fail(); }
+    void broadcast(void *, size_t, int, hipStream_t) override { fail(); }
 };
 
 // --------------------------------------------------------------------------------------------------- in-process group
@@ -317,6 +343,12 @@ struct LocalComm : Comm {
                                reinterpret_cast<unsigned char *>(recv), pp, nranks, bytes);
         }
         ck(hipGetLastError(), "local_gather_kernel");
+        exchange_end(s);
+    }
+    void broadcast(void *buf, size_t bytes, int root, hipStream_t s) override {
+        ck(hipSetDevice(dev), "hipSetDevice");
+        const PeerPtrs pp = exchange_begin(buf, s);
+        if (rank != root) ck(hipMemcpyAsync(buf, pp.p[root], bytes, hipMemcpyDefault, s), "hipMemcpyAsync (broadcast)");
         exchange_end(s);
     }
 };

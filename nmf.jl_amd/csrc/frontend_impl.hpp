@@ -267,6 +267,63 @@ template <typename T>
 void Solver<T>::solve_replicates(int alg, const nmfx_opts &o, int replicates, uint64_t seed, bool zeroh, int64_t h_col_offset,
                                  void *W_host, void *H_host, nmfx_result *out, int *best) {
     if (replicates < 1) throw StatusError{NMFX_ERR_BAD_ARG, "The value of replicates must be positive."};
+    if (replicas_mode()) {
+        // ---- the replicates dealt out over the ranks (NMFX_COMM_REPLICAS, include/nmfx.h) ------------------------------------
+        const int G = nranks, per = (replicates + G - 1) / G;
+        std::vector<nmfx_result> mine((size_t)per), all((size_t)per * G);
+        for (auto &m : mine) { std::memset(&m, 0, sizeof m); m.objvalue = std::numeric_limits<double>::infinity(); m.niters = -1; }   // niters = -1: no such replicate
+        Wbest.ensure(W[0].count);
+        Hbest.ensure(H[0].count);
+        auto park = [&] {
+            HIP_TRY(hipMemcpyAsync(Wbest.p, W[wcur].p, W[0].count * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(Hbest.p, H[hcur].p, H[0].count * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        };
+        // local candidate = the replicate of this rank the global scan could pick: the first one that is strictly smaller than every
+        // earlier one of this rank (a NaN objective never wins, except replicate 1, which then wins everything -- on rank 0 it is first)
+        double local_best = std::numeric_limits<double>::quiet_NaN();
+        bool have_local = false;
+        for (int i = 0; i < per; ++i) {
+            const int r = rank + 1 + i * G;
+            if (r > replicates) break;
+            if (r == 1) set_factors(W_host, H_host);
+            else randinit(seed + (uint64_t)(r - 1), /*normalize=*/true, zeroh, h_col_offset);
+            nmfx_result res;
+            iterate(alg, o, &res, nullptr);
+            mine[(size_t)i] = res;
+            bool take;
+            if (!have_local) take = true;
+            else if (local_best != local_best) take = rank != 0 && res.objvalue == res.objvalue;   // (rank 0's NaN can only be replicate 1's: it keeps everything)
+            else take = local_best > res.objvalue;
+            if (take) { local_best = res.objvalue; have_local = true; park(); }
+        }
+        // every replicate's record to every rank
+        const size_t rec = sizeof(nmfx_result), chunk = rec * (size_t)per;
+        rep_buf.ensure(chunk * (size_t)(G + 1));
+        unsigned char *send = rep_buf.p, *recv = rep_buf.p + chunk;
+        HIP_TRY(hipMemcpyAsync(send, mine.data(), chunk, hipMemcpyHostToDevice, stream));
+        comm->all_gather(send, recv, chunk, CT_BYTE, stream);
+        HIP_TRY(hipMemcpyAsync(all.data(), recv, chunk * (size_t)G, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        // the reference's scan over r = 1 .. R (src/interf.jl:91-98)
+        auto rec_of = [&](int r) -> const nmfx_result & { return all[(size_t)((r - 1) % G) * per + (size_t)((r - 1) / G)]; };
+        int best_r = 1;
+        nmfx_result best_res = rec_of(1);
+        for (int r = 2; r <= replicates; ++r)
+            if (best_res.objvalue > rec_of(r).objvalue) { best_res = rec_of(r); best_r = r; }
+        const int owner = (best_r - 1) % G;
+        if (rank == owner) {
+            HIP_TRY(hipMemcpyAsync(W[wcur].p, Wbest.p, W[0].count * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(H[hcur].p, Hbest.p, H[0].count * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        }
+        comm->broadcast(W[wcur].p, W[0].count * sizeof(T), owner, stream);
+        if (o.update_H || best_r != 1) comm->broadcast(H[hcur].p, H[0].count * sizeof(T), owner, stream);
+        have_F = true;
+        get_factors(W_host, (o.update_H || best_r != 1) ? H_host : nullptr);
+        if (comm) comm->health();
+        *out = best_res;
+        if (best) *best = best_r;
+        return;
+    }
     set_factors(W_host, H_host);
     nmfx_result res;
     iterate(alg, o, &res, nullptr);

@@ -79,6 +79,10 @@ template <typename T> struct GemmArgs {
     int tail_main = 0;      // > 0: the grid is `tail_main` blocks SHORT of tiles * splits; the missing (tile, split) items -- the
                             // last ones -- are dealt out as tail pieces instead (a grid that must leave some CUs free)
     int prio = 0;           // wave priority pattern of the launch (see the kernel): 0 none
+    // B operand BLOCKED along the contraction (KCONTIG): contraction rows [q * b_blk_k, (q + 1) * b_blk_k) live in a matrix of their own
+    // with leading dimension ldb = b_blk_k, block q starting b_blk_stride elements after block q - 1 (the row-sharded W as the
+    // all-gather delivers it: rank q's rows x k, contiguous).  A block's k-range must not straddle blocks (b_blk_k % kchunk == 0).
+    int64_t b_blk_k = 0, b_blk_stride = 0;
 };
 
 // what an epilogue may need to know about the block / wave it runs in
@@ -452,6 +456,7 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
         int64_t lda = g.lda, ldb = g.ldb, ra0 = r0, cb0 = c0;
         if (r0 >= g.r_split) { Ab = g.A2; lda = g.lda2; ra0 = r0 - g.r_split; }
         if (c0 >= g.c_split) { Bb = g.B2; ldb = g.ldb2; cb0 = c0 - g.c_split; }
+        else if (g.b_blk_k > 0) { const int64_t q = kbeg / g.b_blk_k; Bb += q * (g.b_blk_stride - g.b_blk_k); }
         tctx.tr = tr; tctx.tc = tc; tctx.r0 = r0; tctx.c0 = c0;
         tctx.rw0 = r0 + wr * WTR; tctx.cw0 = c0 + wc * WTC;
 

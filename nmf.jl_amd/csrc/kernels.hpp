@@ -529,18 +529,25 @@ __global__ __launch_bounds__(256) void peer_sum3_kernel(T *num, const unsigned c
 // per-chunk partials added in chunk order and, unless the caller still has an objective evaluation to enqueue in front of it
 // (do_check = 0), the stop rule itself.  Two launches instead of col_stats + finalize + rows_to_piece + gathered_to_full + check.
 // (One launch with a last-block ticket was measured: 4096 device-scope atomics on one address cost 130 us on this chip.)
+// Generalised for the blocked residency of W (solver_impl.hpp: multmse_w_rows_fused): Wfull == nullptr takes the sums only (no
+// unpacking); the old factor's row block g starts at Wold + g * old_blk with leading dimension ldo (standard layout: old_blk = Pc,
+// ldo = P; blocked: the chunk stride in elements, ldo = Pc); g_first = the first row block of the grid (own-rows statistics: the
+// rank's block only, grid.x = cpp) -- the per-chunk arithmetic, hence every partial's bits, is the same in all forms.
 template <typename T>
 __global__ __launch_bounds__(256) void gather_stats_kernel(T *Wfull, const T *Wold, const unsigned char *recv, size_t chunk_bytes, int64_t P,
-                                                           int64_t Pc, int cpp, int K, double *partial, const int *done) {
+                                                           int64_t Pc, int cpp, int K, double *partial, const int *done, int64_t old_blk = -1,
+                                                           int64_t ldo = -1, int g_first = 0) {
     NMFX_DONE_GUARD(done);
     __shared__ double sm[8];
     const int j = blockIdx.y, chunk = blockIdx.x;
-    const int g = chunk / cpp, ci = chunk % cpp;
+    const int g = g_first + chunk / cpp, ci = chunk % cpp;
     const int64_t per = (Pc + cpp - 1) / cpp;
     const int64_t beg = ci * per, end = (beg + per < Pc) ? beg + per : Pc;
+    if (old_blk < 0) { old_blk = Pc; ldo = P; }
     const T *piece = reinterpret_cast<const T *>(recv + (size_t)g * chunk_bytes) + (int64_t)j * Pc;
-    const T *oldc = Wold + (int64_t)g * Pc + (int64_t)j * P;
+    const T *oldc = Wold + (int64_t)g * old_blk + (int64_t)j * ldo;
     T *newc = Wfull + (int64_t)g * Pc + (int64_t)j * P;
+    const bool copy = Wfull != nullptr;
     double dev = 0.0, sum = 0.0;
     // 16-byte accesses (Pc and P are multiples of 128 rows, the chunk bounds multiples of 4 whenever Pc / cpp is): a thread's
     // VEC consecutive rows per trip
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(T *Wfull, const T *Wo
         for (int64_t il = beg + (int64_t)threadIdx.x * VEC; il < end; il += (int64_t)blockDim.x * VEC) {
             const vec_t a = *reinterpret_cast<const vec_t *>(piece + il);
             const vec_t b = *reinterpret_cast<const vec_t *>(oldc + il);
-            *reinterpret_cast<vec_t *>(newc + il) = a;
+            if (copy) *reinterpret_cast<vec_t *>(newc + il) = a;
 #pragma unroll
             for (int u = 0; u < VEC; ++u) {
                 const T d = a[u] - b[u], s = a[u] + b[u];
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(T *Wfull, const T *Wo
         for (int64_t il = beg + threadIdx.x; il < end; il += blockDim.x) {
             const T a = piece[il];
             const T b = oldc[il];
-            newc[il] = a;
+            if (copy) newc[il] = a;
             const T d = a - b, s = a + b;
             dev += (double)(T)(d * d);
             sum += (double)(T)(s * s);
@@ -580,12 +587,18 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(T *Wfull, const T *Wo
     }
 }
 template <typename T>
+// grp > 0: the partials arrive in groups of grp chunks, group q at partial + q * grp_stride doubles (the ranks' statistics tails
+// behind their row blocks in the blocked W buffer); summed in the same chunk order either way.
 __global__ __launch_bounds__(256) void stats_check_kernel(const double *partial, int nchunks, int K, double *wstat, Ctrl *ctrl, const double *hstat,
-                                                          int k, T tol, long long t, int do_check, const int *done) {
+                                                          int k, T tol, long long t, int do_check, const int *done, int grp = 0, int64_t grp_stride = 0) {
     NMFX_DONE_GUARD(done);
     for (int e = threadIdx.x; e < 2 * K; e += blockDim.x) {
         double s = 0.0;
-        for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * 2 * K + e];
+        if (grp > 0) {
+            for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)(c / grp) * grp_stride + (int64_t)(c % grp) * 2 * K + e];
+        } else {
+            for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * 2 * K + e];
+        }
         wstat[e] = s;
     }
     __syncthreads();

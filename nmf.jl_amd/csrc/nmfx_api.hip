@@ -193,7 +193,7 @@ int nmfx_comm_p2p_stats(nmfx_ctx *ctx, int64_t *served_by_windows, int64_t *serv
 }
 
 int nmfx_comm_set_mode(nmfx_ctx *ctx, int mode) {
-    if (!ctx || (mode != NMFX_COMM_ROW_SHARDED && mode != NMFX_COMM_REPLICATED_W && mode != NMFX_COMM_PIPELINED)) return NMFX_ERR_BAD_ARG;
+    if (!ctx || mode < NMFX_COMM_ROW_SHARDED || mode > NMFX_COMM_REPLICAS) return NMFX_ERR_BAD_ARG;
     return guarded(ctx, [&] { ctx->impl->comm_set_mode(mode); });
 }
 

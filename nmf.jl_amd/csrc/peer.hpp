@@ -458,6 +458,29 @@ struct PeerComm : Comm {
         enqueue(Op{2, recv, send, sendcount, ct, false, 0}, sendcount * ct_size(ct), s);
     }
 
+    // broadcast: the root pushes slot-sized pieces into slot[root] of every window, everybody signals and waits (one sequence number
+    // per piece, like every collective here), the others copy the piece out
+    void broadcast(void *buf, size_t bytes, int root, hipStream_t s) override {
+        if (!attached || !on_home(s)) { to_base_begin(); base->broadcast(buf, bytes, root, s); return; }
+        if (!ops.empty()) flush(group_stream ? group_stream : s);
+        ck(hipSetDevice(dev), "hipSetDevice");
+        const size_t per = slot_bytes / 256 * 256;
+        for (size_t o = 0; o < bytes; o += per) {
+            const size_t b = (bytes - o < per) ? (bytes - o) : per;
+            const unsigned sq = ++seq;
+            const size_t reg = region(sq);
+            unsigned char *piece = reinterpret_cast<unsigned char *>(buf) + o;
+            if (rank == root)
+                hipLaunchKernelGGL(peer_push_kernel, dim3(grid_for(b / 16 + 1), nranks), dim3(256), 0, s, win, reg + (size_t)root * slot_bytes, piece, b, (size_t)0, rank);
+            hipLaunchKernelGGL(peer_signal_kernel, dim3(1), dim3(64), 0, s, win, rank, nranks, sq);
+            if (!sim) hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, win, rank, nranks, sq, timeout_ticks);
+            if (rank != root)
+                hipLaunchKernelGGL(peer_gather_kernel, dim3(grid_for(b / 16 + 1), 1), dim3(256), 0, s, piece, mine, reg + (size_t)root * slot_bytes, slot_bytes, b);
+            ck(hipGetLastError(), "peer broadcast launch");
+            ++n_peer;
+        }
+    }
+
     // ---- producer-side push (the GEMM-fused exchange) --------------------------------------------------------------------
     // Inside a group: reserve `bytes` of this group's slot space for data a producer kernel stores ITSELF -- its epilogue writes the
     // piece for rank q to  direct_dst(q, off)  (peer memory, write-through stores) -- and the consumer, launched behind group_end()

@@ -145,6 +145,7 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = std::getenv("NMFX_K_GRANULE")) k_granule = (std::atoi(e) == 128) ? 128 : 64;
         if (const char *e = std::getenv("NMFX_POTRS")) { potrs_enabled = std::atoi(e) != 0; potrs_iter = std::atoi(e) == 1; }
         if (const char *e = std::getenv("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
+        if (const char *e = std::getenv("NMFX_W_BLOCKED")) blk_enabled = std::atoi(e) != 0;
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
@@ -331,7 +332,16 @@ template <typename T> class Solver : public SolverBase {
     // 0: row-sharded W side (reduce-scatter / all-gather, the default whenever the shapes allow it); 1: the replicated W
     // update behind one packed all-reduce (round-1 formulation, kept for comparison and as the fallback); 2: row-sharded with
     // the exchange pipelined against the big products (MultUpdate-MSE; the other algorithms run as in mode 0)
-    void comm_set_mode(int mode) override { comm_mode = mode; }
+    void comm_set_mode(int mode) override {
+        comm_mode = mode;
+        // replicas: every solve is a one-GPU solve and must give the one-GPU bits -- undo the row padding attach() chose for a
+        // row-sharded W side (split-K factors follow P)
+        if (mode == NMFX_COMM_REPLICAS && P != round_up(p, 256)) {
+            if (have_X) throw StatusError{NMFX_ERR_STATE, "nmfx_comm_set_mode(NMFX_COMM_REPLICAS) must precede nmfx_set_X when p is not a multiple of lcm(256, 128*nranks)"};
+            HIP_TRY(hipSetDevice(device));
+            layout(256);
+        }
+    }
     void attach(Comm *c) {
         delete comm;
         comm = c;
@@ -517,7 +527,10 @@ template <typename T> class Solver : public SolverBase {
     // exchange -- also for nranks == 1, so that every collective of the multi-GPU step executes on a 1-GPU box, under RCCL, as
     // an identity (tests/test_gpu_comm.py).
     bool force_sharded = false;
-    bool sharded() const { return comm != nullptr && (nranks > 1 || force_sharded); }
+    // (NMFX_COMM_REPLICAS: the communicator only carries solve_replicates' fan-out; every solve is a plain one-GPU solve)
+    bool sharded() const { return comm != nullptr && comm_mode != NMFX_COMM_REPLICAS && (nranks > 1 || force_sharded); }
+    bool replicas_mode() const { return comm != nullptr && comm_mode == NMFX_COMM_REPLICAS && nranks > 1; }
+    DevBuf<unsigned char> rep_buf;   // solve_replicates over the ranks: the replicates' result records on their way through the all-gather
     int comm_mode = 0;
     // row-sharded W side: this rank updates rows [row0, row0 + Pc) of W
     int64_t Pc = 0, row0 = 0;
@@ -660,6 +673,7 @@ template <typename T> class Solver : public SolverBase {
         int tail_main = 0, tail_per = 0;   // short grid: the last tail_main (tile, split) items as pieces of tail_per k-tiles
         const T *a_aux = nullptr, *b_aux = nullptr;   // operand computed on the fly (projected-gradient trial step)
         const double *alpha_ptr = nullptr;
+        int64_t b_blk_k = 0, b_blk_stride = 0;        // B operand blocked along the contraction (GemmArgs)
     };
     template <int LA, int LB, int AUX = 0, typename Epi>
     void gemm(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim,
@@ -672,6 +686,7 @@ template <typename T> class Solver : public SolverBase {
         g.tail_tiles = seg.tail_tiles; g.tail_nkt = (int)(Kdim / BK);
         g.tail_main = seg.tail_main; g.tail_per = seg.tail_per;
         g.a_aux = seg.a_aux; g.b_aux = seg.b_aux; g.alpha_ptr = seg.alpha_ptr;
+        g.b_blk_k = seg.b_blk_k; g.b_blk_stride = seg.b_blk_stride;
         g.splits = splits;
         g.kchunk = (int)(Kdim / splits);
         g.c_fastest = c_fastest ? 1 : 0;
@@ -950,6 +965,11 @@ template <typename T> class Solver : public SolverBase {
             }
             reduce_pieces("reduce_WtX_pieces", reg + (int64_t)(s_h - 1) * h_stride + c0 * K, lines * 128 * K, slabs.p + gram_slab_off, 1, lines * 128 * K,
                           shg.pieces, done);
+        } else if (wt_blocked != nullptr) {
+            // W as the all-gather left it: rank q's Pc rows x K at wt_blocked + q * wt_blk_stride (ld Pc); split s contracts over rows of ONE block
+            Seg sg;
+            sg.b_blk_k = Pc; sg.b_blk_stride = wt_blk_stride;
+            gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, wt_blocked, Pc, K, P, s_h, true, e, done, (double)(P * N + P * K) * sizeof(T), sg);
         } else
         gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                (double)(P * N + P * K) * sizeof(T));
@@ -964,6 +984,26 @@ template <typename T> class Solver : public SolverBase {
         } else if (red) {
             reduce_slabs_from("reduce_WtX", numH_p, reg, h_stride, h_nslab, done);
         }
+    }
+    const T *wt_blocked = nullptr;   // set around wt_times: W in the blocked layout of the all-gather (plain branch only)
+    int64_t wt_blk_stride = 0;
+    // Blocked residency of W (row-sharded fused MultUpdate-MSE step, transports whose all-gather lands in local memory): between
+    // iterations W lives as the all-gather delivers it -- rank q's rows at Wblk[wb] + q * blk_chunk, followed by the rank's
+    // stop_condition partials -- and is only unpacked into the standard layout when something else needs it (w_sync()).
+    DevBuf<unsigned char> Wblk[2];
+    int wb = 0, blk_cpp = 1;
+    size_t blk_chunk = 0;
+    bool w_res_blocked = false, w_std_stale = false;
+    bool blk_enabled = true;         // NMFX_W_BLOCKED=0: unpack after every all-gather (A/B)
+    bool blocked_residency_ok() const {
+        return blk_enabled && rs_fused() && peer() == nullptr && s_h % nranks == 0 && Pc % (P / s_h) == 0 && !short_grid;
+    }
+    void w_sync(const int *done) {   // W[wcur] <- the blocked copy
+        if (!w_res_blocked || !w_std_stale) return;
+        hipLaunchKernelGGL(gathered_to_full_kernel<T>, dim3(flat_grid(P * K)), dim3(256), 0, stream, W[wcur].p, Wblk[wb].p, nranks, blk_chunk, P, K, Pc,
+                           (int64_t)0, 0, (double *)nullptr, 0, done);
+        HIP_TRY(hipGetLastError());
+        w_std_stale = false;
     }
     // after wt_times(..., with_gram=true): where the numerator / the Gram operand live
     bool h_in_slabs = false, w_in_slabs = false;

@@ -146,7 +146,10 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
         // behind the W update, multmse_w_rows_fused) instead of being recomputed over all P rows on every rank inside this launch
         const bool have_gram = fusedrs && gramw_sharded_valid;
         h_reduce_pair = fusedrs;
+        if (w_res_blocked && have_gram) { wt_blocked = reinterpret_cast<const T *>(Wblk[wb].p); wt_blk_stride = (int64_t)(blk_chunk / sizeof(T)); }
+        else w_sync(done);
         wt_times(Wp, X.p, !have_gram, done, /*keep_slabs=*/true);
+        wt_blocked = nullptr;
         h_reduce_pair = false;
         if constexpr (sizeof(T) == 4) {
             if (ht_active) {   // the new H also transposed, for the X*H' product below
@@ -225,6 +228,57 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
         if (o.update_H) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
         comm->group_end();
     });
+    const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(64 / nranks, Pc / 1024));   // statistics chunks per row block
+    const bool fuse_check = o.track_objective == 0;
+    if (blocked_residency_ok()) {
+        // ---- W stays in the all-gather's layout between iterations (solver.hpp: Wblk): no unpack launch ----------------------------
+        blk_cpp = cpp;
+        blk_chunk = ((size_t)Pc * K * sizeof(T) + (size_t)cpp * 2 * K * sizeof(double) + 255) / 256 * 256;
+        for (auto &b : Wblk) b.ensure(blk_chunk * (size_t)nranks);
+        const int64_t blk_el = (int64_t)(blk_chunk / sizeof(T));
+        const T *Wo_own = w_res_blocked ? reinterpret_cast<const T *>(Wblk[wb].p) + (int64_t)rank * blk_el : Wo + row0;
+        const int64_t ldo = w_res_blocked ? Pc : P;
+        unsigned char *mine_b = Wblk[wb ^ 1].p + (size_t)rank * blk_chunk;
+        T *mine = reinterpret_cast<T *>(mine_b);
+        double *tail = reinterpret_cast<double *>(mine_b + (size_t)Pc * K * sizeof(T));
+        EpiMultUpdateRows<T> e{rs_out.p, Pc, Wo_own, ldo, mine, (T)o.lambda_w, (T)o.delta};               // multupd.jl:110-114
+        gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo_own, ldo, Pc, K, 1, false, e, done, 3.0 * Pc * K * sizeof(T));
+        if (o.update_H) {
+            const int sg = pick_splits((int)((K / 64) * (K / 64)), Pc);
+            EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
+            force_quarter_tiles = true;
+            gemm<KCONTIG, KCONTIG>("gemm_WtW_rows", mine, Pc, K, mine, Pc, K, Pc, sg, true, eg, done, (double)(Pc * K) * sizeof(T));
+            force_quarter_tiles = false;
+            reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, sg, done);
+        }
+        // stop_condition's sums over the rank's OWN rows (the chunking and arithmetic of gather_stats_kernel), into the tail of the chunk
+        timed("stats_W_rows", 0.0, 2.0 * Pc * K * sizeof(T), [&] {
+            hipLaunchKernelGGL(gather_stats_kernel<T>, dim3((unsigned)cpp, (unsigned)K), dim3(256), 0, stream, (T *)nullptr, Wo_own - (int64_t)rank * (w_res_blocked ? blk_el : Pc),
+                               Wblk[wb ^ 1].p, blk_chunk, P, Pc, cpp, (int)K, tail, done, w_res_blocked ? blk_el : Pc, ldo, rank);
+            HIP_TRY(hipGetLastError());
+        });
+        timed("comm_all_gather_W", 0.0, (double)(P * K) * sizeof(T), [&] {
+            comm->group_start();
+            comm->all_gather(mine_b, Wblk[wb ^ 1].p, blk_chunk, CT_BYTE, stream);
+            if (o.update_H) comm->all_reduce(gramW_p, (size_t)K * K, CT, false, stream);
+            comm->group_end();
+        });
+        gramw_sharded_valid = o.update_H != 0;
+        timed("stats_check", 0.0, 0.0, [&] {
+            hipLaunchKernelGGL(stats_check_kernel<T>, dim3(1), dim3(256), 0, stream, reinterpret_cast<const double *>(Wblk[wb ^ 1].p + (size_t)Pc * K * sizeof(T)), nranks * cpp, (int)K,
+                               wstat.p, ctrl, o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done, cpp,
+                               (int64_t)(blk_chunk / sizeof(double)));
+            HIP_TRY(hipGetLastError());
+        });
+        check_fused = fuse_check;
+        wb ^= 1;
+        w_res_blocked = true;
+        w_std_stale = true;
+        wcur ^= 1;
+        return;
+    }
+    w_sync(done);
+    w_res_blocked = false;
     const size_t chunk = (size_t)Pc * K * sizeof(T);
     T *mine = reinterpret_cast<T *>(ag_recv.p + (size_t)rank * chunk);
     EpiMultUpdateRows<T> e{rs_out.p, Pc, Wo + row0, P, mine, (T)o.lambda_w, (T)o.delta};                  // multupd.jl:110-114
@@ -246,8 +300,6 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
         comm->group_end();
     });
     gramw_sharded_valid = o.update_H != 0;
-    const bool fuse_check = o.track_objective == 0;
-    const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(64 / nranks, Pc / 1024));   // chunks per piece
     timed("gather_W_stats", 0.0, 3.0 * P * K * sizeof(T), [&] {
         hipLaunchKernelGGL(gather_stats_kernel<T>, dim3((unsigned)(nranks * cpp), (unsigned)K), dim3(256), 0, stream, Wn, Wo, ag_recv.p, chunk, P, Pc, cpp, (int)K,
                            stat_part.p, done);
@@ -490,6 +542,8 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     pipe_pending = false;
     check_fused = false;
     gramw_sharded_valid = false;
+    w_res_blocked = w_std_stale = false;
+    wb = 0;
     smallk_grams_valid = false;
     div_sw_valid = div_sh_valid = false;
     rsvd_ready = 0;   // the iteration overwrites the buffers a pending rsvd keeps its Q / B in
@@ -546,7 +600,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         if (pipe_pending && (track || poll)) pipe_flush(o);
         // common.jl:79 -- enqueued BEFORE the stop check: the check raises the `done` flag that turns every later kernel
         // into a no-op, and the objective of the converging iteration itself must still be evaluated
-        if (track) enqueue_objective(alg, o, trace_dev.p + t, done_flag());
+        if (track) { w_sync(done_flag()); enqueue_objective(alg, o, trace_dev.p + t, done_flag()); }
         if (!pipe_pending) enqueue_check(o, t);                            // common.jl:73
         if (poll) {
             HIP_TRY(hipMemcpyAsync(ctrl_host, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
@@ -573,6 +627,15 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     // iterations enqueued after the stop were no-ops: the live buffers are those of iteration `niters`
     wcur = (int)((w0 + niters) & 1);
     hcur = o.update_H ? (int)((h0 + niters) & 1) : h0;
+    if (w_res_blocked) {
+        // W of iteration `niters` lives in the blocked buffer that iteration wrote (the in-place all-gathers of the no-op iterations
+        // behind a stop re-deliver what is already there): unpack it into the standard layout for everything that follows
+        wb = (int)(niters & 1);
+        w_res_blocked = niters >= 1;
+        w_std_stale = w_res_blocked;
+        w_sync(nullptr);
+        w_res_blocked = false;
+    }
     if (ctrl_host->status == 0) {
         if (!track && final_objective) enqueue_objective(alg, o, obj_final.p, nullptr);       // common.jl:85-87
     }

@@ -26,7 +26,7 @@ SYMBOLS = [
     "nmfx_device_info", "nmfx_check_nonneg", "nmfx_randinit", "nmfx_solve_replicates", "nmfx_nndsvd", "nmfx_get_iter_trace", "nmfx_rsvd_begin", "nmfx_rsvd_finish",
     "nmfx_local_group_create", "nmfx_local_group_destroy", "nmfx_comm_init_local", "nmfx_comm_set_mode", "nmfx_comm_init_sim", "nmfx_comm_init_p2p", "nmfx_comm_p2p_export", "nmfx_comm_p2p_attach", "nmfx_comm_p2p_stats", "nmfx_pdsolve", "nmfx_pdrsolve", "nmfx_spa_init",
 ]
-COMM_ROW_SHARDED, COMM_REPLICATED_W, COMM_PIPELINED = 0, 1, 2
+COMM_ROW_SHARDED, COMM_REPLICATED_W, COMM_PIPELINED, COMM_REPLICAS = 0, 1, 2, 3
 
 
 class Opts(C.Structure):

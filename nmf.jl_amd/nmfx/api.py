@@ -474,9 +474,11 @@ class Context:
         return w.value, b.value
 
     def comm_set_mode(self, mode: str):
-        """'row_sharded' (default: reduce-scatter / all-gather, each rank updates its rows of W) or 'replicated_w'
-        (one packed all-reduce, every rank applies the full W update)."""
-        self._ck(self.lib.nmfx_comm_set_mode(self.h, {"row_sharded": L.COMM_ROW_SHARDED, "replicated_w": L.COMM_REPLICATED_W, "pipelined": L.COMM_PIPELINED}[mode]))
+        """'row_sharded' (default: reduce-scatter / all-gather, each rank updates its rows of W), 'replicated_w' (one packed
+        all-reduce, every rank applies the full W update), 'pipelined' (opt-in, MultUpdate-MSE), or 'replicas': every rank holds the
+        FULL X and solve_replicates deals the replicates out over the ranks (src/interf.jl:85-101; include/nmfx.h)."""
+        self._ck(self.lib.nmfx_comm_set_mode(self.h, {"row_sharded": L.COMM_ROW_SHARDED, "replicated_w": L.COMM_REPLICATED_W, "pipelined": L.COMM_PIPELINED,
+                                                       "replicas": L.COMM_REPLICAS}[mode]))
 
     def profile_enable(self, mode=1):
         """0 off, 1 every launch (slow), 2 dominant GEMMs sampled 1-in-8 (bench roofline)."""

@@ -78,5 +78,5 @@ def test_bench_gpus_n_without_a_launcher_spawns_torch_distributed_run(monkeypatc
     assert bench.self_launch(4) == 0
     c = seen["cmd"]
     assert c[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in c and "127.0.0.1" in c
-    assert c[-4:] == ["--gpus", "4", "--steps", "7"] and c[-5].endswith("bench.py")
+    assert c[-1].endswith("bench.py") and json.loads(seen["env"]["NMFX_BENCH_ARGV"]) == ["--gpus", "4", "--steps", "7"]
     assert seen["env"]["NMFX_BENCH_DEVICE"] == "0"       # fewer than 4 devices here: every rank on device 0

@@ -37,7 +37,12 @@ def test_c2_trajectory(built, obj):
     assert np.max(np.abs(Hg - Hc)) <= 1e-3 * np.max(np.abs(Hc))
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=1)
 def _c3_inputs():
+    """(X, W0, H0) of the headline shape; built once per session (callers copy W0 / H0 and never write to X)."""
     p = n = 16384
     k = 256
     g = torch.Generator(device="cuda")
@@ -83,9 +88,7 @@ def test_c3_multmse_one_iteration_pieces(built):
         Wref = W0[I, :] * (np.maximum(numw, 0) / denw)
         assert np.max(np.abs(W1[I, :] - Wref)) <= 2e-5 * np.max(np.abs(Wref))
         # --- objective of the result: fp32 product like the reference, Float64 accumulation (sqL2dist)
-        WH = W1 @ H1
-        d = X - WH
-        ref_obj = 0.5 * float(np.sum((d * d).astype(np.float64)))
+        ref_obj = 0.5 * orc.sqL2dist(X, W1 @ H1)
         assert abs(trace[1] - ref_obj) <= 1e-5 * ref_obj
         # --- properties
         assert np.all(W1 >= 0) and np.all(H1 >= 0) and np.isfinite(W1).all() and np.isfinite(H1).all()
@@ -142,10 +145,7 @@ def test_c3_multdiv_properties(built):
         assert np.all(W1 >= 0) and np.all(H1 >= 0) and np.isfinite(W1).all() and np.isfinite(H1).all()
         assert not W1[::97, 3].any() and not H1[5, ::101].any()
         # generalized KL divergence of the final factors (gkldiv, term in T, Float64 accumulation)
-        WH = W1 @ H1
-        pos = X > 0
-        t = np.where(pos, X * np.log(np.where(pos, X, 1) / WH) - X + WH, WH)
-        ref = float(np.sum(t.astype(np.float64)))
+        ref = orc.gkldiv(X, W1 @ H1)            # (in column blocks: the one-shot form's 1 GiB temporaries cost ~25 s of page faults here)
         assert abs(trace[3] - ref) <= 2e-5 * abs(ref)
 
 

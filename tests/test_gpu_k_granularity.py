@@ -20,7 +20,7 @@ def test_sixty_four_granular_k_against_the_oracle(built, alg, T, k, monkeypatch)
     X, W0, H0 = planted(p, n, k, T, seed=31 + k, normalize=(alg != "projals"), k0=min(k, 40))
     # (projals in Float32: a regularisation that keeps the rank-40 Grams well conditioned, as in test_projals_k_beyond_one_lds_column)
     lam = (0.5 if T == np.float64 else 20.0) if alg == "projals" else lam_for(alg, T)
-    iters = 3 if alg == "alspgrad" else 6
+    iters = (2 if k > 200 else 3) if alg == "alspgrad" else 6     # (alspgrad: the CPU oracle's ~600 inner iterations per outer one dominate the test's time)
     kw = dict(maxiter=iters, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True)
     Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
     with nmfx.Context(T, p, n, k) as ctx:

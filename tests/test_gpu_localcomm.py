@@ -359,3 +359,80 @@ def test_sharded_first_update_is_bit_identical_to_the_oracle_on_exact_inputs(bui
         assert np.array_equal(Hs, H0) and not np.array_equal(Ws, W0)
     if alg == "greedycd":
         assert sum(res.inner_iters for res, _ in rr) == ro.counters["inner"]
+
+
+def _replicates_over_ranks(T, X, W0, H0, alg, kw, G, R, seed, zeroh, peer=False, timeout=600):
+    """nmfx_solve_replicates with the replicates dealt out over G in-process ranks (NMFX_COMM_REPLICAS): every rank holds the full X."""
+    p, n = X.shape
+    k = W0.shape[1]
+    group = None if peer else nmfx.LocalGroup(G)
+    out, errs, handles = [None] * G, [], [None] * G
+    bar = threading.Barrier(G)
+
+    def worker(r):
+        try:
+            with nmfx.Context(T, p, n, k) as ctx:
+                if peer:
+                    ctx.comm_init_p2p(r, G)
+                    handles[r] = ctx.comm_p2p_export()
+                    bar.wait(timeout)
+                    ctx.comm_p2p_attach(handles)
+                else:
+                    ctx.comm_init_local(group, r)
+                ctx.comm_set_mode("replicas")
+                ctx.set_X(X)
+                W, H = W0.copy(order="F"), H0.copy(order="F")
+                res, best = ctx.solve_replicates(ALG[alg], nmfx.make_opts(T, **kw), R, seed, zeroh, W, H)
+                out[r] = (W, H, res.niters, bool(res.converged), res.objvalue, best)
+                bar.wait(timeout)
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+            bar.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout)
+    assert not errs, errs
+    if group is not None:
+        group.close()
+    return out
+
+
+@pytest.mark.parametrize("alg,T,G,R", [("multmse", np.float32, 2, 5), ("multmse", np.float64, 4, 6), ("projals", np.float64, 4, 3),
+                                       ("greedycd", np.float32, 2, 4)])
+def test_replicates_over_ranks_equal_the_sequential_loop(built, alg, T, G, R):
+    """solve_replicates! (src/interf.jl:85-101) fanned out over the ranks: rank g runs replicates g + 1, g + 1 + G, ...; the winner,
+    its index, niters / converged / objvalue and the factors on EVERY rank are bit-identical to the sequential one-GPU call with the
+    same seed.  G = 4 with R = 3 leaves one rank without a replicate; R = 6 on 4 ranks gives two ranks a second one."""
+    p, n, k = 300, 260, 6
+    X, W0, H0 = planted(p, n, k, T, seed=8, normalize=(alg != "projals"))
+    lam = lam_for(alg, T)
+    kw = dict(maxiter=25, tol=1e-4, lambda_w=lam, lambda_h=lam)
+    zeroh = alg == "projals"
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        Ws, Hs = W0.copy(order="F"), H0.copy(order="F")
+        rs, bs = ctx.solve_replicates(ALG[alg], nmfx.make_opts(T, **kw), R, 1234, zeroh, Ws, Hs)
+    out = _replicates_over_ranks(T, X, W0, H0, alg, kw, G, R, 1234, zeroh)
+    for W, H, niters, conv, objv, best in out:
+        assert best == bs and niters == rs.niters and conv == bool(rs.converged) and objv == rs.objvalue
+        assert np.array_equal(W, Ws) and np.array_equal(H, Hs)
+
+
+def test_replicates_over_ranks_on_the_peer_windows_and_update_h_false(built):
+    """The same fan-out with the peer windows as the only transport (the broadcast travels through the slots), and update_H = false:
+    when replicate 1 wins, H comes back untouched on every rank (test/interf.jl:33-37)."""
+    T = np.float32
+    p, n, k = 256, 200, 5
+    X, W0, H0 = planted(p, n, k, T, seed=4)
+    for kw, R in ((dict(maxiter=20, tol=1e-30), 4), (dict(maxiter=20, tol=1e-30, update_H=False), 3)):
+        with nmfx.Context(T, p, n, k) as ctx:
+            ctx.set_X(X)
+            Ws, Hs = W0.copy(order="F"), H0.copy(order="F")
+            rs, bs = ctx.solve_replicates(ALG["multmse"], nmfx.make_opts(T, **kw), R, 77, False, Ws, Hs)
+        out = _replicates_over_ranks(T, X, W0, H0, "multmse", kw, 2, R, 77, False, peer=True)
+        for W, H, niters, conv, objv, best in out:
+            assert best == bs and niters == rs.niters and objv == rs.objvalue
+            assert np.array_equal(W, Ws) and np.array_equal(H, Hs)

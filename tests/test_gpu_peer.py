@@ -200,7 +200,7 @@ def run_peer_processes(T, shape, alg, G, iters, lam, seed=17, mode="row_sharded"
     ("multmse", np.float32, 4, (1024, 1100, 256), 6),      # K = 256, whole 128-row tiles per rank: the fused row-sharded step
     ("multmse", np.float32, 8, (2048, 2300, 256), 6),      # the 8-rank layout of the driver's run at 1/8 scale
     ("alspgrad", np.float64, 4, (300, 530, 6), 4),         # the line-search scalars travel inside the decision kernels
-    ("alspgrad", np.float64, 8, (300, 513, 6), 3),
+    ("alspgrad", np.float64, 8, (300, 513, 6), 2),        # (8 processes time-sharing one GPU: ~30 us per in-kernel all-reduce, ~25 s per outer iteration)
     ("projals", np.float64, 2, (300, 530, 6), 8),
     ("multdiv", np.float32, 4, (300, 530, 6), 8),
     ("greedycd", np.float64, 2, (300, 530, 6), 6),

@@ -21,6 +21,7 @@ from problems import planted, rel_trace_err, uniform
 
 pytestmark = pytest.mark.gpu
 TOL = {np.float64: 1e-7, np.float32: 2e-3}
+TOL_ALSPGRAD_F32 = 5e-4   # measured: <= 2.1e-4 on six seeded problems in every gradient mode (profiles/r05_alspgrad_gradient_modes.jsonl)
 
 
 @pytest.mark.parametrize("T", [np.float64, np.float32])
@@ -168,7 +169,7 @@ def test_alspgrad_trajectory(built, T, shape):
     Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
     ro = orc.solve("alspgrad", X, Wc, Hc, orc.Opts(maxiter=8, tol=1e-30, track_objective=True))
     assert r.niters == ro.niters == 8
-    assert rel_trace_err(r.trace, ro.trace) < TOL[T]
+    assert rel_trace_err(r.trace, ro.trace) < (TOL_ALSPGRAD_F32 if T == np.float32 else TOL[T])
     assert np.all(Wg >= 0) and np.all(Hg >= 0)
     if T == np.float64:
         assert r.info["inner_iters"] == ro.counters["inner"]
@@ -272,7 +273,7 @@ def test_alspgrad_f32_counters_near_the_oracle(built):
     assert r.niters == ro.niters == 6
     ci, cb = ro.counters["inner"], ro.counters["backtracks"]
     assert abs(r.info["inner_iters"] - ci) <= max(2, 0.02 * ci) and abs(r.info["backtracks"] - cb) <= max(4, 0.02 * cb)
-    assert rel_trace_err(r.trace, ro.trace) < 2e-3
+    assert rel_trace_err(r.trace, ro.trace) < TOL_ALSPGRAD_F32
 
 
 @pytest.mark.parametrize("k", [5, 70, 130, 256])
@@ -363,4 +364,4 @@ def test_alspgrad_exact_gradient_mode(built, T):
             assert rel_trace_err(out[g][0].trace, ro.trace) < 1e-7
     else:
         assert abs(r.info["inner_iters"] - ci) <= max(2, 0.02 * ci) and abs(r.info["backtracks"] - cb) <= max(4, 0.02 * cb)
-        assert rel_trace_err(r.trace, ro.trace) < TOL[T]
+        assert rel_trace_err(r.trace, ro.trace) < TOL_ALSPGRAD_F32

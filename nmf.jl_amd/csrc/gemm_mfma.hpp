@@ -724,7 +724,8 @@ template <typename T> struct EpiStorePeer {
 // STATS = 1 additionally accumulates the stop_condition sums of the component that runs along c
 // (src/common.jl:100-104: dev = sum (new-old)^2, sum = sum (new+old)^2; term in T, sum in Float64) and writes
 // one partial per r-tile:  stat_partial[(tr*ncomp + c)*2 + {0,1}]  -- the layout finalize_partials_kernel reduces.
-template <typename T, int STATS> struct EpiMultUpdate {
+// NSL = the largest slab count the prefetch handles (2 or 8): slabs 1 .. NSL-1 are loaded unconditionally and selected (see prefetch).
+template <typename T, int STATS, int NSL = 2> struct EpiMultUpdate {
     const T *num;
     int nslab;
     int64_t slab_stride;
@@ -780,14 +781,16 @@ template <typename T, int STATS> struct EpiMultUpdate {
         // The second slab (the usual case: the numerator product ran 2-way split-K) is loaded UNCONDITIONALLY -- from slab 0 again when
         // there is only one -- and selected afterwards.  As a loop over a run-time slab count every element's load sat in its own
         // basic block behind s_waitcnt vmcnt(0): 16 dependent memory round trips per wave tile in front of the main loop (ISA).
-        {
-            const int64_t s1 = (nslab > 1) ? slab_stride : 0;
+#pragma unroll
+        for (int sl = 1; sl < NSL; ++sl) {
+            const int64_t s1 = (nslab > sl) ? (int64_t)sl * slab_stride : 0;
             const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(num + (s1 + tile_off)), 0, -1, 0x00020000);
             const T v1 = buf_ld<T>(rs, la.lb, so);
             const T sum = nu + v1;
-            nu = (nslab > 1) ? sum : nu;
+            nu = (nslab > sl) ? sum : nu;
         }
-        // (nslab <= 2 here: the callers combine three or more slabs by a reduction launch first -- Solver::h_num_nslab / w_num_nslab)
+        // (nslab <= NSL here: the callers combine more slabs by a reduction launch first -- Solver::h_num_nslab / w_num_nslab; NSL = 8 serves
+        // the 8-rank shard of the headline problem, whose W'X runs 8-way split-K: the 7 us combine launch and its 2 MB round trip go away)
         return Pre{nu, buf_ld<T>(rold, la.lb, so)};
     }
     __device__ __forceinline__ void apply(int ro, int co, T v, int jt, const Pre &pre) {

@@ -38,16 +38,31 @@ __global__ void reduce_slabs_kernel(T *dst, const T *src, int64_t count, int nsl
 
 // the same sum, 4 (Float32) / 2 (Float64) consecutive elements per thread as one 16-byte access per slab: a quarter of the load
 // instructions and 1 KB per wave-load (count, stride and the base pointers multiples of the vector: the padded operand sizes are)
+// (eight slabs' loads in flight, then the adds in slab order: the plain `s += load` loop over a run-time count chained nslab
+// dependent memory round trips -- 6.4 us for the 8 slabs of a 256 x 256 Gram)
+template <typename T>
+__device__ __forceinline__ void reduce_slabs_vec_body(T *dst, const T *src, int64_t nvec, int nslab, int64_t stride, int64_t i) {
+    constexpr int V = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    if (i >= nvec) return;
+    vec_t s = *reinterpret_cast<const vec_t *>(src + i * V);
+    for (int k0 = 1; k0 < nslab; k0 += 8) {
+        vec_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = (k0 + u < nslab) ? k0 + u : nslab - 1;
+            v[u] = *reinterpret_cast<const vec_t *>(src + (int64_t)k * stride + i * V);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < nslab) s += v[u];
+    }
+    *reinterpret_cast<vec_t *>(dst + i * V) = s;
+}
 template <typename T>
 __global__ void reduce_slabs_vec_kernel(T *dst, const T *src, int64_t nvec, int nslab, int64_t stride, const int *done) {
     NMFX_DONE_GUARD(done);
-    constexpr int V = 16 / sizeof(T);
-    typedef T vec_t __attribute__((ext_vector_type(V)));
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvec) return;
-    vec_t s = *reinterpret_cast<const vec_t *>(src + i * V);
-    for (int k = 1; k < nslab; ++k) s += *reinterpret_cast<const vec_t *>(src + (int64_t)k * stride + i * V);
-    *reinterpret_cast<vec_t *>(dst + i * V) = s;
+    reduce_slabs_vec_body<T>(dst, src, nvec, nslab, stride, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // Same sum for MANY slabs of a small matrix (the tail pieces of the fused Gram: ~128 slabs of k x k).  A thread per
@@ -534,12 +549,9 @@ __global__ __launch_bounds__(256) void peer_sum3_kernel(T *num, const unsigned c
 // ldo = P; blocked: the chunk stride in elements, ldo = Pc); g_first = the first row block of the grid (own-rows statistics: the
 // rank's block only, grid.x = cpp) -- the per-chunk arithmetic, hence every partial's bits, is the same in all forms.
 template <typename T>
-__global__ __launch_bounds__(256) void gather_stats_kernel(T *Wfull, const T *Wold, const unsigned char *recv, size_t chunk_bytes, int64_t P,
-                                                           int64_t Pc, int cpp, int K, double *partial, const int *done, int64_t old_blk = -1,
-                                                           int64_t ldo = -1, int g_first = 0) {
-    NMFX_DONE_GUARD(done);
+__device__ __forceinline__ void gather_stats_body(int chunk, int j, T *Wfull, const T *Wold, const unsigned char *recv, size_t chunk_bytes, int64_t P,
+                                                  int64_t Pc, int cpp, int K, double *partial, int64_t old_blk, int64_t ldo, int g_first) {
     __shared__ double sm[8];
-    const int j = blockIdx.y, chunk = blockIdx.x;
     const int g = g_first + chunk / cpp, ci = chunk % cpp;
     const int64_t per = (Pc + cpp - 1) / cpp;
     const int64_t beg = ci * per, end = (beg + per < Pc) ? beg + per : Pc;
@@ -587,17 +599,47 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(T *Wfull, const T *Wo
     }
 }
 template <typename T>
+__global__ __launch_bounds__(256) void gather_stats_kernel(T *Wfull, const T *Wold, const unsigned char *recv, size_t chunk_bytes, int64_t P,
+                                                           int64_t Pc, int cpp, int K, double *partial, const int *done, int64_t old_blk = -1,
+                                                           int64_t ldo = -1, int g_first = 0) {
+    NMFX_DONE_GUARD(done);
+    gather_stats_body<T>((int)blockIdx.x, (int)blockIdx.y, Wfull, Wold, recv, chunk_bytes, P, Pc, cpp, K, partial, old_blk, ldo, g_first);
+}
+// Behind the rank's W update in the blocked-residency step: its two independent small passes in ONE launch -- blocks [0, nbs): the
+// stop_condition sums of the rank's own rows (gather_stats_body, block b <-> chunk b % nchunk, component b / nchunk); the rest: the
+// split-K combine of the own-rows Gram (reduce_slabs_vec_body).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_tail_kernel(const T *Wold, const unsigned char *recv, size_t chunk_bytes, int64_t P, int64_t Pc, int cpp, int K,
+                                                        double *partial, int64_t old_blk, int64_t ldo, int g_first, unsigned nbs, T *gdst, const T *gsrc,
+                                                        int64_t gnvec, int gslabs, int64_t gstride, const int *done) {
+    NMFX_DONE_GUARD(done);
+    if (blockIdx.x < nbs) {
+        gather_stats_body<T>((int)(blockIdx.x % (unsigned)cpp), (int)(blockIdx.x / (unsigned)cpp), (T *)nullptr, Wold, recv, chunk_bytes, P, Pc, cpp, K, partial, old_blk,
+                             ldo, g_first);
+    } else {
+        reduce_slabs_vec_body<T>(gdst, gsrc, gnvec, gslabs, gstride, (int64_t)(blockIdx.x - nbs) * blockDim.x + threadIdx.x);
+    }
+}
+template <typename T>
 // grp > 0: the partials arrive in groups of grp chunks, group q at partial + q * grp_stride doubles (the ranks' statistics tails
 // behind their row blocks in the blocked W buffer); summed in the same chunk order either way.
 __global__ __launch_bounds__(256) void stats_check_kernel(const double *partial, int nchunks, int K, double *wstat, Ctrl *ctrl, const double *hstat,
                                                           int k, T tol, long long t, int do_check, const int *done, int grp = 0, int64_t grp_stride = 0) {
     NMFX_DONE_GUARD(done);
+    // (sixteen loads in flight, then the adds in chunk order: as a plain `s += partial[...]` loop every load waited for the add before it --
+    // 16 dependent HBM round trips, 17 us for 64 KB at the 8-rank shard shape)
     for (int e = threadIdx.x; e < 2 * K; e += blockDim.x) {
         double s = 0.0;
-        if (grp > 0) {
-            for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)(c / grp) * grp_stride + (int64_t)(c % grp) * 2 * K + e];
-        } else {
-            for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * 2 * K + e];
+        for (int c0 = 0; c0 < nchunks; c0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = (c0 + u < nchunks) ? c0 + u : nchunks - 1;
+                v[u] = (grp > 0) ? partial[(int64_t)(c / grp) * grp_stride + (int64_t)(c % grp) * 2 * K + e] : partial[(int64_t)c * 2 * K + e];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (c0 + u < nchunks) s += v[u];
         }
         wstat[e] = s;
     }

@@ -973,7 +973,7 @@ template <typename T> class Solver : public SolverBase {
         } else
         gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                (double)(P * N + P * K) * sizeof(T));
-        const bool red = !keep_slabs || h_nslab > 2;
+        const bool red = !keep_slabs || h_nslab > h_keep_max;
         h_in_slabs = !red;
         if (with_gram) {
             EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
@@ -1008,8 +1008,9 @@ template <typename T> class Solver : public SolverBase {
     // after wt_times(..., with_gram=true): where the numerator / the Gram operand live
     bool h_in_slabs = false, w_in_slabs = false;
     const T *h_num() const { return h_in_slabs ? slabs.p : numH_p; }
-    int h_num_nslab() const {   // (EpiMultUpdate sums at most two slabs)
-        if (h_in_slabs && h_nslab > 2) throw StatusError{NMFX_ERR_UNSUPPORTED, "internal: more than two numerator slabs left for the update epilogue"};
+    int h_keep_max = 2;   // slabs the consumer of wt_times(keep_slabs) can sum itself (EpiMultUpdate<.., NSL>: 2, or 8 in the row-sharded fused step)
+    int h_num_nslab() const {
+        if (h_in_slabs && h_nslab > h_keep_max) throw StatusError{NMFX_ERR_UNSUPPORTED, "internal: more numerator slabs left than the update epilogue sums"};
         return h_in_slabs ? h_nslab : 1;
     }
 

@@ -148,17 +148,29 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
         h_reduce_pair = fusedrs;
         if (w_res_blocked && have_gram) { wt_blocked = reinterpret_cast<const T *>(Wblk[wb].p); wt_blk_stride = (int64_t)(blk_chunk / sizeof(T)); }
         else w_sync(done);
+        // (row-sharded fused step, Gram already all-reduced: up to 8 split-K slabs of the numerator go straight into the update's epilogue)
+        const bool many = have_gram && s_h > 2 && s_h <= 8;
+        h_keep_max = many ? 8 : 2;
         wt_times(Wp, X.p, !have_gram, done, /*keep_slabs=*/true);
+        h_keep_max = 2;
         wt_blocked = nullptr;
         h_reduce_pair = false;
+        const bool eight = h_in_slabs && h_nslab > 2;
         if constexpr (sizeof(T) == 4) {
-            if (ht_active) {   // the new H also transposed, for the X*H' product below
-                EpiMultUpdate<T, 2> e{h_num(), h_num_nslab(), h_stride, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};  // :99-103
+            if (ht_active && !eight) {   // the new H also transposed, for the X*H' product below
+                EpiMultUpdate<T, 2> e{h_num(), h_in_slabs ? h_nslab : 1, h_stride, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};  // :99-103
                 e.outT = Ht[hcur ^ 1].p; e.ldT = N;
-                gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (4.0 + h_num_nslab()) * K * N * sizeof(T));
+                gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (4.0 + e.nslab) * K * N * sizeof(T));
+            } else if (ht_active) {
+                EpiMultUpdate<T, 2, 8> e{h_num(), h_nslab, h_stride, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};
+                e.outT = Ht[hcur ^ 1].p; e.ldT = N;
+                gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (4.0 + e.nslab) * K * N * sizeof(T));
             }
         }
-        if (!ht_active) {
+        if (!ht_active && eight) {
+            EpiMultUpdate<T, 1, 8> e{h_num(), h_nslab, h_stride, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};
+            gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (3.0 + e.nslab) * K * N * sizeof(T));
+        } else if (!ht_active) {
         EpiMultUpdate<T, 1> e{h_num(), h_num_nslab(), h_stride, Ho, Hn, K, (T)o.lambda_h, (T)o.delta, stat_part.p, (int)K};  // :99-103
         gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (3.0 + h_num_nslab()) * K * N * sizeof(T));
         }
@@ -243,18 +255,25 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
         double *tail = reinterpret_cast<double *>(mine_b + (size_t)Pc * K * sizeof(T));
         EpiMultUpdateRows<T> e{rs_out.p, Pc, Wo_own, ldo, mine, (T)o.lambda_w, (T)o.delta};               // multupd.jl:110-114
         gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo_own, ldo, Pc, K, 1, false, e, done, 3.0 * Pc * K * sizeof(T));
+        int sg = 0;
         if (o.update_H) {
-            const int sg = pick_splits((int)((K / 64) * (K / 64)), Pc);
+            sg = pick_splits((int)((K / 64) * (K / 64)), Pc);
             EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
             force_quarter_tiles = true;
             gemm<KCONTIG, KCONTIG>("gemm_WtW_rows", mine, Pc, K, mine, Pc, K, Pc, sg, true, eg, done, (double)(Pc * K) * sizeof(T));
             force_quarter_tiles = false;
-            reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, sg, done);
+            // (16 or more slabs keep their own combine launch: reduce_many_slabs_kernel adds them in another -- fixed -- order, and the peer
+            // transport's step, which must give the same bits, uses it)
+            if (sg >= 16) { reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, sg, done); sg = 0; }
         }
-        // stop_condition's sums over the rank's OWN rows (the chunking and arithmetic of gather_stats_kernel), into the tail of the chunk
-        timed("stats_W_rows", 0.0, 2.0 * Pc * K * sizeof(T), [&] {
-            hipLaunchKernelGGL(gather_stats_kernel<T>, dim3((unsigned)cpp, (unsigned)K), dim3(256), 0, stream, (T *)nullptr, Wo_own - (int64_t)rank * (w_res_blocked ? blk_el : Pc),
-                               Wblk[wb ^ 1].p, blk_chunk, P, Pc, cpp, (int)K, tail, done, w_res_blocked ? blk_el : Pc, ldo, rank);
+        // ONE launch: stop_condition's sums over the rank's OWN rows (the chunking and arithmetic of gather_stats_kernel) into the tail of
+        // the chunk, and the split-K combine of the own-rows Gram (reduce_slabs_vec_kernel's arithmetic)
+        timed("stats_W_rows+reduce_WtW", 0.0, (2.0 * Pc * K + (double)K * K * (sg + 1)) * sizeof(T), [&] {
+            constexpr int V = 16 / (int)sizeof(T);
+            const int64_t gnvec = (int64_t)K * K / V;
+            const unsigned nbs = (unsigned)(cpp * K), nbr = sg > 0 ? (unsigned)((gnvec + 255) / 256) : 0u;
+            hipLaunchKernelGGL(rows_tail_kernel<T>, dim3(nbs + nbr), dim3(256), 0, stream, Wo_own - (int64_t)rank * (w_res_blocked ? blk_el : Pc), Wblk[wb ^ 1].p, blk_chunk,
+                               P, Pc, cpp, (int)K, tail, w_res_blocked ? blk_el : Pc, ldo, rank, nbs, gramW_p, slabs.p + gram_slab_off, gnvec, sg, (int64_t)K * K, done);
             HIP_TRY(hipGetLastError());
         });
         timed("comm_all_gather_W", 0.0, (double)(P * K) * sizeof(T), [&] {

@@ -134,10 +134,20 @@ def _col_blocks(a, b):
         yield a[:, j0:j0 + step], b[:, j0:j0 + step]
 
 
+def _pmap(fn, blocks):
+    """fn over the blocks on a small thread pool (NumPy's element-wise loops release the GIL), results in BLOCK ORDER: the sum of
+    the blocks' sums does not depend on the schedule.  Full-size parity runs only (see _col_blocks)."""
+    import concurrent.futures as cf
+    import os
+    blocks = list(blocks)
+    with cf.ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1))) as ex:
+        return list(ex.map(lambda xy: fn(*xy), blocks))
+
+
 def sqL2dist(a, b):
     """StatsBase.sqL2dist: r=0.0; r += abs2(a[i]-b[i]) -- term in T, sum in Float64."""
     if a.ndim == 2 and a.size > _BLOCKED_ABOVE:
-        return float(sum(sqL2dist(x, y) for x, y in _col_blocks(a, b)))
+        return float(sum(_pmap(sqL2dist, _col_blocks(a, b))))
     d = a - b
     return float(np.sum((d * d).astype(np.float64)))
 
@@ -145,7 +155,7 @@ def sqL2dist(a, b):
 def gkldiv(a, b):
     """StatsBase.gkldiv: sum(a>0 ? a*log(a/b) - a + b : b), term in T, sum in Float64."""
     if a.ndim == 2 and a.size > _BLOCKED_ABOVE:
-        return float(sum(gkldiv(x, y) for x, y in _col_blocks(a, b)))
+        return float(sum(_pmap(gkldiv, _col_blocks(a, b))))
     T = a.dtype.type
     pos = a > 0
     safe_a = np.where(pos, a, T(1))
@@ -374,9 +384,17 @@ class _MultDiv:
             return X / (self.WH + d)
         if getattr(self, "_Q", None) is None or self._Q.shape != X.shape:
             self._Q = np.empty_like(X)
-        np.add(self.WH, d, out=self._Q)
-        np.divide(X, self._Q, out=self._Q)
-        return self._Q
+        Q, WH = self._Q, self.WH
+
+        def blk(x, q):           # q is a view into Q; its columns [j0, j1) are recovered from the view's offset
+            j0 = (q.__array_interface__["data"][0] - Q.__array_interface__["data"][0]) // Q.strides[1]
+            w = WH[:, j0:j0 + q.shape[1]]
+            np.add(w, d, out=q)
+            np.divide(x, q, out=q)
+            return 0
+
+        _pmap(blk, _col_blocks(X, Q))
+        return Q
 
     def update(self, X, W, H):
         T, o = self.T, self.o

@@ -535,7 +535,9 @@ def live_traffic(kernel):
     if exe is None:
         return None, None
     # the launches behind the bench names (csrc/solver.hpp): W'X = both operands contraction-contiguous, XH' = both strided; 128 x 128 tiles
-    pat = {"gemm_WtX": "gemm_mfma_kernel<float, 0, 0, 128, 128, 2, 2, nmfx::EpiStore<float>", "gemm_XHt": "gemm_mfma_kernel<float, 1, 1, 128, 128, 2, 2, nmfx::EpiStore<float>"}.get(kernel)
+    # (round 5: X*H' runs on the transposed images of X and H, i.e. on the SAME instantiation as W'X -- both operands contraction-contiguous;
+    # the two launches read X once each plus a 16 MiB factor and write two 16 MiB slabs: the counters are averaged over both)
+    pat = {"gemm_WtX": "gemm_mfma_kernel<float, 0, 0, 128, 128, 2, 2, nmfx::EpiStore<float>", "gemm_XHt": "gemm_mfma_kernel<float, 0, 0, 128, 128, 2, 2, nmfx::EpiStore<float>"}.get(kernel)
     if pat is None:
         return None, None
     vals = {}

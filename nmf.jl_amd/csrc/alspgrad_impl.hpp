@@ -110,7 +110,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     const int AHEAD = 8;
     int SPEC = std::min(pg_spec_hint[left ? 0 : 1], traceiter);
     int forced = 0;                                                        // NMFX_PG_SPEC=n pins it (tests: every value gives the same bits)
-    if (const char *e = std::getenv("NMFX_PG_SPEC")) forced = std::atoi(e);
+    if (const char *e = dev_env("NMFX_PG_SPEC")) forced = std::atoi(e);
     if (forced > 0) SPEC = std::min(forced, traceiter);
     auto retune = [&]() {
         if (forced > 0) return;
@@ -163,7 +163,7 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
         retune();
     }
     apply(true);                                                           // the accept of the last executed search, if any
-    if (const char *e = std::getenv("NMFX_PG_HIST"); e && e[0] == '1' && pg_host) {
+    if (const char *e = dev_env("NMFX_PG_HIST"); e && e[0] == '1' && pg_host) {
         std::fprintf(stderr, "[nmfx] pg_subsolve(%s): %lld inner iterations, searches by steps:", left ? "H" : "W", t);
         for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %d", pg_host->hist[i]);
         std::fprintf(stderr, "\n");

@@ -18,6 +18,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <cstdint>
 #include <mutex>
@@ -25,6 +26,14 @@
 #include <vector>
 
 namespace nmfx {
+
+// Development switches (A/B measurements, tests of alternative kernels; the NMFX_* names read through this function) are honoured
+// only when NMFX_DEV=1 is set as well: a caller's environment cannot change what the library computes by accident.  The one
+// run-time setting a deployment may want, NMFX_P2P_TIMEOUT_S, is read directly.
+static inline const char *dev_env(const char *name) {
+    static const bool on = [] { const char *e = std::getenv("NMFX_DEV"); return e != nullptr && e[0] == '1'; }();
+    return on ? std::getenv(name) : nullptr;
+}
 
 struct CommError {
     std::string msg;

@@ -256,9 +256,9 @@ struct PeerComm : Comm {
         double tmo_s = 30.0;
         if (const char *e = std::getenv("NMFX_P2P_TIMEOUT_S")) tmo_s = std::max(0.01, std::atof(e));
         timeout_ticks = (unsigned long long)(tmo_s * 1e8);   // wall_clock64: 100 MHz
-        if (const char *e = std::getenv("NMFX_P2P_TINY")) tiny_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_P2P_TINY")) tiny_enabled = std::atoi(e) != 0;
         // uncached: remote stores and local reads both bypass the (non-coherent) L2s; NMFX_P2P_MEM=finegrained|plain for experiments
-        const char *kind = std::getenv("NMFX_P2P_MEM");
+        const char *kind = dev_env("NMFX_P2P_MEM");
         hipError_t e;
         if (kind && std::strcmp(kind, "plain") == 0) e = hipMalloc(reinterpret_cast<void **>(&mine), win_bytes);
         else e = hipExtMallocWithFlags(reinterpret_cast<void **>(&mine), win_bytes, (kind && std::strcmp(kind, "finegrained") == 0) ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);

@@ -96,7 +96,7 @@ template <typename T> bool Solver<T>::rsvd_cholqr2(T *Qbuf, T *tmp) {
     T *Uinv = work[1].p, *Gkeep = work[2].p, *src = Qbuf, *dst = tmp;
     std::vector<T> gh(kk);
     const double eps = (double)std::numeric_limits<T>::epsilon(), limit = 1.0 / (8.0 * std::sqrt(eps));
-    const bool dbg = std::getenv("NMFX_DEBUG") != nullptr;
+    const bool dbg = dev_env("NMFX_DEBUG") != nullptr;
     Ctrl init;
     std::memset(&init, 0, sizeof init);
     auto factor = [&](T shift, double &dmin, double &dmax) {      // gramW_p <- chol(gramW_p + shift I); false on a non-positive pivot

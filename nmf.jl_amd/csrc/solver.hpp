@@ -134,18 +134,18 @@ template <typename T> class Solver : public SolverBase {
         // ProjectedALS runs its single-workgroup factorisations UNDER the big products (projals_impl.hpp): the products launch
         // `chol_slots` blocks short of two per CU, a high-priority side stream owns the half-empty CUs that leaves.
         // NMFX_CHOL_SLOTS=0 turns it off (factorisations between the products, as in round 1).
-        if (const char *e = std::getenv("NMFX_CHOL_SLOTS")) chol_slots = std::max(0, std::min(128, std::atoi(e)));
-        if (const char *e = std::getenv("NMFX_FORCE_SHARDED")) force_sharded = std::atoi(e) != 0;
-        if (const char *e = std::getenv("NMFX_CD_LDS")) cd_force_lds = std::atoi(e) != 0;
-        if (const char *e = std::getenv("NMFX_CD_BLOCKED")) cd_blocked = std::atoi(e) != 0 ? 1 : 0;
-        if (const char *e = std::getenv("NMFX_RS_FUSED")) rs_fused_enabled = std::atoi(e) != 0;
-        if (const char *e = std::getenv("NMFX_STREAM_WH")) stream_wh = std::atoi(e) != 0;
-        if (const char *e = std::getenv("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
-        if (const char *e = std::getenv("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
-        if (const char *e = std::getenv("NMFX_K_GRANULE")) k_granule = (std::atoi(e) == 128) ? 128 : 64;
-        if (const char *e = std::getenv("NMFX_POTRS")) { potrs_enabled = std::atoi(e) != 0; potrs_iter = std::atoi(e) == 1; }
-        if (const char *e = std::getenv("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
-        if (const char *e = std::getenv("NMFX_W_BLOCKED")) blk_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_CHOL_SLOTS")) chol_slots = std::max(0, std::min(128, std::atoi(e)));
+        if (const char *e = dev_env("NMFX_FORCE_SHARDED")) force_sharded = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_CD_LDS")) cd_force_lds = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_CD_BLOCKED")) cd_blocked = std::atoi(e) != 0 ? 1 : 0;
+        if (const char *e = dev_env("NMFX_RS_FUSED")) rs_fused_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_STREAM_WH")) stream_wh = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_K_GRANULE")) k_granule = (std::atoi(e) == 128) ? 128 : 64;
+        if (const char *e = dev_env("NMFX_POTRS")) { potrs_enabled = std::atoi(e) != 0; potrs_iter = std::atoi(e) == 1; }
+        if (const char *e = dev_env("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_W_BLOCKED")) blk_enabled = std::atoi(e) != 0;
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));

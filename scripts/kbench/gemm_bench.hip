@@ -128,6 +128,19 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (what == 7) {   // 8-rank shard shapes: 4 waves (one per SIMD) against 8 waves (two per SIMD) on the same 128 x 128 tile
+        for (int round = 0; round < 3; ++round) {
+            printf("--- round %d\n", round);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 2>("TN sh8 WtX 4 waves s8", 2048, 256, 16384, 8, true, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 4, 2>("TN sh8 WtX 8 waves 2x4 s8", 2048, 256, 16384, 8, true, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 4, 2, 2>("TN sh8 WtX 8 waves 4x2 s8", 2048, 256, 16384, 8, true, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 2>("TN sh8 XHt' 4 waves s1", 256, 16384, 2048, 1, false, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 4, 2>("TN sh8 XHt' 8 waves 2x4 s1", 256, 16384, 2048, 1, false, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 4, 2, 2>("TN sh8 XHt' 8 waves 4x2 s1", 256, 16384, 2048, 1, false, reps);
+            run<float, KCONTIG, KCONTIG, 128, 128, 2, 2, 2>("TN sh8 XHt' 4 waves s2", 256, 16384, 2048, 2, false, reps);
+        }
+        return 0;
+    }
     if (what == 3) {   // buffer loads vs buffer loads + k-loop unrolled by two (LDS stage offsets as immediates)
         g_stagger = 1;
         for (int round = 0; round < 4; ++round) {

@@ -1,4 +1,5 @@
 #!/bin/bash
+export NMFX_DEV=1   # the NMFX_* development switches below are honoured only with it (csrc/comm.hpp)
 # Round-3 evidence run (GPU box): rocprofv3 summaries of the headline and the multdiv command, one bench line per config,
 # the per-launch event tables and the simulated-rank timings.  Everything lands under gpurun_out/r03p/.
 R="$(cd "$(dirname "$0")/.." && pwd)"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export NMFX_DEV=1   # the NMFX_* development switches below are honoured only with it (csrc/comm.hpp)
 # Round-4 evidence run (GPU box): rocprofv3 summaries of the headline and the multdiv command, one bench line per config, per-launch
 # event tables, the simulated-rank timings (RCCL stand-in and peer-window launch sequence), the multi-process bench on one GPU.
 # Everything lands under gpurun_out/r04p/.

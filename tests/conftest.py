@@ -8,6 +8,9 @@ import pytest
 # process's streams onto GPU_MAX_HW_QUEUES = 4 queues by default; a signal queued behind a spinning wait would never run).  Read by
 # the HIP runtime at initialisation, hence before torch.  One process per GPU -- the production layout -- needs nothing of the kind.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# the library's development switches (NMFX_POTRS, NMFX_K_GRANULE, NMFX_RS_FUSED, ...: alternative kernels the tests run against each
+# other) are dead unless NMFX_DEV=1 is set as well (csrc/comm.hpp: dev_env)
+os.environ.setdefault("NMFX_DEV", "1")
 
 import torch  # noqa: E402,F401  first: pins ONE HIP runtime for the process (see nmfx/_lib.py)
 

@@ -203,19 +203,7 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
     allreduce_w_side(o.update_H != 0, done);
     EpiMultUpdate<T, 0> e{w_num(), w_num_nslab(), w_stride, Wo, Wn, P, (T)o.lambda_w, (T)o.delta, nullptr, 0};   // :110-114
     gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo, P, P, K, 1, false, e, done, 3.0 * P * K * sizeof(T));
-    if (!sharded() && o.track_objective == 0) {
-        // one GPU, untracked: the column sums' finalisation and the stop rule in ONE one-block launch (stats_check_kernel, as in the
-        // row-sharded step) instead of finalize_partials + check_kernel
-        timed("stats_W", 0.0, 2.0 * P * K * sizeof(T), [&] {
-            hipLaunchKernelGGL(col_stats_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wn, Wo, P, P, (int)K, stat_part.p, done);
-            hipLaunchKernelGGL(stats_check_kernel<T>, dim3(1), dim3(256), 0, stream, stat_part.p, stat_chunks_w, (int)K, wstat.p, ctrl,
-                               o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, 1, done, 0, (int64_t)0);
-            HIP_TRY(hipGetLastError());
-        });
-        check_fused = true;
-    } else {
-        stats_w(Wn, Wo, done);
-    }
+    stats_w(Wn, Wo, done);
     wcur ^= 1;
 }
 

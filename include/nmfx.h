@@ -116,6 +116,15 @@ typedef struct {
      * default; NMFX_HSOLVE_PRODUCT (1): Uinv (Uinv' B), two products with the inverted factor; NMFX_HSOLVE_POTRS (2): forward and back
      * substitution with the factor itself, the reference's potrs! route (csrc/chol.hpp: potrs_panel_kernel). */
     int32_t h_solve;
+    /* stop_condition's four sums per component (src/common.jl:95-104).  0 (default): the T-rounded terms summed in Float64 in a fixed
+     * tree order, inside the update launches (free; differs from the reference's totals by <= ~eps(T) sqrt(length) relative, so the
+     * decision can differ only when an iteration's relative change sits that close to tol).  1: the reference's own arithmetic -- every
+     * sum accumulated SEQUENTIALLY in T, one chain per component, in index order -- by a pass of its own after each iteration
+     * (measured 0.22 ms per side at 16384 rows, k = 256: one dependent add per element and chain, k / 16 workgroups); `niters`,
+     * `converged` and the relchange column are then the
+     * reference's bit for bit whenever W and H are.  One GPU only (the chains would have to run through the ranks in turn). */
+    int32_t stop_sums;
+    int32_t reserved0;        /* must be 0 */
 } nmfx_opts;
 enum { NMFX_PREC_FP32 = 0, NMFX_PREC_BF16X3 = 1 };
 enum { NMFX_HSOLVE_AUTO = 0, NMFX_HSOLVE_PRODUCT = 1, NMFX_HSOLVE_POTRS = 2 };

@@ -215,6 +215,91 @@ __global__ void finalize_partials_kernel(const double *partial, int nchunks, int
     if (lane == 0) out[e] = (OutT)s;
 }
 
+// stop_condition's sums EXACTLY as the reference forms them (src/common.jl:95-104; nmfx_opts.stop_sums = 1): per component j
+//     dev_w += (W[i,j] - preW[i,j])^2,  sum_w += (W[i,j] + preW[i,j])^2   for i in index order, accumulated in T
+// and the same over row j of H.  One thread per chain pair: the adds are a dependent chain by definition.
+// out[2j] = dev, out[2j+1] = sum, stored as the Float64 image of the T-precision totals (check_body rounds back to T: exact).
+template <typename T, bool ALONG_ELEM>
+__global__ __launch_bounds__(256) void stop_sums_exact_kernel(const T *An, const T *Ao, int64_t len, int64_t elem_stride, int64_t chain_stride, int nchains,
+                                                              double *out, const int *done) {
+    NMFX_DONE_GUARD(done);
+    // A block owns 16 chains (k / 16 blocks: the only parallelism there is, and each block's memory round trip per tile is what paces it).
+    // All 256 threads stage tiles of TILE elements x 16 chains of both factors' TERMS through LDS with coalesced 16-byte loads (along
+    // whichever of the two indices is contiguous), double-buffered; 16 lanes of wave 0 walk the staged tile, lane c <-> chain c.
+    // (The first version let every chain's thread read its own column straight from memory: columns 64 KiB apart alias in every cache
+    // level -- 190 cycles per element, 1.3 ms per side at 16384 rows.)
+    constexpr int CH = 16, TILE = 1024 / (int)sizeof(T), V = 16 / (int)sizeof(T), PERV = CH * TILE / V / 256;
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    constexpr int SZ = (CH * (TILE + 1) > TILE * (CH + 1)) ? CH * (TILE + 1) : TILE * (CH + 1);
+    __shared__ T sa[2][SZ], sb[2][SZ];
+    const int tid = threadIdx.x, c0 = blockIdx.x * CH;
+    constexpr bool along_elem = ALONG_ELEM;        // W (elem_stride == 1): a chain's elements are contiguous; H (chain_stride == 1): the chains are
+    // LDS image: [chain][element] (+1) when the loaders' lanes run along the elements, [element][chain] (+1) when they run along the
+    // chains -- either way the staging writes and the chain wave's reads (lane <-> chain) spread over the banks (the first layout,
+    // [element][chain] for both, put the W side's writes on 8 banks)
+    auto at = [&](int c, int i) { return along_elem ? c * (TILE + 1) + i : i * (CH + 1) + c; };
+    // 16-byte loads along the contiguous index (the buffers are the padded ones: whole tiles and whole groups of 64 chains exist and
+    // are zero beyond the real extent; 4-byte loads made this kernel load-ISSUE-bound: 512 wave-loads per 64-element tile)
+    vec_t ra[PERV], rb[PERV];
+    auto fetch = [&](int64_t i0) {
+#pragma unroll
+        for (int u = 0; u < PERV; ++u) {
+            const int e = tid + 256 * u;
+            const int c = along_elem ? e / (TILE / V) : V * (e % (CH / V)), i = along_elem ? V * (e % (TILE / V)) : e / (CH / V);
+            const int64_t off = (int64_t)(c0 + c) * chain_stride + (i0 + i) * elem_stride;
+            ra[u] = *reinterpret_cast<const vec_t *>(An + off);
+            rb[u] = *reinterpret_cast<const vec_t *>(Ao + off);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PERV; ++u) {
+            const int e = tid + 256 * u;
+            const int c = along_elem ? e / (TILE / V) : V * (e % (CH / V)), i = along_elem ? V * (e % (TILE / V)) : e / (CH / V);
+            // the TERMS are formed here, by all four waves; the chain wave is left with its two dependent adds per element
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                const T d = ra[u][q] - rb[u][q], sp = ra[u][q] + rb[u][q];
+                const T td = (T)(d * d), ts = (T)(sp * sp);
+                const int ix = along_elem ? at(c, i + q) : at(c + q, i);
+                sa[buf][ix] = td;
+                sb[buf][ix] = ts;
+            }
+        }
+    };
+    T dev = (T)0, sum = (T)0;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t i0 = 0; i0 < len; i0 += TILE) {
+        const bool more = i0 + TILE < len;
+        if (more) fetch(i0 + TILE);
+        if (tid < CH) {
+            // (elements past `len` were staged as zeros: they add +0 to sums that are never -0.  Eight LDS reads in flight per chain
+            // step group: read one by one, every element waited ~100 cycles for its ds_read)
+#pragma unroll
+            for (int i = 0; i < TILE; i += 8) {
+                T x[8], y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { x[u] = sa[buf][at(tid, i + u)]; y[u] = sb[buf][at(tid, i + u)]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    dev = dev + x[u];
+                    sum = sum + y[u];
+                }
+            }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (tid < CH && c0 + tid < nchains) {
+        out[2 * (c0 + tid)] = (double)dev;
+        out[2 * (c0 + tid) + 1] = (double)sum;
+    }
+}
+
 // stop_condition decision (src/common.jl:105-110) + iteration bookkeeping.
 // wstat/hstat: [j*2] = dev, [j*2+1] = sum (hstat may be null when update_H is false).
 // The reference accumulates in T; the comparison is done in T on the rounded sums.

@@ -44,7 +44,7 @@ template <typename T> void Solver<T>::enqueue_multmse_smallk(const nmfx_opts &o,
         });
         // the stop rule of this iteration rides in the W-side finish launch unless the caller tracks the objective (check_kernel then
         // also records the verbose table's relchange column)
-        const bool fuse_check = o.track_objective == 0;
+        const bool fuse_check = o.track_objective == 0 && o.stop_sums == 0;
         if (fuse_check && !smallk_ticket.p) smallk_ticket.ensure(1);
         timed("smallk_finish_W", 0.0, (double)stripes_w * (4096 * sizeof(T) + 128 * sizeof(double)), [&] {
             if (fuse_check)

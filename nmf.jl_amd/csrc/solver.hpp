@@ -1245,6 +1245,18 @@ template <typename T> class Solver : public SolverBase {
     }
     void enqueue_check(const nmfx_opts &o, long long t) {
         const bool track = o.track_objective != 0;
+        if (o.stop_sums != 0) {
+            // the reference's sequential T-precision sums (nmfx_opts.stop_sums): the factors of iteration t against those of t - 1 (the
+            // ping-pong partners), overwriting the tree sums the update launches left in wstat / hstat
+            w_sync(done_flag());
+            hipLaunchKernelGGL((stop_sums_exact_kernel<T, true>), dim3((unsigned)((k + 15) / 16)), dim3(256), 0, stream, W[wcur].p, W[wcur ^ 1].p, P, (int64_t)1, P, (int)k, wstat.p,
+                               done_flag());
+            if (o.update_H)
+                hipLaunchKernelGGL((stop_sums_exact_kernel<T, false>), dim3((unsigned)((k + 15) / 16)), dim3(256), 0, stream, H[hcur].p, H[hcur ^ 1].p, N, K, (int64_t)1, (int)k,
+                                   hstat.p, done_flag());
+            HIP_TRY(hipGetLastError());
+            check_fused = false;
+        }
         if (check_fused) {
             check_fused = false;   // stats_check_kernel ran the stop rule of iteration t (never while tracking)
         } else {

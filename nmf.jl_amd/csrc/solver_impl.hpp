@@ -241,7 +241,7 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
         comm->group_end();
     });
     const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(64 / nranks, Pc / 1024));   // statistics chunks per row block
-    const bool fuse_check = o.track_objective == 0;
+    const bool fuse_check = o.track_objective == 0 && o.stop_sums == 0;
     if (blocked_residency_ok()) {
         // ---- W stays in the all-gather's layout between iterations (solver.hpp: Wblk): no unpack launch ----------------------------
         blk_cpp = cpp;
@@ -556,6 +556,8 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     if (alg < 0 || alg > NMFX_ALG_GREEDYCD) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid algorithm."};
     if (o.precision != NMFX_PREC_FP32 && o.precision != NMFX_PREC_BF16X3) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for precision."};
     if (o.pg_refresh < 0) throw StatusError{NMFX_ERR_BAD_ARG, "pg_refresh must be non-negative."};
+    if (o.stop_sums != 0 && o.stop_sums != 1) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for stop_sums."};
+    if (o.stop_sums != 0 && sharded()) throw StatusError{NMFX_ERR_UNSUPPORTED, "stop_sums = 1 (sequential sums) is a one-GPU option"};
     if (o.h_solve < NMFX_HSOLVE_AUTO || o.h_solve > NMFX_HSOLVE_POTRS) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for h_solve."};
     precision = o.precision;
     pipe_pending = false;

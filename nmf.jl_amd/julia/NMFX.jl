@@ -40,6 +40,8 @@ struct COpts
     cd_shuffle::Int32  # 0 = shuffle=false; != 0: shuffle=true, permutations keyed by this value (include/nmfx.h)
     pg_refresh::Int32  # ALSPGrad gradient form: 0 = library default, 1 = exact (src/alspgrad.jl:124-127), n = refresh period
     h_solve::Int32     # ProjectedALS H solve: 0 = library default, 1 = product form, 2 = potrs! route (src/utils.jl:63-70)
+    stop_sums::Int32   # 1: stop_condition's sums sequentially in T like src/common.jl:95-104 (one GPU); 0: Float64 tree sums inside the update launches
+    reserved0::Int32
 end
 
 # struct nmfx_result
@@ -125,9 +127,9 @@ function run!(ctx::Context{T}, alg::Int32, o::COpts, W::Matrix{T}, H::Matrix{T};
 end
 
 opts(T; maxiter, tol, update_H, lambda_w=0.0, lambda_h=0.0, maxsubiter=200, tolg=eps(T)^(1/4),
-     l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision=0, cd_shuffle=0, verbose=false, pg_refresh=0, h_solve=0) =
+     l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision=0, cd_shuffle=0, verbose=false, pg_refresh=0, h_solve=0, exact_stop=false) =
     COpts(maxiter, update_H, verbose ? 1 : 0, maxsubiter, 20, 0, tol, lambda_w, lambda_h, sqrt(eps(T)), tolg, T(0.2), T(0.01),
-          l1_w, l2_w, l1_h, l2_h, precision, cd_shuffle, pg_refresh, h_solve)
+          l1_w, l2_w, l1_h, l2_h, precision, cd_shuffle, pg_refresh, h_solve, exact_stop ? 1 : 0, 0)
 
 # ---- solve! methods: same signatures as src/multupd.jl:45, src/projals.jl:37, src/alspgrad.jl:381, with a
 # ---- leading device Context.  `solve!(alg, X, W, H)` without a Context creates one for the call.

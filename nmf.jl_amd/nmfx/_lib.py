@@ -35,7 +35,7 @@ class Opts(C.Structure):
                 ("tol", C.c_double), ("lambda_w", C.c_double), ("lambda_h", C.c_double), ("delta", C.c_double),
                 ("tolg", C.c_double), ("beta", C.c_double), ("sigma", C.c_double),
                 ("l1_w", C.c_double), ("l2_w", C.c_double), ("l1_h", C.c_double), ("l2_h", C.c_double),
-                ("precision", C.c_int32), ("cd_shuffle", C.c_int32), ("pg_refresh", C.c_int32), ("h_solve", C.c_int32)]
+                ("precision", C.c_int32), ("cd_shuffle", C.c_int32), ("pg_refresh", C.c_int32), ("h_solve", C.c_int32), ("stop_sums", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class CResult(C.Structure):

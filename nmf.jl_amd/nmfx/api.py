@@ -239,7 +239,7 @@ class Result:
 
 def make_opts(T, maxiter=100, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.0, delta=None, maxsubiter=200,
               traceiter=20, tolg=None, beta=0.2, sigma=0.01, track_objective=False, check_every=0,
-              l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision="fp32", cd_shuffle=0, pg_refresh=0, h_solve="auto") -> L.Opts:
+              l1_w=0.0, l2_w=0.0, l1_h=0.0, l2_h=0.0, precision="fp32", cd_shuffle=0, pg_refresh=0, h_solve="auto", exact_stop=False) -> L.Opts:
     T = np.dtype(T).type
     return L.Opts(int(maxiter), int(bool(update_H)), int(bool(track_objective)), int(maxsubiter), int(traceiter),
                   int(check_every),
@@ -248,7 +248,7 @@ def make_opts(T, maxiter=100, tol=None, update_H=True, lambda_w=0.0, lambda_h=0.
                   float(T(_eps(T) ** 0.25) if tolg is None else tolg), float(T(beta)), float(T(sigma)),
                   float(l1_w), float(l2_w), float(l1_h), float(l2_h),
                   {"fp32": L.PREC_FP32, "bf16x3": L.PREC_BF16X3}[precision], int(cd_shuffle), int(pg_refresh),
-                  {"auto": 0, "product": 1, "potrs": 2}[h_solve])
+                  {"auto": 0, "product": 1, "potrs": 2}[h_solve], int(bool(exact_stop)), 0)
 
 
 def nmf_checksize(X, W, H):

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_struct_layouts(built):
     import nmfx
     L = nmfx._lib
-    assert C.sizeof(L.Opts) == 6 * 4 + 11 * 8 + 4 * 4
+    assert C.sizeof(L.Opts) == 6 * 4 + 11 * 8 + 6 * 4
     assert C.sizeof(L.CResult) == 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8
     assert C.sizeof(L.KernelStat) == 64 + 8 + 8 + 8 + 8
     assert L.Opts.tol.offset == 24 and L.CResult.objvalue.offset == 16

@@ -118,3 +118,47 @@ def test_final_objective_can_be_deferred(built, alg, algid):
     assert out[0][3] == out[1][3] == 7
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     assert out[0][0] == out[1][0] and np.isfinite(out[0][0])
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(50, 40, 5), (300, 200, 64), (1100, 900, 100)])
+def test_exact_stop_sums_reproduce_the_reference_bit_for_bit(built, T, shape):
+    """nmfx_opts.stop_sums = 1: stop_condition's sums accumulated sequentially in T, one chain per component (src/common.jl:95-104).
+    On small-integer inputs with update_H = false the first W update is bit-identical to the oracle's (exact products), so the
+    relchange column -- sqrt(max_j dev_w / sum_w), a quotient of those sums -- must then equal the oracle's BIT FOR BIT; the default
+    (Float64 tree sums of the same terms) agrees to rounding only.  And a stop threshold placed between the two roundings of a real
+    run cannot be told apart, so `niters` is checked on a seeded problem against the oracle with NO margin requirement."""
+    p, n, k = shape
+    rng = np.random.default_rng(11 + k)
+    X = np.asfortranarray(rng.integers(0, 4, size=(p, n)).astype(T))
+    W0 = np.asfortranarray(rng.integers(0, 3, size=(p, k)).astype(T))
+    H0 = np.asfortranarray(rng.integers(1, 3, size=(k, n)).astype(T))
+    assert 2 * 2 * k * n * 2 < 2 ** 24
+    out = {}
+    for exact in (True, False):
+        Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+        with nmfx.Context(T, p, n, k) as ctx:
+            ctx.set_X(X)
+            res, _ = ctx.solve(0, nmfx.make_opts(T, maxiter=1, tol=1e-30, update_H=False, track_objective=True, exact_stop=exact), Wg, Hg)
+            _, rc = ctx.iter_trace(2)
+        out[exact] = (Wg, rc[1])
+    Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+    orc.solve("multmse", X, Wc, Hc, orc.Opts(maxiter=1, tol=1e-30, update_H=False))
+    U = np.uint32 if T == np.float32 else np.uint64
+    assert np.array_equal(out[True][0].view(U), Wc.view(U))
+    _, devmax = orc.stop_condition_dev(Wc, W0, H0, H0, 1e-30)
+    assert T(out[True][1]) == T(devmax), (out[True][1], devmax)
+    assert abs(out[False][1] - devmax) <= 1e-5 * devmax
+
+
+def test_exact_stop_sums_niters_without_a_margin(built):
+    T = np.float32
+    X, W0, H0 = planted(300, 260, 6, T, seed=21)
+    for tol in (3e-3, 1e-3, 4e-4):
+        Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
+        ro = orc.solve("multmse", X, Wc, Hc, orc.Opts(maxiter=400, tol=tol))
+        Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+        with nmfx.Context(T, 300, 260, 6) as ctx:
+            ctx.set_X(X)
+            res, _ = ctx.solve(0, nmfx.make_opts(T, maxiter=400, tol=tol, exact_stop=True), Wg, Hg)
+        assert abs(res.niters - ro.niters) <= 1 and bool(res.converged) == ro.converged

@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "gemm_mfma.hpp"
 #include "kernels.hpp"
 
@@ -531,6 +533,221 @@ __global__ __launch_bounds__(POTRS_THREADS) void potrs_panel_kernel(const T *Tm,
         if (old != nullptr && stat_partial != nullptr) {
             stat_partial[((int64_t)blockIdx.x * ncomp + a) * 2] = dev;
             stat_partial[((int64_t)blockIdx.x * ncomp + a) * 2 + 1] = sum;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// potrs! by STRIPS (round 5): the two substitutions of src/utils.jl:69 with no LDS panel, no barrier and no cross-wave traffic.
+//
+// The columns of the right-hand side are independent, so ONE WAVE owns a strip of 16 columns for both sweeps and keeps the whole
+// K x 16 strip in accumulator registers: block row i (32 rows) is two 16 x 16 tiles of v_mfma_{f32,f64}_16x16x4, i.e. 2 x 4
+// registers per lane.  Left-looking:  r_i = b_i - sum_{j < i} L_ij y_j  (the matrix core accumulates into b_i; the packed blocks are
+// stored NEGATED), then  y_i = inv(L_ii) r_i  as one more block product; the backward sweep mirrors it with U.  The trick that makes
+// the registers enough: the B operand of the 16x16x4 instruction wants lane (n, g) to supply contraction index (k-step, g), and an
+// accumulator tile holds rows {4 g + r} (Float32) / {g + 4 r} (Float64) of column n in lane (n, g) -- so if k-step kk of a block
+// product is DEFINED to contract row  rho(kk, g) = 16 (kk / 4) + 4 g + kk % 4  (Float32;  16 (kk / 4) + g + 4 (kk % 4)  in Float64) of
+// the block, the B operand IS accumulator register kk % 4 of tile kk / 4: finished block rows feed the next products straight from
+// the registers the matrix core wrote them to (any partition of the contraction is a valid order of the sum; cd.hpp uses the same
+// freedom).  The A operand -- the 32 x 32 blocks of the factor, the same for every strip -- is packed once per factorisation in
+// exactly the order the sweeps consume it (potrs_strip_pack_kernel): block after block, inside a block 16 values per lane as
+// consecutive 16-byte chunks, so a wave's load instruction is one contiguous KiB and the walk over the factor is a linear stream
+// from L2, requested TWO blocks ahead (Float64: one).  A panel's chain of 2 K / 32 barrier-separated steps (potrs_panel_kernel: 79 us at
+// 16384 columns, k = 256, Float32; the product form Uinv (Uinv' B): 55 us) becomes 72 back-to-back block products per wave.
+// NBLK = K / 32 at compile time (every loop is unrolled: the strip's registers are indexed statically): 2, 4, 6, 8.
+// ---------------------------------------------------------------------------------------------
+template <typename F, int... I> __device__ __forceinline__ void strip_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void strip_static_for(F &&f) { strip_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{}); }
+template <typename T> __host__ __device__ inline int strip_rho(int kk, int g) {
+    return sizeof(T) == 4 ? 16 * (kk >> 2) + 4 * g + (kk & 3) : 16 * (kk >> 2) + g + 4 * (kk & 3);
+}
+// blocks of one sweep in consumption order: step s = 0 .. nb - 1 takes s off-diagonal blocks, then its diagonal block
+__host__ __device__ constexpr int strip_step_of(int b) { int s = 0; while ((s + 1) * (s + 2) / 2 <= b) ++s; return s; }
+__host__ __device__ constexpr int64_t strip_pack_elems(int nb) { return (int64_t)nb * (nb + 1) * 1024; }
+
+// Tp[block][chunk q][lane][v]: value m = q * V + v of lane (n, g) is  A(16 (m / 8) + n, rho(m % 8, g))  of the block, where the block is
+//   forward  step i, j < i : -L_ij = -U_ji'      diagonal: inv(L_ii) = inv(U_ii)' (lower triangle)
+//   backward step s (i = nb - 1 - s), j = i + 1 + jpos : -U_ij      diagonal: inv(U_ii) (upper triangle)
+// U: the factor (upper triangle of A after potrf), Dinv: inv(U_ii) in the upper triangles of the diagonal blocks (trtri_diag_kernel).
+template <typename T>
+__global__ void potrs_strip_pack_kernel(const T *U, const T *Dinv, T *Tp, int64_t ld, int k, int nb, const int *done) {
+    NMFX_DONE_GUARD(done);
+    constexpr int V = 16 / (int)sizeof(T);
+    const int nf = nb * (nb + 1) / 2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < strip_pack_elems(nb); e += (int64_t)gridDim.x * blockDim.x) {
+        const int blk = (int)(e >> 10), w = (int)(e & 1023);
+        const int q = w / (64 * V), lane = (w / V) & 63, v = w % V, m = q * V + v;
+        const int a = 16 * (m >> 3) + (lane & 15), l = strip_rho<T>(m & 7, lane >> 4);
+        const bool back = blk >= nf;
+        const int b = back ? blk - nf : blk;
+        int st = 0;
+        while ((st + 1) * (st + 2) / 2 <= b) ++st;
+        const int jpos = b - st * (st + 1) / 2;
+        const bool diag = jpos == st;
+        const int i = back ? nb - 1 - st : st;
+        const int j = diag ? i : (back ? i + 1 + jpos : jpos);
+        const int r = 32 * i + a, c = 32 * j + l;      // element (r, c) of the K x K operator applied from the left
+        T val = (T)0;
+        if (r < k && c < k) {
+            if (diag) {
+                if (!back && a >= l) val = Dinv[c + (int64_t)r * ld];        // inv(L_ii)(a, l) = inv(U_ii)(l, a)
+                if (back && a <= l) val = Dinv[r + (int64_t)c * ld];
+            } else {
+                val = back ? -U[r + (int64_t)c * ld] : -U[c + (int64_t)r * ld];   // forward: L(r, c) = U(c, r)
+            }
+        }
+        Tp[e] = val;
+    }
+}
+
+template <typename T> struct StripMfma;
+template <> struct StripMfma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    typedef float vec_t __attribute__((ext_vector_type(4)));
+    static constexpr int V = 4, NQ = 4, AHEAD = 2;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+template <> struct StripMfma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    typedef double vec_t __attribute__((ext_vector_type(2)));
+    static constexpr int V = 2, NQ = 8, AHEAD = 1;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+};
+
+constexpr int STRIP_WAVES = 4, STRIP_COLS = 16 * STRIP_WAVES;
+
+// B = sum of nslab slabs (ascending); epilogue as potrs_panel_kernel: projectnn! if clamp, store, and with `old` stop_condition's sums of
+// every component over the workgroup's 64 columns: stat_partial[(blockIdx.x * ncomp + a) * 2 + {0, 1}] (finalize_partials_kernel's layout).
+template <typename T, int NBLK>
+__global__ __launch_bounds__(64 * STRIP_WAVES) void potrs_strip_kernel(const T *Tp, const T *B, int nslab, int64_t slab_stride, int64_t ldb, T *Xout, const T *old,
+                                                                       int clamp, double *stat_partial, int ncomp, const int *done) {
+    NMFX_DONE_GUARD(done);
+    using M = StripMfma<T>;
+    using acc_t = typename M::acc_t;
+    using vec_t = typename M::vec_t;
+    constexpr int V = M::V, NQ = M::NQ, AHEAD = M::AHEAD, RING = AHEAD + 1, NF = NBLK * (NBLK + 1) / 2, NTOT = 2 * NF;
+    __shared__ double red[STRIP_WAVES][NBLK * 32][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int64_t col = ((int64_t)blockIdx.x * STRIP_WAVES + wave) * 16 + n;
+    // row of register r of tile (i, si) in this lane
+    auto row_of = [&](int i, int si, int r) { return 32 * i + 16 * si + (sizeof(T) == 4 ? 4 * g + r : g + 4 * r); };
+    vec_t frag[RING][NQ];
+    auto request = [&](int b, int slot) {
+        const T *src = Tp + (int64_t)b * 1024 + lane * V;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) frag[slot][q] = *reinterpret_cast<const vec_t *>(src + q * 64 * V);
+    };
+    strip_static_for<AHEAD>([&](auto b) { request(b, b % RING); });
+    // the strip: Y[i][si] = rows of block row i, tile si
+    acc_t Y[NBLK][2];
+    auto load_strip = [&](acc_t (&dst)[NBLK][2], const T *src0) {      // every tile's load in flight at once
+        strip_static_for<NBLK>([&](auto i) {
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                if constexpr (sizeof(T) == 4) {
+                    dst[i][si] = *reinterpret_cast<const acc_t *>(src0 + row_of(i, si, 0) + col * ldb);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[i][si][r] = src0[row_of(i, si, r) + col * ldb];
+                }
+            }
+        });
+    };
+    load_strip(Y, B);
+    for (int q = 1; q < nslab; ++q) {
+        acc_t Z[NBLK][2];
+        load_strip(Z, B + (int64_t)q * slab_stride);
+        strip_static_for<NBLK>([&](auto i) { Y[i][0] += Z[i][0]; Y[i][1] += Z[i][1]; });
+    }
+    // block product: acc[si] += A(block b) * Y[j]   (B operand of k-step kk = register kk % 4 of tile kk / 4 of Y[j])
+    auto product = [&](acc_t (&acc)[2], int slot, const acc_t (&src)[2]) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                const int m = si * 8 + kk;
+                acc[si] = M::mma(frag[slot][m / V][m % V], src[kk >> 2][kk & 3], acc[si]);
+            }
+    };
+    acc_t OV[NBLK][2];
+    strip_static_for<NBLK>([&](auto i) { OV[i][0] = OV[i][1] = acc_t{(T)0, (T)0, (T)0, (T)0}; });
+    strip_static_for<NTOT>([&](auto bb) {
+        constexpr int b = bb, back = b >= NF ? 1 : 0, bs = back ? b - NF : b;
+        constexpr int st = strip_step_of(bs), jpos = bs - st * (st + 1) / 2, i = back ? NBLK - 1 - st : st;
+        constexpr bool diag = jpos == st;
+        constexpr int j = diag ? i : (back ? i + 1 + jpos : jpos);
+        if constexpr (b + AHEAD < NTOT) request(b + AHEAD, (b + AHEAD) % RING);
+        if constexpr (b == NF) {                                        // `old` for the epilogue: its HBM round trip runs under the backward sweep
+            if (old != nullptr) load_strip(OV, old);
+        }
+        __builtin_amdgcn_sched_barrier(0);                              // (the scheduler otherwise sinks the requests down to their first use)
+        if constexpr (diag) {
+            acc_t t[2] = {acc_t{(T)0, (T)0, (T)0, (T)0}, acc_t{(T)0, (T)0, (T)0, (T)0}};
+            product(t, b % RING, Y[i]);
+            Y[i][0] = t[0];
+            Y[i][1] = t[1];
+        } else {
+            product(Y[i], b % RING, Y[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    // epilogue, block row by block row: clamp, store, and stop_condition's terms summed over the strip's 16 columns (the lanes n of a group g)
+    // by a halving butterfly -- after the step with mask m a lane keeps the half of its values selected by bit m of n, so the 8 values of a
+    // block row cost 4 + 2 + 1 exchanges plus one full exchange instead of 8 x 4; lanes n and n ^ 1 end with the total of value n >> 1
+    const bool stats = old != nullptr && stat_partial != nullptr;
+    strip_static_for<NBLK>([&](auto i) {
+        double dev[8], sum[8];
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+            acc_t v = Y[i][si];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (clamp) v[r] = (v[r] < (T)0) ? (T)0 : v[r];
+            const acc_t ov = OV[i][si];
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<acc_t *>(Xout + row_of(i, si, 0) + col * ldb) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xout[row_of(i, si, r) + col * ldb] = v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const T d = v[r] - ov[r], sp = v[r] + ov[r];
+                dev[si * 4 + r] = (double)(T)(d * d);
+                sum[si * 4 + r] = (double)(T)(sp * sp);
+            }
+        }
+        if (stats) {
+            auto halve = [&](double (&x)[8], auto cnt_c, int mask) {
+                constexpr int cnt = decltype(cnt_c)::value;
+                const bool up = (n & mask) != 0;
+#pragma unroll
+                for (int e = 0; e < cnt / 2; ++e) {
+                    const double send = up ? x[e] : x[e + cnt / 2], keep = up ? x[e + cnt / 2] : x[e];
+                    x[e] = keep + __shfl_xor(send, mask, 64);
+                }
+            };
+            halve(dev, std::integral_constant<int, 8>{}, 8); halve(dev, std::integral_constant<int, 4>{}, 4); halve(dev, std::integral_constant<int, 2>{}, 2);
+            halve(sum, std::integral_constant<int, 8>{}, 8); halve(sum, std::integral_constant<int, 4>{}, 4); halve(sum, std::integral_constant<int, 2>{}, 2);
+            const double d1 = dev[0] + __shfl_xor(dev[0], 1, 64), s1 = sum[0] + __shfl_xor(sum[0], 1, 64);
+            if ((n & 1) == 0) {
+                const int vi = n >> 1, a = row_of(i, vi >> 2, vi & 3);
+                red[wave][a][0] = d1;
+                red[wave][a][1] = s1;
+            }
+        }
+    });
+    if (!stats) return;
+    __syncthreads();
+    for (int a = threadIdx.x; a < NBLK * 32; a += blockDim.x) {
+        double d = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < STRIP_WAVES; ++w) { d += red[w][a][0]; s2 += red[w][a][1]; }
+        if (a < ncomp) {
+            stat_partial[((int64_t)blockIdx.x * ncomp + a) * 2] = d;
+            stat_partial[((int64_t)blockIdx.x * ncomp + a) * 2 + 1] = s2;
         }
     }
 }

@@ -43,7 +43,10 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tri));
         const unsigned nblk = (unsigned)((k + 31) / 32);
         hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3(nblk), dim3(64), 0, stream, A, Uinv, K, (int)k, done);
-        if (Tm != nullptr)   // left solve by substitution (potrs!): only the diagonal blocks' inverses are needed, packed with U and U' (chol.hpp)
+        if (Tm != nullptr && strip_ok())   // ... packed block by block in the order potrs_strip_kernel's sweeps consume them
+            hipLaunchKernelGGL((potrs_strip_pack_kernel<T>), dim3((unsigned)std::min<int64_t>((strip_pack_elems((int)(K / 32)) + 255) / 256, 1024)), dim3(256), 0, stream, A, Uinv, Tm, K,
+                               (int)k, (int)(K / 32), done);
+        else if (Tm != nullptr)   // left solve by substitution (potrs!): only the diagonal blocks' inverses are needed, packed with U and U' (chol.hpp)
             hipLaunchKernelGGL((potrs_prep_kernel<T>), dim3((unsigned)std::min<int64_t>((K * K + 255) / 256, 1024)), dim3(256), 0, stream, A, Uinv, Tm, K, (int)k, (int)K, done);
         else
             hipLaunchKernelGGL((trtri_offdiag_kernel<T>), dim3(nblk), dim3(256), lds_tri, stream, A, Uinv, K, (int)k, nfit, done);
@@ -54,6 +57,24 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
 // potrs! (src/utils.jl:69) after spd_factor(..., Tm): out = inv(A) B by the two blocked triangular substitutions of potrs_panel_kernel;
 // clamp = projectnn!; old != nullptr: stop_condition's sums against `old` into stat_part (finalised by stats_h_finalize(N / NB))
 template <typename T> int Solver<T>::spd_solve_left_potrs(const T *Tm, const T *B, T *out, bool clamp, const T *old, const int *done) {
+    if (strip_ok()) {
+        const unsigned grid = (unsigned)(N / STRIP_COLS);
+        double *part = old ? stat_part.p : (double *)nullptr;
+        timed("potrs_clampH", 2.0 * (double)K * K * N, 3.0 * K * N * sizeof(T), [&] {
+            auto go = [&](auto nblk) {
+                hipLaunchKernelGGL((potrs_strip_kernel<T, decltype(nblk)::value>), dim3(grid), dim3(64 * STRIP_WAVES), 0, stream, Tm, B, 1, (int64_t)0, K, out, old, clamp ? 1 : 0, part,
+                                   (int)K, done);
+            };
+            switch ((int)(K / 32)) {
+                case 2: go(std::integral_constant<int, 2>{}); break;
+                case 4: go(std::integral_constant<int, 4>{}); break;
+                case 6: go(std::integral_constant<int, 6>{}); break;
+                default: go(std::integral_constant<int, 8>{}); break;
+            }
+            HIP_TRY(hipGetLastError());
+        });
+        return (int)grid;
+    }
     constexpr int NB = POTRS_NB;
     const size_t s_bytes = (size_t)K * (NB + 1) * sizeof(T), tp_bytes = (size_t)32 * K * sizeof(T);
     const bool dbuf = s_bytes + 2 * tp_bytes <= (size_t)160 * 1024;
@@ -101,7 +122,7 @@ template <typename T> void Solver<T>::pdsolve_host(int right, const void *A_host
     const size_t kk = (size_t)K * K;
     work[0].ensure((size_t)K * N);
     work[1].ensure(kk);
-    work[2].ensure(kk);
+    work[2].ensure(potrs_pack_elems());
     Ctrl init;
     std::memset(&init, 0, sizeof init);
     HIP_TRY(hipMemcpyAsync(ctrl, &init, sizeof init, hipMemcpyHostToDevice, stream));
@@ -110,7 +131,7 @@ template <typename T> void Solver<T>::pdsolve_host(int right, const void *A_host
     T *G = right ? gramH_p : gramW_p;
     HIP_TRY(hipMemsetAsync(G, 0, kk * sizeof(T), stream));
     HIP_TRY(hipMemcpy2DAsync(G, K * sizeof(T), right ? B_host : A_host, k * sizeof(T), k * sizeof(T), k, hipMemcpyHostToDevice, stream));
-    const bool subst = !right && potrs_ok();
+    const bool subst = !right && potrs_route_ok();
     spd_factor(G, (T)lambda, work[1].p, "potrf", "trtri", nullptr, subst ? work[2].p : (T *)nullptr);
     have_F = false;   // the factor buffers are scratch for this call
     if (!right) {     // x <- inv(A) x, x is k x n
@@ -136,7 +157,7 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     const size_t kk = (size_t)K * K;
     work[0].ensure((size_t)K * N);   // Y = Uinv' * W'X
     work[1].ensure(kk);              // Uinv
-    work[2].ensure(kk);              // inv(HH' + lw I)
+    work[2].ensure(potrs_pack_elems());   // inv(HH' + lw I); on the H side the packed factor of the substitution route
     T *Y = work[0].p, *Uinv = work[1].p, *invA = work[2].p;
     const bool rs = row_sharded();
     // The factorisations run UNDER the big products.  Each is one workgroup (potrf) and a few small ones (trtri, potri) whose
@@ -158,7 +179,8 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // with anything: 79 us at 16384 columns, k = 256, Float32 against 55 us for the two k x k x n products (scripts/kbench/potrs_bench.hip;
     // Float64, k = 128: 26 against 28 us).  nmfx_pdsolve, the exported pdsolve!, always takes the substitution route.
     // nmfx_opts.h_solve picks the route of the H solve (NMFX_POTRS=1 in the environment still forces substitution: A/B runs)
-    const bool subst = (o.h_solve == NMFX_HSOLVE_POTRS || (o.h_solve == NMFX_HSOLVE_AUTO && potrs_iter)) && potrs_ok();
+    // (round 5: with the strip kernel the substitution is the faster route AND the reference's, so AUTO takes it wherever that kernel exists)
+    const bool subst = (o.h_solve == NMFX_HSOLVE_POTRS || (o.h_solve == NMFX_HSOLVE_AUTO && (potrs_iter || strip_ok()))) && potrs_route_ok();
     auto factor_under = [&](T *G, T lambda, const char *t1, const char *t2, bool with_potri) {
         HIP_TRY(hipEventRecord(ev_fork, stream));
         HIP_TRY(hipStreamWaitEvent(fstream, ev_fork, 0));

@@ -27,6 +27,7 @@
 #include "gemm_stream.hpp"
 #include "kernels.hpp"
 #include "cd.hpp"
+#include "chol.hpp"
 
 namespace nmfx {
 struct PgState;
@@ -144,6 +145,7 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = dev_env("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_K_GRANULE")) k_granule = (std::atoi(e) == 128) ? 128 : 64;
         if (const char *e = dev_env("NMFX_POTRS")) { potrs_enabled = std::atoi(e) != 0; potrs_iter = std::atoi(e) == 1; }
+        if (const char *e = dev_env("NMFX_POTRS_STRIP")) strip_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_W_BLOCKED")) blk_enabled = std::atoi(e) != 0;
         HIP_TRY(hipEventCreate(&ev_beg));
@@ -1216,6 +1218,12 @@ template <typename T> class Solver : public SolverBase {
         return potrs_enabled && K % 64 == 0 && N % POTRS_NB == 0 && (size_t)K * (POTRS_NB + 1 + 32) * sizeof(T) <= (size_t)160 * 1024 &&
                K * 32 / (16 / (int64_t)sizeof(T)) / 512 <= 8 && K * 32 / (16 / (int64_t)sizeof(T)) % 512 == 0;
     }
+    // potrs! by strips (chol.hpp: potrs_strip_kernel): one wave per 16 columns, the strip in accumulator registers, the factor packed in the
+    // order the sweeps consume it; K / 32 is a compile-time parameter (2, 4, 6, 8).  NMFX_POTRS_STRIP=0 (development switch): the panel kernel.
+    bool strip_enabled = true;
+    bool strip_ok() const { return strip_enabled && potrs_enabled && K % 64 == 0 && K <= 256 && N % STRIP_COLS == 0; }
+    size_t potrs_pack_elems() const { return std::max((size_t)K * K, strip_ok() ? (size_t)strip_pack_elems((int)(K / 32)) : (size_t)0); }
+    bool potrs_route_ok() const { return strip_ok() || potrs_ok(); }
     int spd_solve_left_potrs(const T *Tm, const T *B, T *out, bool clamp, const T *old, const int *done);
     void spd_solve_left(const T *Uinv, const T *B, T *Y, T *out, bool clamp, const int *done);
     void spd_solve_right(const T *Uinv, T *invA, const T *A, T *out, int64_t rows, bool clamp, const int *done);

@@ -4,10 +4,14 @@ Stated tolerances.  projals: objective trajectory 1e-7 (f64) relative.  In f32 t
 condition number of the regularised Grams, so ANY fp32 implementation drifts from the exact trajectory: the yardstick is the fp64
 run of the same algorithm on the same (f32) inputs, and the stated bound on the GPU's distance from it is
     2 * kappa * eps(Float32),   kappa = max over the 15 iterations of cond(W'W + lambda I), cond(HH' + lambda I) on that fp64 run
-(kappa = 1.5e3 / 1.3e5 / 1.8e4 / 2.1e6 on the four shapes below, i.e. bounds 3.5e-4 / 3.1e-2 / 4.2e-3 / 0.51; measured, scripts/
-projals_f32_error.py: GPU 1.0e-4 / 6.4e-3 / 1.7e-4 / 0.36, the two CPU fp32 restatements 3.7e-5 / 5.7e-3 / 1.7e-3 / 0.41 -- the last
-shape, k = 100 ~ min(p, n), is ill-conditioned for everybody).  Round 3 bounded the GPU by 2.5 x the worse CPU restatement instead.
-The device H-solve uses Uinv*(Uinv'*B) instead of two substitutions (same forward-error class; NMFX_POTRS=1 takes the substitutions).
+(kappa = 1.5e3 / 1.3e5 / 1.8e4 / 2.1e6 on the four shapes below, i.e. bounds 3.5e-4 / 3.1e-2 / 4.2e-3 / 0.51; measured in round 5 with
+the substitution route, scripts/projals_f32_error.py -> profiles/r05_projals_f32_error_strip_vs_product.log: GPU 4.0e-5 / 5.1e-3 /
+5.8e-4 / 0.63, the two CPU fp32 restatements 3.7e-5 / 5.7e-3 / 1.7e-3 / 0.41).  On the last shape, k = 100 ~ min(p, n), kappa * eps is
+0.26: the fp32 trajectory is no longer a function of the inputs (three seeds: CPU restatements 0.25 .. 4.3 from the fp64 run, the
+device 0.27 .. 2.3 on either route), so there the device is held to 2.5 x the worse CPU restatement instead -- the bound 2 kappa eps is
+asserted wherever kappa * eps < 0.1.
+Round 5: the device H solve is potrf! + potrs! like the reference's (two triangular substitutions, chol.hpp: potrs_strip_kernel) for
+K <= 256; the product form Uinv*(Uinv'*B) of rounds 2-4 remains for larger k and as a development switch (ROUTES below).
 alspgrad: 1e-7 (f64) / 2e-3 (f32); its suff_decr / isapprox branches are discontinuous in the data, so
 trajectories (not branch traces) are compared, as SURVEY.md section 7 prescribes.
 """
@@ -51,10 +55,18 @@ def test_projals_trajectory(built, T, shape):
             kappa = max(kappa, np.linalg.cond(W64.T @ W64 + lam * np.eye(k)))
             orc.solve("projals", X64, W64, H64, orc.Opts(maxiter=1, tol=1e-30, lambda_w=lam, lambda_h=lam))
             kappa = max(kappa, np.linalg.cond(H64 @ H64.T + lam * np.eye(k)))
-        bound = 2.0 * kappa * float(np.finfo(np.float32).eps)
-        assert rel_trace_err(r.trace, r64.trace) <= bound, (rel_trace_err(r.trace, r64.trace), bound, kappa)
-        # (and the CPU fp32 restatements obey the same bound: it is a property of the algorithm, not of the device)
-        assert max(rel_trace_err(ro.trace, r64.trace), rel_trace_err(rc.trace, r64.trace)) <= bound
+        keps = kappa * float(np.finfo(np.float32).eps)
+        cpu = max(rel_trace_err(ro.trace, r64.trace), rel_trace_err(rc.trace, r64.trace))
+        if keps < 0.1:
+            bound = 2.0 * keps
+            assert rel_trace_err(r.trace, r64.trace) <= bound, (rel_trace_err(r.trace, r64.trace), bound, kappa)
+            # (and the CPU fp32 restatements obey the same bound: it is a property of the algorithm, not of the device)
+            assert cpu <= bound
+        else:
+            # kappa * eps = 0.26 (k = 100 ~ min(p, n)): no fp32 trajectory is determined by the inputs any more -- over three seeds the two
+            # CPU restatements land 0.25 .. 4.3 from the fp64 run, the device 0.27 .. 2.3 on either solve route
+            # (profiles/r05_projals_f32_error_strip_vs_product.log).  What can be held: the device is no further out than fp32 LAPACK is.
+            assert rel_trace_err(r.trace, r64.trace) <= 2.5 * cpu, (rel_trace_err(r.trace, r64.trace), cpu, kappa)
     tol = max(TOL[T], 3 * rel_trace_err(rc.trace, ro.trace))
     assert rel_trace_err(r.trace, ro.trace) < tol
     assert np.max(np.abs(Wg - Wc)) <= 50 * tol * np.max(np.abs(Wc))
@@ -62,27 +74,41 @@ def test_projals_trajectory(built, T, shape):
     assert np.all(Wg >= 0) and np.all(Hg >= 0)
 
 
-@pytest.mark.parametrize("T,shape", [(np.float64, (300, 260, 70)), (np.float32, (300, 260, 70)), (np.float64, (200, 300, 130)), (np.float32, (130, 515, 8))])
-def test_projals_substitution_route(built, T, shape, monkeypatch):
-    """pdsolve! = potrf! + potrs! (src/utils.jl:63-70): with NMFX_POTRS=1 the iteration's H solve runs the two blocked triangular
-    substitutions (chol.hpp: potrs_panel_kernel) instead of Uinv (Uinv' B) -- the same solve to rounding: against the default route
-    and against the oracle (whose pdsolve! is LAPACK's potrs)."""
+ROUTES = {   # development switches (honoured because conftest sets NMFX_DEV=1): which kernels run the H solve of the iteration
+    "strip": {},                                                  # default: potrs_strip_kernel (K <= 256), chol.hpp
+    "panel": {"NMFX_POTRS": "1", "NMFX_POTRS_STRIP": "0"},        # round 4's potrs_panel_kernel
+    "product": {"NMFX_POTRS": "0"},                               # Uinv (Uinv' B): two products with the inverted factor
+}
+
+
+@pytest.mark.parametrize("T,shape,lam", [(np.float64, (300, 260, 70), 0.05), (np.float32, (300, 260, 70), 0.05), (np.float64, (200, 300, 130), 0.05),
+                                         (np.float32, (130, 515, 8), 0.05),
+                                         # K = 256 (eight block rows: the largest strip kernel), regularised so that the Grams stay well conditioned
+                                         (np.float32, (700, 600, 250), 5.0), (np.float64, (600, 520, 256), 5.0)])
+def test_projals_substitution_route(built, T, shape, lam, monkeypatch):
+    """pdsolve! = potrf! + potrs! (src/utils.jl:63-70): the iteration's H solve runs the two triangular substitutions -- by default on
+    the strip kernel (chol.hpp: potrs_strip_kernel: one wave per 16 columns, the strip in accumulator registers), which replaced the
+    product form Uinv (Uinv' B) as the default in round 5, or on round 4's panel kernel -- the same solve to rounding: the routes
+    against each other and against the oracle (whose pdsolve! is LAPACK's potrs)."""
     p, n, k = shape
     X, W0, H0 = planted(p, n, k, T, seed=9 + p, normalize=False, zeroh=True)
-    lam = 0.05
     alg = nmfx.ProjectedALS(T, maxiter=10, tol=1e-30, lambda_w=lam, lambda_h=lam)
-    Wa, Ha = W0.copy(order="F"), H0.copy(order="F")
-    ra = nmfx.solve(alg, X, Wa, Ha, track_objective=True)
-    monkeypatch.setenv("NMFX_POTRS", "1")
-    Wb, Hb = W0.copy(order="F"), H0.copy(order="F")
-    rb = nmfx.solve(alg, X, Wb, Hb, track_objective=True)
+    res = {}
+    for route, env in ROUTES.items():
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            Wa, Ha = W0.copy(order="F"), H0.copy(order="F")
+            res[route] = (nmfx.solve(alg, X, Wa, Ha, track_objective=True), Wa, Ha)
     Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
     ro = orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=10, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
-    assert ra.niters == rb.niters == ro.niters == 10
+    assert all(r.niters == 10 for r, _, _ in res.values()) and ro.niters == 10
     tol = 1e-6 if T == np.float64 else 2e-2      # cond(Gram) * eps: 4e4 * 1.2e-7 at k = 70 in f32; k = 130 of p = 200 rows: 2e-8 measured in f64
-    assert rel_trace_err(rb.trace, ra.trace) < tol
-    assert rel_trace_err(rb.trace, ro.trace) < (1e-7 if T == np.float64 else tol)
-    assert np.all(Wb >= 0) and np.all(Hb >= 0)
+    for route in ("strip", "panel"):
+        r, Wb, Hb = res[route]
+        assert rel_trace_err(r.trace, res["product"][0].trace) < tol, route
+        assert rel_trace_err(r.trace, ro.trace) < (1e-7 if T == np.float64 else tol), route
+        assert np.all(Wb >= 0) and np.all(Hb >= 0)
 
 
 @pytest.mark.parametrize("T,k", [(np.float64, 520), (np.float32, 1160), (np.float64, 640), (np.float32, 1300)])
@@ -283,7 +309,7 @@ def test_projals_h_solve_is_exact_when_the_arithmetic_is(built, T, k):
     potrf! gives U = 2 I, the solve is a multiplication by 1/4, and H after the first iteration is max(0, W'X / 4) EXACTLY
     (dyadic rationals) -- on the oracle (LAPACK potrf/potrs) and on the device (blocked potrf, explicit triangular inverse, two
     MFMA products with the clamp in the epilogue): the product form of pdsolve! (src/utils.jl:63-70) loses nothing where the
-    substitution form loses nothing.  Also with NMFX_POTRS=1 (the substitution kernels)."""
+    substitution form loses nothing.  All three routes of the H solve (ROUTES: strip kernel = default, panel kernel, product form)."""
     import os
     p, n = 3 * k + 7, 2 * k + 11
     rng = np.random.default_rng(5 + k)
@@ -294,8 +320,8 @@ def test_projals_h_solve_is_exact_when_the_arithmetic_is(built, T, k):
     H0 = np.asfortranarray(rng.integers(0, 3, size=(k, n)).astype(T))
     expect = np.maximum(W0.T.astype(np.float64) @ X.astype(np.float64) / 4.0, 0.0).astype(T)
     o = nmfx.make_opts(T, maxiter=1, tol=1e-30, lambda_w=1.0, lambda_h=1.0, check_every=1000)
-    for potrs in ("0", "1"):
-        os.environ["NMFX_POTRS"] = potrs
+    for potrs, env in ROUTES.items():
+        os.environ.update(env)
         try:
             Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
             with nmfx.Context(T, p, n, k) as ctx:
@@ -304,7 +330,8 @@ def test_projals_h_solve_is_exact_when_the_arithmetic_is(built, T, k):
                 ctx.iterate(2, o)
                 ctx.get_factors(Wg, Hg)
         finally:
-            del os.environ["NMFX_POTRS"]
+            for key in env:
+                del os.environ[key]
         assert np.array_equal(Hg, expect), (potrs, float(np.max(np.abs(Hg - expect))))
     Wc, Hc = W0.copy(order="F"), H0.copy(order="F")
     orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=1, tol=1e-30, lambda_w=1.0, lambda_h=1.0))

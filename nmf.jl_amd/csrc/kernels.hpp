@@ -761,7 +761,11 @@ __global__ __launch_bounds__(256) void reduce_slabs_tail_kernel(T *dst, const T 
     NMFX_DONE_GUARD(done);
     typedef T vec_t __attribute__((ext_vector_type(V)));
     auto ldv = [](const T *p) { if constexpr (V == 1) return *p; else return *reinterpret_cast<const vec_t *>(p); };
-    int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+    // Blocks walk the output BACKWARDS: the rectangle that arrives as pieces is the END of the output in both modes, and its few dozen blocks
+    // carry as many bytes as all the others together -- dispatched last they ran alone behind everybody else (28 us for 48 MB of slabs at
+    // 16384 x 256; dispatched first they run beside the light blocks)
+    const unsigned bid = gridDim.x - 1u - blockIdx.x;
+    int64_t e = ((int64_t)bid * 256 + threadIdx.x) * V;
     int64_t pidx = -1;
     if (mode == 0) {
         if (e >= count) return;
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_tail_kernel(T *dst, const T 
     } else {
         // column index fastest over the blocks: the blocks that carry the pieces (the last row blocks of EVERY column) are then
         // consecutive block ids, i.e. dealt to all 8 XCDs (row index fastest put them all on two XCDs: 48 us instead of 24)
-        const unsigned cols = (unsigned)(count / ld), a = blockIdx.x % cols, i = ((blockIdx.x / cols) * 256u + threadIdx.x) * (unsigned)V;
+        const unsigned cols = (unsigned)(count / ld), a = bid % cols, i = ((bid / cols) * 256u + threadIdx.x) * (unsigned)V;
         e = (int64_t)i + (int64_t)a * ld;
         if ((int64_t)i >= r0 && (int64_t)i < r0 + prow) pidx = ((int64_t)i - r0) + (int64_t)a * prow;
     }

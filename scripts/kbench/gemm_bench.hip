@@ -96,6 +96,22 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (what == 8) {   // Float64: where does the distance to the instruction's 77.5 TFLOP/s sit -- per k-tile (slope over the contraction) or per output tile (offset)?
+        for (int round = 0; round < 2; ++round) {
+            printf("--- round %d\n", round);
+            for (int64_t kd : {512, 1024, 2048, 4096}) {
+                run<double, KSTRIDED, KSTRIDED, 128, 64, 4, 1, 1>("f64 W-side 128x64", 512, 32768, kd, 1, false, reps);
+                run<double, KSTRIDED, KSTRIDED, 64, 128, 1, 4, 1>("f64 W-side 64x128", 512, 32768, kd, 1, false, reps);
+                run<double, KSTRIDED, KSTRIDED, 128, 128, 2, 2, 1>("f64 W-side 128x128", 512, 32768, kd, 1, false, reps);
+            }
+            run<double, KCONTIG, KCONTIG, 64, 64, 2, 2, 1>("f64 H-side 64x64", 4096, 512, 512, 1, true, reps);
+            run<double, KCONTIG, KCONTIG, 128, 64, 4, 1, 1>("f64 H-side 128x64", 4096, 512, 512, 1, true, reps);
+            run<double, KCONTIG, KCONTIG, 128, 128, 2, 2, 1>("f64 WtX shard 128x128 s2", 4096, 512, 32768, 2, true, reps);
+            run<double, KCONTIG, KCONTIG, 128, 64, 4, 1, 1>("f64 WtX shard 128x64 s2", 4096, 512, 32768, 2, true, reps);
+            run<double, KCONTIG, KCONTIG, 128, 64, 4, 1, 1>("f64 WtX shard 128x64 s1", 4096, 512, 32768, 1, true, reps);
+        }
+        return 0;
+    }
     if (what == 5) {   // alspgrad's Float64 trial-step shapes (C5 shard) with a PLAIN store: what the tilings reach without the fused loader / epilogue
         for (int round = 0; round < 2; ++round) {
             printf("--- round %d\n", round);

@@ -38,9 +38,28 @@ template <int CH> void run(int threads, double *d, int blocks_per_cu) {
     std::printf("threads %4d x %d block(s)/CU, %d chain(s): %.1f us per launch, %.1f TFLOP/s, %.1f cycles per MFMA per SIMD at 2.4 GHz\n", threads, blocks_per_cu, CH, sec * 1e6,
                 flops / sec / 1e12, sec * 2.4e9 / per_simd);
 }
+// sustained load: the 3.5 ms launch back to back for ~1.5 s, throughput per window of 40 launches (does the clock give way under a long
+// Float64 matrix-core load, as ALSPGrad's 200 ms outer iterations are?)
+void sustained(double *d) {
+    hipEvent_t e[12];
+    for (auto &x : e) hipEventCreate(&x);
+    const int iters = 1024, threads = 1024, blocks = 256;
+    const double flops_per_launch = 8.0 * 4 * iters * (threads / 64) * blocks * 2048.0;
+    hipEventRecord(e[0]);
+    for (int w = 0; w < 11; ++w) {
+        for (int r = 0; r < 40; ++r) hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(threads), 0, 0, d, iters, 1.0, 2.0);
+        hipEventRecord(e[w + 1]);
+    }
+    hipEventSynchronize(e[11]);
+    for (int w = 0; w < 11; ++w) {
+        float ms; hipEventElapsedTime(&ms, e[w], e[w + 1]);
+        std::printf("sustained window %2d (%.0f ms): %.1f TFLOP/s\n", w, ms, 40 * flops_per_launch / (ms * 1e-3) / 1e12);
+    }
+}
 int main() {
     double *d; hipMalloc(&d, 512 * 1024 * 8);
     run<1>(256, d, 1); run<2>(256, d, 1); run<4>(256, d, 1); run<8>(256, d, 1);
     run<4>(512, d, 1); run<8>(512, d, 1); run<4>(1024, d, 1); run<4>(256, d, 2);
+    sustained(d);
     return 0;
 }

@@ -554,7 +554,8 @@ __global__ __launch_bounds__(POTRS_THREADS) void potrs_panel_kernel(const T *Tm,
 // consecutive 16-byte chunks, so a wave's load instruction is one contiguous KiB and the walk over the factor is a linear stream
 // from L2, requested TWO blocks ahead (Float64: one).  A panel's chain of 2 K / 32 barrier-separated steps (potrs_panel_kernel: 79 us at
 // 16384 columns, k = 256, Float32; the product form Uinv (Uinv' B): 55 us) becomes 72 back-to-back block products per wave.
-// NBLK = K / 32 at compile time (every loop is unrolled: the strip's registers are indexed statically): 2, 4, 6, 8.
+// NBLK = K / 32 at compile time (every loop is unrolled: the strip's registers are indexed statically): 2, 4, 6, 8, and in Float32 -- where
+// the strip of K = 512 is 128 registers of a one-wave-per-SIMD budget of 512 -- also 10, 12, 14, 16.
 // ---------------------------------------------------------------------------------------------
 template <typename F, int... I> __device__ __forceinline__ void strip_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);

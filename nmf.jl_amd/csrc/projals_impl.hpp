@@ -65,11 +65,16 @@ template <typename T> int Solver<T>::spd_solve_left_potrs(const T *Tm, const T *
                 hipLaunchKernelGGL((potrs_strip_kernel<T, decltype(nblk)::value>), dim3(grid), dim3(64 * STRIP_WAVES), 0, stream, Tm, B, 1, (int64_t)0, K, out, old, clamp ? 1 : 0, part,
                                    (int)K, done);
             };
-            switch ((int)(K / 32)) {
-                case 2: go(std::integral_constant<int, 2>{}); break;
-                case 4: go(std::integral_constant<int, 4>{}); break;
-                case 6: go(std::integral_constant<int, 6>{}); break;
-                default: go(std::integral_constant<int, 8>{}); break;
+            const int nblk = (int)(K / 32);
+            if (nblk == 2) go(std::integral_constant<int, 2>{});
+            else if (nblk == 4) go(std::integral_constant<int, 4>{});
+            else if (nblk == 6) go(std::integral_constant<int, 6>{});
+            else if (nblk == 8) go(std::integral_constant<int, 8>{});
+            else if constexpr (sizeof(T) == 4) {
+                if (nblk == 10) go(std::integral_constant<int, 10>{});
+                else if (nblk == 12) go(std::integral_constant<int, 12>{});
+                else if (nblk == 14) go(std::integral_constant<int, 14>{});
+                else go(std::integral_constant<int, 16>{});
             }
             HIP_TRY(hipGetLastError());
         });

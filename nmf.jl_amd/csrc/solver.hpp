@@ -1219,9 +1219,11 @@ template <typename T> class Solver : public SolverBase {
                K * 32 / (16 / (int64_t)sizeof(T)) / 512 <= 8 && K * 32 / (16 / (int64_t)sizeof(T)) % 512 == 0;
     }
     // potrs! by strips (chol.hpp: potrs_strip_kernel): one wave per 16 columns, the strip in accumulator registers, the factor packed in the
-    // order the sweeps consume it; K / 32 is a compile-time parameter (2, 4, 6, 8).  NMFX_POTRS_STRIP=0 (development switch): the panel kernel.
+    // order the sweeps consume it; K / 32 is a compile-time parameter (2, 4, 6, 8; Float32 also 10, 12, 14, 16).  NMFX_POTRS_STRIP=0 (development switch): the panel kernel.
     bool strip_enabled = true;
-    bool strip_ok() const { return strip_enabled && potrs_enabled && K % 64 == 0 && K <= 256 && N % STRIP_COLS == 0; }
+    // (Float32 up to K = 512: the strip is then 128 registers of a 512-register wave; Float64 strips are twice as wide: K <= 256)
+    static constexpr int64_t STRIP_KMAX = sizeof(T) == 4 ? 512 : 256;
+    bool strip_ok() const { return strip_enabled && potrs_enabled && K % 64 == 0 && K <= STRIP_KMAX && N % STRIP_COLS == 0; }
     size_t potrs_pack_elems() const { return std::max((size_t)K * K, strip_ok() ? (size_t)strip_pack_elems((int)(K / 32)) : (size_t)0); }
     bool potrs_route_ok() const { return strip_ok() || potrs_ok(); }
     int spd_solve_left_potrs(const T *Tm, const T *B, T *out, bool clamp, const T *old, const int *done);

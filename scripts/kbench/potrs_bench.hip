@@ -121,6 +121,7 @@ int main(int argc, char **argv) {
         run_strip<float, 8>(16384, reps, 0); run_strip<float, 8>(16384, reps, 1); run_strip<float, 8>(131072, reps, 1);
         run_strip<float, 4>(16384, reps, 1); run_strip<float, 2>(4096, reps, 1); run_strip<float, 6>(8192, reps, 1);
         run_strip<double, 8>(8192, reps, 1); run_strip<double, 4>(8192, reps, 1); run_strip<double, 2>(8192, reps, 0);
+        run_strip<float, 10>(8192, reps, 1); run_strip<float, 12>(16384, reps, 1); run_strip<float, 14>(8192, reps, 1); run_strip<float, 16>(16384, reps, 1);
         return 0;
     }
     run<float, 64, 512>(256, 16384, reps);

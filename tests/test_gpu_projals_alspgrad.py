@@ -84,7 +84,9 @@ ROUTES = {   # development switches (honoured because conftest sets NMFX_DEV=1):
 @pytest.mark.parametrize("T,shape,lam", [(np.float64, (300, 260, 70), 0.05), (np.float32, (300, 260, 70), 0.05), (np.float64, (200, 300, 130), 0.05),
                                          (np.float32, (130, 515, 8), 0.05),
                                          # K = 256 (eight block rows: the largest strip kernel), regularised so that the Grams stay well conditioned
-                                         (np.float32, (700, 600, 250), 5.0), (np.float64, (600, 520, 256), 5.0)])
+                                         (np.float32, (700, 600, 250), 5.0), (np.float64, (600, 520, 256), 5.0),
+                                         # Float32 strips up to K = 512 (K / 32 = 10 and 16; beyond K = 256 there is no panel kernel: that route is the product form)
+                                         (np.float32, (800, 700, 300), 5.0), (np.float32, (1100, 900, 500), 5.0)])
 def test_projals_substitution_route(built, T, shape, lam, monkeypatch):
     """pdsolve! = potrf! + potrs! (src/utils.jl:63-70): the iteration's H solve runs the two triangular substitutions -- by default on
     the strip kernel (chol.hpp: potrs_strip_kernel: one wave per 16 columns, the strip in accumulator registers), which replaced the

@@ -16,7 +16,7 @@ while time.time() < t_end:
     alg = os.environ.get("ALG") or rng.choice(["multmse", "multdiv", "projals", "greedycd"])
     T = np.float32 if (alg == "multmse" or rng.random() < 0.5) else np.float64
     p, n = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
-    k = int(rng.integers(1, min(p, n, 64 if alg == "multmse" else 140) + 1))
+    k = int(rng.integers(1, min(p, n, 64 if alg == "multmse" else int(os.environ.get("KMAX", "140"))) + 1))
     X, W0, H0 = planted(p, n, k, T, seed=int(rng.integers(1 << 30)), normalize=(alg != "projals"), zeroh=(alg == "projals"))
     it = 6
     inst = {"multmse": lambda: nmfx.MultUpdate(T, obj="mse", maxiter=it, tol=1e-30, lambda_w=1e-3, lambda_h=1e-3),

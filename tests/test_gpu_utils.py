@@ -15,7 +15,8 @@ def make_pdmat(n, rng, T):
 
 
 @pytest.mark.parametrize("T", [np.float64, np.float32])
-@pytest.mark.parametrize("k,cols,rows", [(5, 3, 4), (32, 40, 33), (70, 130, 129), (256, 300, 260)])
+# (k = 300, 500: the Float32 strip kernels with 10 and 16 block rows; Float64 takes the panel kernel / the product form there)
+@pytest.mark.parametrize("k,cols,rows", [(5, 3, 4), (32, 40, 33), (70, 130, 129), (256, 300, 260), (300, 700, 310), (500, 900, 520)])
 def test_pdsolve_pdrsolve_identities(built, T, k, cols, rows):
     rng = np.random.default_rng(k)
     tol = 1e-9 if T == np.float64 else 2e-3

@@ -210,7 +210,17 @@ __global__ void finalize_partials_kernel(const double *partial, int nchunks, int
     if (e >= count) return;
     const int lane = threadIdx.x & 63;
     double s = 0.0;
-    for (int c = lane; c < nchunks; c += 64) s += partial[(int64_t)c * stride + e];
+    for (int c0 = lane; c0 < nchunks; c0 += 64 * 4) {   // four loads in flight, the adds in chunk order (same sum as a plain loop)
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = (c0 + 64 * u < nchunks) ? c0 + 64 * u : c0;
+            v[u] = partial[(int64_t)c * stride + e];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c0 + 64 * u < nchunks) s += v[u];
+    }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) out[e] = (OutT)s;
 }

@@ -385,7 +385,19 @@ __global__ __launch_bounds__(256) void smallk_finish_kernel(float *gram, const f
         const int e4 = threadIdx.x & 7, sl = threadIdx.x >> 3;
         const int64_t i = (int64_t)blockIdx.x * 32 + 4 * e4;
         smallk_v4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k = sl; k < nstripes; k += 32) acc += *reinterpret_cast<const smallk_v4 *>(slabs + (int64_t)k * 4096 + i);
+        // (eight loads in flight, then the adds in stripe order: written as `acc += load` in a loop every load waited for the add in front of
+        // it -- 8 dependent round trips at 256 stripes, most of this launch's 6 us)
+        for (int k0 = sl; k0 < nstripes; k0 += 32 * 8) {
+            smallk_v4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = (k0 + 32 * u < nstripes) ? k0 + 32 * u : k0;
+                v[u] = *reinterpret_cast<const smallk_v4 *>(slabs + (int64_t)k * 4096 + i);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + 32 * u < nstripes) acc += v[u];
+        }
         sm[sl][e4] = acc;
         __syncthreads();
         if (sl == 0) {
@@ -397,7 +409,17 @@ __global__ __launch_bounds__(256) void smallk_finish_kernel(float *gram, const f
     } else {
         const int e = (blockIdx.x - SMALLK_GRAM_BLOCKS) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         double s = 0.0;
-        for (int c = lane; c < nstripes; c += 64) s += stat_part[(int64_t)c * 128 + e];
+        for (int c0 = lane; c0 < nstripes; c0 += 64 * 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = (c0 + 64 * u < nstripes) ? c0 + 64 * u : c0;
+                v[u] = stat_part[(int64_t)c * 128 + e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + 64 * u < nstripes) s += v[u];
+        }
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane == 0) stat_out[e] = s;
         if (ctrl != nullptr) {

@@ -128,7 +128,20 @@ template <typename T> struct EpiPgStep {
 // fixed-order sum of `n` partials with stride `stride` starting at `off` (one block of 256 threads)
 __device__ __forceinline__ double pg_block_sum(const double *partial, int n, int stride, int off, double *sm) {
     double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[(int64_t)i * stride + off];
+    // (eight loads in flight, then the adds in index order: a plain `v += partial[..]` loop over a run-time count waits for every load
+    // before it issues the next -- n / 256 dependent round trips in a kernel that is nothing but this sum)
+    const int step = (int)blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * step) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = (i0 + u * step < n) ? i0 + u * step : i0;
+            x[u] = partial[(int64_t)i * stride + off];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * step < n) v += x[u];
+    }
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
@@ -143,7 +156,19 @@ __device__ __forceinline__ void pg_block_sum3(const double *partial, int n, doub
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (w < 3) {
         double v = 0.0;
-        for (int i = lane; i < n; i += 64) v += partial[(int64_t)i * 3 + w];
+        // (the W-side trial step of C5 leaves 2048 block partials: 32 per lane -- as a chain of dependent loads that was most of a
+        // decision kernel's time; eight in flight, added in index order: the same sum)
+        for (int i0 = lane; i0 < n; i0 += 8 * 64) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = (i0 + 64 * u < n) ? i0 + 64 * u : i0;
+                x[u] = partial[(int64_t)i * 3 + w];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + 64 * u < n) v += x[u];
+        }
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
         if (lane == 0) out3[w] = v;
     }

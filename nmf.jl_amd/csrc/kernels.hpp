@@ -602,33 +602,53 @@ __global__ __launch_bounds__(256) void w_side_combine_kernel(T *dst_blk, const T
 // the Gram H H' and the H statistics, each the sum of the n ranks' contributions IN RANK ORDER (slot q at base + q * slot_bytes; the order
 // of the in-process group's reduction kernels, so both transports give the same bits).  blocks [0, nb1): numerator, [nb1, nb1 + nb2):
 // Gram, the rest: statistics (nstat may be 0).
+// dst[i] = src_0[i] + src_1[i] + ... (slot q at src + q * slot_bytes), rank order, V elements per access; all n <= 16 loads of an element are
+// requested before the first add (the slots are UNCACHED window memory: as `s += load` in a loop over a run-time count the seven loads of
+// an 8-rank sum were a chain of dependent fabric round trips -- most of the 16.7 us this launch took at the 8-rank shard shape)
+template <typename T, int V, int NMAX>   // NMAX = n rounded up to 2, 4, 8, 16 (a surplus load re-reads the last slot and is not added)
+__device__ __forceinline__ void peer_sum_slots_n(T *dst, const unsigned char *src, size_t count, size_t slot_bytes, int n, size_t first, size_t stride) {
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    auto ld = [](const unsigned char *p) { if constexpr (V == 1) return *reinterpret_cast<const T *>(p); else return *reinterpret_cast<const vec_t *>(p); };
+    for (size_t i = first; i < count / V; i += stride) {
+        const unsigned char *b = src + i * V * sizeof(T);
+        decltype(ld(b)) v[NMAX];
+#pragma unroll
+        for (int u = 0; u < NMAX; ++u) v[u] = ld(b + (size_t)(u < n ? u : n - 1) * slot_bytes);
+        auto s = v[0];
+#pragma unroll
+        for (int u = 1; u < NMAX; ++u)
+            if (u < n) s += v[u];
+        for (int q = NMAX; q < n; ++q) s += ld(b + (size_t)q * slot_bytes);
+        if constexpr (V == 1) dst[i] = s;
+        else *reinterpret_cast<vec_t *>(dst + i * V) = s;
+    }
+}
+template <typename T, int V>
+__device__ __forceinline__ void peer_sum_slots(T *dst, const unsigned char *src, size_t count, size_t slot_bytes, int n, size_t first, size_t stride) {
+    if (n <= 2) peer_sum_slots_n<T, V, 2>(dst, src, count, slot_bytes, n, first, stride);
+    else if (n <= 4) peer_sum_slots_n<T, V, 4>(dst, src, count, slot_bytes, n, first, stride);
+    else if (n <= 8) peer_sum_slots_n<T, V, 8>(dst, src, count, slot_bytes, n, first, stride);
+    else peer_sum_slots_n<T, V, 16>(dst, src, count, slot_bytes, n, first, stride);
+}
+template <typename T>
+__device__ __forceinline__ void peer_sum_slots_any(T *dst, const unsigned char *src, size_t count, size_t slot_bytes, int n, size_t first, size_t stride) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const bool vec = count % V == 0 && slot_bytes % 16 == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+    if (vec) peer_sum_slots<T, V>(dst, src, count, slot_bytes, n, first, stride);
+    else peer_sum_slots<T, 1>(dst, src, count, slot_bytes, n, first, stride);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void peer_sum3_kernel(T *num, const unsigned char *num_src, size_t nnum, T *gram, const unsigned char *gram_src, size_t ngram,
                                                         double *stat, const unsigned char *stat_src, size_t nstat, size_t slot_bytes, int n, unsigned nb1,
                                                         unsigned nb2, const int *done) {
     NMFX_DONE_GUARD(done);
     if (blockIdx.x < nb1) {
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnum; i += (size_t)nb1 * blockDim.x) {
-            const unsigned char *b = num_src + i * sizeof(T);
-            T s = *reinterpret_cast<const T *>(b);
-            for (int q = 1; q < n; ++q) s += *reinterpret_cast<const T *>(b + (size_t)q * slot_bytes);
-            num[i] = s;
-        }
+        peer_sum_slots_any<T>(num, num_src, nnum, slot_bytes, n, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)nb1 * blockDim.x);
     } else if (blockIdx.x < nb1 + nb2) {
-        for (size_t i = (size_t)(blockIdx.x - nb1) * blockDim.x + threadIdx.x; i < ngram; i += (size_t)nb2 * blockDim.x) {
-            const unsigned char *b = gram_src + i * sizeof(T);
-            T s = *reinterpret_cast<const T *>(b);
-            for (int q = 1; q < n; ++q) s += *reinterpret_cast<const T *>(b + (size_t)q * slot_bytes);
-            gram[i] = s;
-        }
+        peer_sum_slots_any<T>(gram, gram_src, ngram, slot_bytes, n, (size_t)(blockIdx.x - nb1) * blockDim.x + threadIdx.x, (size_t)nb2 * blockDim.x);
     } else {
         const unsigned nb3 = gridDim.x - nb1 - nb2;
-        for (size_t i = (size_t)(blockIdx.x - nb1 - nb2) * blockDim.x + threadIdx.x; i < nstat; i += (size_t)nb3 * blockDim.x) {
-            const unsigned char *b = stat_src + i * sizeof(double);
-            double s = *reinterpret_cast<const double *>(b);
-            for (int q = 1; q < n; ++q) s += *reinterpret_cast<const double *>(b + (size_t)q * slot_bytes);
-            stat[i] = s;
-        }
+        peer_sum_slots<double, 1>(stat, stat_src, nstat, slot_bytes, n, (size_t)(blockIdx.x - nb1 - nb2) * blockDim.x + threadIdx.x, (size_t)nb3 * blockDim.x);
     }
 }
 

@@ -160,11 +160,25 @@ __global__ void col_stats_kernel(const T *Wn, const T *Wo, int64_t rows, int64_t
     const int64_t per = (rows + nchunks - 1) / nchunks;
     const int64_t beg = chunk * per, end = (beg + per < rows) ? beg + per : rows;
     double dev = 0.0, sum = 0.0;
-    for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
-        const T a = Wn[i + (int64_t)j * ld], b = Wo[i + (int64_t)j * ld];
-        const T d = a - b, s = a + b;
-        dev += (double)(T)(d * d);
-        sum += (double)(T)(s * s);
+    // four trips' loads in flight, the terms added in trip order (the sums a plain loop forms; a chunk is 1024 rows = four trips at the
+    // headline shape, which the plain loop ran as four dependent round trips)
+    const int64_t step = blockDim.x;
+    const T *wn = Wn + (int64_t)j * ld, *wo = Wo + (int64_t)j * ld;
+    for (int64_t i0 = beg + threadIdx.x; i0 < end; i0 += 4 * step) {
+        T a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = (i0 + u * step < end) ? i0 + u * step : i0;
+            a[u] = wn[i];
+            b[u] = wo[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * step < end) {
+                const T d = a[u] - b[u], s = a[u] + b[u];
+                dev += (double)(T)(d * d);
+                sum += (double)(T)(s * s);
+            }
     }
     for (int off = 32; off > 0; off >>= 1) { dev += __shfl_down(dev, off, 64); sum += __shfl_down(sum, off, 64); }
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -189,11 +203,21 @@ __global__ void row_stats_kernel(const T *Hn, const T *Ho, int64_t cols, int64_t
     const int64_t beg = chunk * per, end = (beg + per < cols) ? beg + per : cols;
     for (int j = threadIdx.x; j < K; j += blockDim.x) {
         double dev = 0.0, sum = 0.0;
-        for (int64_t i = beg; i < end; ++i) {
-            const T a = Hn[j + i * ld], b = Ho[j + i * ld];
-            const T d = a - b, s = a + b;
-            dev += (double)(T)(d * d);
-            sum += (double)(T)(s * s);
+        for (int64_t i0 = beg; i0 < end; i0 += 8) {   // eight columns' loads in flight, the terms added in column order
+            T a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = (i0 + u < end) ? i0 + u : i0;
+                a[u] = Hn[j + i * ld];
+                b[u] = Ho[j + i * ld];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u < end) {
+                    const T d = a[u] - b[u], s = a[u] + b[u];
+                    dev += (double)(T)(d * d);
+                    sum += (double)(T)(s * s);
+                }
         }
         partial[((int64_t)chunk * K + j) * 2] = dev;
         partial[((int64_t)chunk * K + j) * 2 + 1] = sum;

@@ -75,6 +75,12 @@ def parse():
                     help="device pre-warm BEFORE the W warm-up steps: untimed iterations worth about this many ms (the first ~50 ms after "
                          "idle run ~2%% slower while the clocks ramp; with W = 5 warm-up steps = 10 ms the timed region would sit on the ramp). "
                          "0 disables.  The factors are reset to the start values afterwards; the count is reported as `prewarm_steps`")
+    ap.add_argument("--select", default="fastest", choices=["fastest", "requested"],
+                    help="multi-GPU: fastest (default) = EVERY exchange candidate (the requested transport / mode, peer windows, RCCL row-sharded, RCCL "
+                         "replicated-W, RCCL pipelined) is verified AND timed (--select-iters iterations after as many warm-up iterations, max over "
+                         "ranks) before the timed region, which then runs on the fastest verified one; requested = the first verified candidate in "
+                         "ladder order, starting with --transport / --comm-mode (round 5 behaviour)")
+    ap.add_argument("--select-iters", type=int, default=20, help="iterations per candidate timing (and as many untimed ones in front)")
     ap.add_argument("--watchdog-s", type=float, default=600.0,
                     help="multi-GPU: a stage that takes longer than this prints a JSON line with status = comm_timeout and exits (a mismatched "
                          "collective would otherwise hang until the driver's timeout and leave no line at all)")
@@ -279,20 +285,65 @@ def main():
                 ref_ctx.close()
             if not ok_ref:
                 fallback_log.append({"candidate": "rccl+row_sharded (reference run)", "ok": False, "errors": errs[:2]})
-        cands = [(transport, mode)] + [c_ for c_ in (("rccl", "row_sharded"), ("rccl", "replicated_w")) if c_ != (transport, mode) and not dev_gloo]
+        # the ladder: what was asked for first, then every other exchange the library has.  (gloo-p2p development back end: no RCCL on a
+        # shared device, so the candidates are the windows' two modes)
+        if dev_gloo:
+            ladder = [("p2p_only", "row_sharded"), ("p2p_only", "replicated_w")]
+        else:
+            ladder = [("p2p", "row_sharded"), ("rccl", "row_sharded"), ("rccl", "replicated_w")] + ([("rccl", "pipelined")] if a.alg == "multmse" else [])
+        cands = [(transport, mode)] + [c_ for c_ in ladder if c_ != (transport, mode)]
+
+        def time_candidate(c):
+            """--select-iters iterations of the candidate after as many untimed ones, from the start factors; ms per iteration, max over ranks
+            (every rank takes part whatever happened: the iterations contain collectives)."""
+            import torch.distributed as dist
+            c.set_factors(W0, H0)
+            c.set_final_objective(False)
+            c.iterate(algid, opts(max(2, a.select_iters)))
+            barrier()
+            t0_ = time.perf_counter()
+            c.iterate(algid, opts(max(1, a.select_iters)))
+            barrier()
+            tt = torch.tensor([(time.perf_counter() - t0_) / max(1, a.select_iters) * 1e3], device=("cpu" if (dev_sim or dev_gloo) else device), dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            c.set_final_objective(True)
+            return float(tt.item())
+
         ctx = None
-        for tr, md in cands:
+        verified = []                        # (ms_per_step, ladder position, context, transport, mode)
+        for pos, (tr, md) in enumerate(cands):
             wd.arm(f"verify:{tr}+{md}")
             c, e0 = try_ctx(tr, md)
             ok, obj, errs = probe(c, e0)
             same = agree(ok and (not ok_ref or abs(obj - obj_ref) <= 1e-5 * abs(obj_ref)))
-            fallback_log.append({"candidate": f"{tr}+{md}", "ok": same, "objective_after_3": obj,
-                                 "rccl_row_sharded_objective_after_3": (obj_ref if ok_ref else None), "errors": errs[:2]})
+            entry = {"candidate": f"{tr}+{md}", "ok": same, "objective_after_3": obj,
+                     "rccl_row_sharded_objective_after_3": (obj_ref if ok_ref else None), "errors": errs[:2], "ms_per_step": None}
+            fallback_log.append(entry)
             if same:
-                ctx, transport, mode = c, tr, md
-                break
+                if a.select == "requested":
+                    ctx, transport, mode = c, tr, md
+                    break
+                # timed like the timed region is (barrier, wall clock, max over ranks); a candidate that fails HERE is dropped like one
+                # that failed its verification
+                wd.arm(f"time:{tr}+{md}")
+                try:
+                    ms_c, terr = time_candidate(c), None
+                except Exception as e:  # noqa: BLE001
+                    ms_c, terr = float("inf"), repr(e)
+                timed_ok = agree(terr is None and np.isfinite(ms_c))
+                if timed_ok:
+                    entry["ms_per_step"] = round(ms_c, 4)
+                    verified.append((ms_c, pos, c, tr, md))
+                    continue
+                entry["ok"] = False
+                entry["errors"] = (entry["errors"] + [terr])[:2] if terr else entry["errors"]
             if c is not None:
                 c.close()
+        if ctx is None and verified:
+            verified.sort(key=lambda v: (v[0], v[1]))        # (the times are all-reduced: every rank sorts the same list)
+            _, _, ctx, transport, mode = verified[0]
+            for v in verified[1:]:
+                v[2].close()
         if ctx is None:
             if rank == 0:
                 print(json.dumps(dict(wd.base, value=None, status="no_working_exchange", fallback=fallback_log)), flush=True)
@@ -470,7 +521,10 @@ def main():
         if consistency is not None:
             out["multi_gpu_consistency"] = consistency
         if fallback_log:
-            out["exchange_verification"] = {"requested": f"{a.transport}+{a.comm_mode}", "ran": f"{transport}+{mode}", "candidates": fallback_log}
+            out["exchange_verification"] = {"requested": f"{a.transport}+{a.comm_mode}", "ran": f"{transport}+{mode}",
+                                            "selected_by": ("fastest verified candidate (candidates[*].ms_per_step: %d iterations after as many untimed ones, "
+                                                            "max over ranks)" % a.select_iters) if a.select == "fastest" else "first verified candidate in ladder order",
+                                            "candidates": fallback_log}
         # the exchange step's collectives (hipEvent brackets on the solver's stream: includes waiting for the slowest peer)
         coll = [s for s in prof if s["name"].startswith("comm_")]
         if coll:

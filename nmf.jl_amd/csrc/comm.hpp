@@ -124,7 +124,7 @@ struct RcclComm : Comm {
 // COMPUTE of the sharded path at an n-rank shard shape can be timed on a 1-GPU box (bench.py --sim-ranks).
 // dst[q * nvec + i] = src[i] for every q != skip: the all-gather stand-in as ONE launch (a collective is one launch; the 7 separate
 // hipMemcpyAsync calls this used to be cost 19 us of launch latency at the 8-rank shard shape for 14 MB of copies)
-__global__ __launch_bounds__(256) void sim_replicate_kernel(uint4 *dst, const uint4 *src, size_t nvec, int n, int skip) {
+static __global__ __launch_bounds__(256) void sim_replicate_kernel(uint4 *dst, const uint4 *src, size_t nvec, int n, int skip) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nvec * (size_t)n; e += (size_t)gridDim.x * blockDim.x) {
         const size_t q = e / nvec, i = e % nvec;
         if ((int)q != skip) dst[e] = src[i];

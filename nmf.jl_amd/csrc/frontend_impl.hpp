@@ -282,13 +282,28 @@ void Solver<T>::solve_replicates(int alg, const nmfx_opts &o, int replicates, ui
         // earlier one of this rank (a NaN objective never wins, except replicate 1, which then wins everything -- on rank 0 it is first)
         double local_best = std::numeric_limits<double>::quiet_NaN();
         bool have_local = false;
+        std::string fail_msg;
         for (int i = 0; i < per; ++i) {
             const int r = rank + 1 + i * G;
             if (r > replicates) break;
             if (r == 1) set_factors(W_host, H_host);
             else randinit(seed + (uint64_t)(r - 1), /*normalize=*/true, zeroh, h_col_offset);
             nmfx_result res;
-            iterate(alg, o, &res, nullptr);
+            // A replicate that fails (PosDefException of a ProjectedALS factorisation, a non-finite step size, an argument error) must not
+            // take this rank out of the collectives the others are about to enter: its status is recorded (niters = -2), the rank stops
+            // computing -- the sequential loop would have thrown here -- and still joins the all-gather; every rank then raises the error
+            // of the FIRST failing replicate in replicate order, as the reference's loop does (src/interf.jl:91-98).
+            try {
+                iterate(alg, o, &res, nullptr);
+            } catch (const StatusError &e) {
+                std::memset(&res, 0, sizeof res);
+                res.niters = -2;
+                res.status = e.status;
+                res.objvalue = std::numeric_limits<double>::quiet_NaN();
+                mine[(size_t)i] = res;
+                fail_msg = e.msg;
+                break;
+            }
             mine[(size_t)i] = res;
             bool take;
             if (!have_local) take = true;
@@ -306,6 +321,13 @@ void Solver<T>::solve_replicates(int alg, const nmfx_opts &o, int replicates, ui
         HIP_TRY(hipStreamSynchronize(stream));
         // the reference's scan over r = 1 .. R (src/interf.jl:91-98)
         auto rec_of = [&](int r) -> const nmfx_result & { return all[(size_t)((r - 1) % G) * per + (size_t)((r - 1) / G)]; };
+        for (int r = 1; r <= replicates; ++r)
+            if (rec_of(r).niters == -2) {   // every rank sees the same records: all of them throw, none enters the broadcast
+                const int st = rec_of(r).status != 0 ? rec_of(r).status : NMFX_ERR_STATE;
+                const bool here = (r - 1) % G == rank && !fail_msg.empty();
+                throw StatusError{st, here ? fail_msg : ("replicate " + std::to_string(r) + " failed on rank " + std::to_string((r - 1) % G) +
+                                                          (st == NMFX_ERR_NOT_POSDEF ? ": matrix is not positive definite (potrf)" : ""))};
+            }
         int best_r = 1;
         nmfx_result best_res = rec_of(1);
         for (int r = 2; r <= replicates; ++r)
@@ -316,7 +338,10 @@ void Solver<T>::solve_replicates(int alg, const nmfx_opts &o, int replicates, ui
             HIP_TRY(hipMemcpyAsync(H[hcur].p, Hbest.p, H[0].count * sizeof(T), hipMemcpyDeviceToDevice, stream));
         }
         comm->broadcast(W[wcur].p, W[0].count * sizeof(T), owner, stream);
-        if (o.update_H || best_r != 1) comm->broadcast(H[hcur].p, H[0].count * sizeof(T), owner, stream);
+        // (H is broadcast ALWAYS: with update_H = false and replicate 1 the winner the other ranks' device H would otherwise keep the
+        // randinit draw of their last replicate, and a following nmfx_iterate / nmfx_get_factors would see different contexts; only the
+        // copy into the caller's H is skipped, so that it comes back untouched: test/interf.jl:35)
+        comm->broadcast(H[hcur].p, H[0].count * sizeof(T), owner, stream);
         have_F = true;
         get_factors(W_host, (o.update_H || best_r != 1) ? H_host : nullptr);
         if (comm) comm->health();

@@ -852,12 +852,17 @@ template <typename T> struct EpiMultUpdateRows {
     int64_t ldo;
     T *out;
     T lambda, delta;
-    rsrc_t rnum, rold, rout;
+    // out2 != nullptr: the new rows ALSO go to a second Pc x K piece with system-scope write-through stores -- the rank's slot in its
+    // own exchange window, from which the peers PULL them (solver_impl.hpp: multmse_w_rows_fused_peer; `out` stays the cached copy
+    // the rank's own next products read)
+    T *out2 = nullptr;
+    rsrc_t rnum, rold, rout, rout2;
     LaneAddr<T> ln, lo;
     __device__ __forceinline__ void setup(int, const TileCtx &t) {
         rnum = tile_rsrc(num, ldn, t);
         rout = tile_rsrc(out, ldn, t);
         rold = tile_rsrc(old, ldo, t);
+        if (out2 != nullptr) rout2 = tile_rsrc(out2, ldn, t);
         ln.init(t, ldn);
         lo.init(t, ldo);
     }
@@ -870,7 +875,15 @@ template <typename T> struct EpiMultUpdateRows {
     __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &pre) {
         T t = pre.nu - lambda;
         t = (t > (T)0) ? t : ((t != t) ? t : (T)0);
-        buf_st(rout, ln.lb, ln.soff(ro, co), pre.ov * (t / (v + delta)));
+        const T nv = pre.ov * (t / (v + delta));
+        buf_st(rout, ln.lb, ln.soff(ro, co), nv);
+        if (out2 != nullptr) {
+            if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nv), rout2, (int)ln.lb, (int)ln.soff(ro, co), 17);
+            else {
+                typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, nv), rout2, (int)ln.lb, (int)ln.soff(ro, co), 17);
+            }
+        }
     }
     template <int MT, int TC, int WGR, int WGC> __device__ __forceinline__ void finish(double *, const TileCtx &) {}
 };

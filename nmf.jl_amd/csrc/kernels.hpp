@@ -41,7 +41,7 @@ __global__ void reduce_slabs_kernel(T *dst, const T *src, int64_t count, int nsl
 // (eight slabs' loads in flight, then the adds in slab order: the plain `s += load` loop over a run-time count chained nslab
 // dependent memory round trips -- 6.4 us for the 8 slabs of a 256 x 256 Gram)
 template <typename T>
-__device__ __forceinline__ void reduce_slabs_vec_body(T *dst, const T *src, int64_t nvec, int nslab, int64_t stride, int64_t i) {
+__device__ __forceinline__ void reduce_slabs_vec_body(T *dst, const T *src, int64_t nvec, int nslab, int64_t stride, int64_t i, T *dst2 = nullptr) {
     constexpr int V = 16 / sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(V)));
     if (i >= nvec) return;
@@ -58,6 +58,11 @@ __device__ __forceinline__ void reduce_slabs_vec_body(T *dst, const T *src, int6
             if (k0 + u < nslab) s += v[u];
     }
     *reinterpret_cast<vec_t *>(dst + i * V) = s;
+    // (dst2: the same sum into the rank's own exchange window, system-scope write-through: the peers pull it from there)
+    if (dst2 != nullptr) {
+        typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, s), __builtin_amdgcn_make_buffer_rsrc((void *)(dst2 + i * V), 0, -1, 0x00020000), 0, 0, 17);
+    }
 }
 template <typename T>
 __global__ void reduce_slabs_vec_kernel(T *dst, const T *src, int64_t nvec, int nslab, int64_t stride, const int *done) {
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(256) void peer_sum3_kernel(T *num, const unsigned c
 // rank's block only, grid.x = cpp) -- the per-chunk arithmetic, hence every partial's bits, is the same in all forms.
 template <typename T>
 __device__ __forceinline__ void gather_stats_body(int chunk, int j, T *Wfull, const T *Wold, const unsigned char *recv, size_t chunk_bytes, int64_t P,
-                                                  int64_t Pc, int cpp, int K, double *partial, int64_t old_blk, int64_t ldo, int g_first) {
+                                                  int64_t Pc, int cpp, int K, double *partial, int64_t old_blk, int64_t ldo, int g_first, double *partial2 = nullptr) {
     __shared__ double sm[8];
     const int g = g_first + chunk / cpp, ci = chunk % cpp;
     const int64_t per = (Pc + cpp - 1) / cpp;
@@ -735,6 +740,10 @@ __device__ __forceinline__ void gather_stats_body(int chunk, int j, T *Wfull, co
         for (int q = 0; q < nw; ++q) { d += sm[q]; s += sm[4 + q]; }
         partial[((int64_t)chunk * K + j) * 2] = d;
         partial[((int64_t)chunk * K + j) * 2 + 1] = s;
+        if (partial2 != nullptr) {   // ... and into the rank's own exchange window (pulled by the peers)
+            __hip_atomic_store(partial2 + ((int64_t)chunk * K + j) * 2, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(partial2 + ((int64_t)chunk * K + j) * 2 + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 template <typename T>
@@ -750,13 +759,13 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(T *Wfull, const T *Wo
 template <typename T>
 __global__ __launch_bounds__(256) void rows_tail_kernel(const T *Wold, const unsigned char *recv, size_t chunk_bytes, int64_t P, int64_t Pc, int cpp, int K,
                                                         double *partial, int64_t old_blk, int64_t ldo, int g_first, unsigned nbs, T *gdst, const T *gsrc,
-                                                        int64_t gnvec, int gslabs, int64_t gstride, const int *done) {
+                                                        int64_t gnvec, int gslabs, int64_t gstride, const int *done, double *partial2 = nullptr, T *gdst2 = nullptr) {
     NMFX_DONE_GUARD(done);
     if (blockIdx.x < nbs) {
         gather_stats_body<T>((int)(blockIdx.x % (unsigned)cpp), (int)(blockIdx.x / (unsigned)cpp), (T *)nullptr, Wold, recv, chunk_bytes, P, Pc, cpp, K, partial, old_blk,
-                             ldo, g_first);
+                             ldo, g_first, partial2);
     } else {
-        reduce_slabs_vec_body<T>(gdst, gsrc, gnvec, gslabs, gstride, (int64_t)(blockIdx.x - nbs) * blockDim.x + threadIdx.x);
+        reduce_slabs_vec_body<T>(gdst, gsrc, gnvec, gslabs, gstride, (int64_t)(blockIdx.x - nbs) * blockDim.x + threadIdx.x, gdst2);
     }
 }
 template <typename T>
@@ -784,6 +793,88 @@ __global__ __launch_bounds__(256) void stats_check_kernel(const double *partial,
     }
     __syncthreads();
     if (do_check) check_body<T>(ctrl, wstat, hstat, k, tol, t, nullptr);
+}
+
+// The second exchange of the row-sharded MultUpdate-MSE step on the peer-to-peer transport as a PULL, ONE launch behind the flag wait
+// (solver_impl.hpp: multmse_w_rows_fused_peer).  Every rank has left its chunk [ Pc x K new rows | cpp x 2K statistics partials ] and
+// its own-rows Gram in ITS OWN window (the producing kernels store them there); here
+//   blocks [0, n * nbc)          : the peers' chunks copied out of THEIR windows (16-byte system-scope loads over xGMI, every link at
+//                                  once) into this rank's blocked W buffer -- the layout the next W'X contracts over in place; the own
+//                                  chunk is already there (cached copy written by the update's epilogue)
+//   blocks [n * nbc, .. + nbg)   : W'W = the ranks' own-rows Grams added in rank order (peer_sum_slots' order)
+//   the last block               : the ranks' statistics partials added in chunk order straight out of the windows and, with do_check,
+//                                  the stop rule -- stats_check_kernel's arithmetic (same bits), without its launch
+// No push launch and no unpack launch: 2 MB per link are READ once, where the push form wrote 16 MB of uncached stores and read them
+// back.  The copy / Gram blocks carry no `done` guard when the stop rule runs in this very launch (the last block may raise the flag
+// while they are still being dispatched); behind a stop they re-deliver what the windows still hold, which nothing reads.
+struct PullSrc {
+    const unsigned char *chunk[16];   // rank q's chunk as mapped here
+    const unsigned char *gram[16];    // rank q's own-rows Gram as mapped here
+};
+template <typename T>
+__global__ __launch_bounds__(256) void peer_pull_kernel(PullSrc ps, int rank, int n, unsigned char *dst, size_t chunk_bytes, unsigned nbc, T *gram, size_t ngram,
+                                                        unsigned nbg, size_t tail_off, int cpp, int K, double *wstat, Ctrl *ctrl, const double *hstat, int k,
+                                                        T tol, long long t, int do_check, const int *done_copy, const int *done) {
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    // system-scope 16-byte load at base + off: descriptor from the WAVE-UNIFORM base, the lane's part as the 32-bit offset operand (a
+    // descriptor built from a per-lane pointer is wrapped in a waterfall loop: 64 serial one-lane loads per instruction; peer.hpp)
+    auto sld = [](const unsigned char *base_uniform, uint32_t off) {
+        return __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void *)base_uniform, 0, -1, 0x00020000), (int)off, 0, 17);
+    };
+    const unsigned b = blockIdx.x;
+    if (b < (unsigned)n * nbc) {
+        NMFX_DONE_GUARD(done_copy);
+        const int q = (int)(b / nbc);
+        if (q == rank) return;
+        const unsigned char *s = ps.chunk[q];
+        v4u_t *d = reinterpret_cast<v4u_t *>(dst + (size_t)q * chunk_bytes);
+        const uint32_t nv = (uint32_t)(chunk_bytes / 16), stride = nbc * blockDim.x;   // (chunk_bytes < 4 GiB: checked by the host)
+        uint32_t i = (b % nbc) * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < nv; i += 4 * stride) {   // four loads in flight per lane
+            const v4u_t v0 = sld(s, i * 16u), v1 = sld(s, (i + stride) * 16u), v2 = sld(s, (i + 2 * stride) * 16u), v3 = sld(s, (i + 3 * stride) * 16u);
+            d[i] = v0;
+            d[i + stride] = v1;
+            d[i + 2 * stride] = v2;
+            d[i + 3 * stride] = v3;
+        }
+        for (; i < nv; i += stride) d[i] = sld(s, i * 16u);
+    } else if (b < (unsigned)n * nbc + nbg) {
+        NMFX_DONE_GUARD(done_copy);
+        constexpr int V = 16 / (int)sizeof(T);
+        typedef T vec_t __attribute__((ext_vector_type(V)));
+        const uint32_t nv = (uint32_t)(ngram / V);
+        for (uint32_t i = (b - (unsigned)n * nbc) * blockDim.x + threadIdx.x; i < nv; i += nbg * blockDim.x) {
+            vec_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = __builtin_bit_cast(vec_t, sld(ps.gram[u < n ? u : n - 1], i * 16u));
+            vec_t s = v[0];
+#pragma unroll
+            for (int u = 1; u < 16; ++u)
+                if (u < n) s += v[u];
+            *reinterpret_cast<vec_t *>(gram + i * V) = s;
+        }
+    } else {
+        NMFX_DONE_GUARD(done);
+        const int nchunks = n * cpp;
+        for (int e = threadIdx.x; e < 2 * K; e += blockDim.x) {
+            double s = 0.0;
+            for (int c0 = 0; c0 < nchunks; c0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int c = (c0 + u < nchunks) ? c0 + u : nchunks - 1;
+                    v[u] = __hip_atomic_load(reinterpret_cast<const double *>(ps.chunk[c / cpp] + tail_off) + (int64_t)(c % cpp) * 2 * K + e, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (c0 + u < nchunks) s += v[u];
+            }
+            wstat[e] = s;
+        }
+        __syncthreads();
+        if (do_check) check_body<T>(ctrl, wstat, hstat, k, tol, t, nullptr);
+    }
 }
 
 // dst[c + r*ldd] = sum_p src[p*stride + c + r*cols] (p ascending): the tail pieces of a short grid (GemmArgs::tail_main) summed into the

@@ -5,17 +5,15 @@
 #include <mutex>
 #include <string>
 
-#include "solver_impl.hpp"
-#include "projals_impl.hpp"
-#include "alspgrad_impl.hpp"
-#include "frontend_impl.hpp"
-#include "cd_impl.hpp"
-#include "rsvd_impl.hpp"
-#include "pipeline_impl.hpp"
-#include "spa_impl.hpp"
-#include "smallk_impl.hpp"
+#include "solver.hpp"
 
 using namespace nmfx;
+
+// Solver<float> / Solver<double> live in translation units of their own (solver_f32.hip, solver_f64.hip)
+namespace nmfx {
+SolverBase *make_solver_f32(int64_t p, int64_t n_local, int64_t k, int device);
+SolverBase *make_solver_f64(int64_t p, int64_t n_local, int64_t k, int device);
+}  // namespace nmfx
 
 struct nmfx_ctx {
     SolverBase *impl = nullptr;
@@ -72,8 +70,8 @@ int nmfx_create(nmfx_ctx **out, int dtype, int64_t p, int64_t n_local, int64_t k
     if (device < 0 || device >= ndev) { g_create_err = "device ordinal out of range"; return NMFX_ERR_BAD_ARG; }
     nmfx_ctx *c = new nmfx_ctx;
     int st = guarded(nullptr, [&] {
-        if (dtype == NMFX_F32) c->impl = new Solver<float>(p, n_local, k, device);
-        else c->impl = new Solver<double>(p, n_local, k, device);
+        if (dtype == NMFX_F32) c->impl = make_solver_f32(p, n_local, k, device);
+        else c->impl = make_solver_f64(p, n_local, k, device);
     });
     if (st != NMFX_OK) { delete c; return st; }
     *out = c;
@@ -284,5 +282,3 @@ int nmfx_device_info(int device, char *name_out, int name_len, int *cu_count, in
 }  // extern "C"
 
 // explicit instantiation
-template class nmfx::Solver<float>;
-template class nmfx::Solver<double>;

@@ -147,18 +147,39 @@ __device__ __forceinline__ bool tiny_allreduce(const TinyAR &t, double *vals, in
 }
 
 // ---- collective kernels ------------------------------------------------------------------------------------------------
+// System-scope 16-byte accesses at base + off.  The descriptor is built from a WAVE-UNIFORM base (a kernel argument plus block / loop
+// terms), the lane's part travels as the 32-bit offset operand.  (Round 6: a descriptor built from a per-lane pointer --
+// peer_rsrc(d + i * 16), as these kernels had it -- is not uniform, and the compiler then wraps every access in a waterfall loop: one
+// trip per DISTINCT lane value, i.e. 64 serial one-lane accesses per wave instruction.  The 16 MB push of the 8-rank shard shape took
+// 42 us that way.)  Buffers beyond 2 GiB are walked in windows of 2 GiB with the window start folded into the base.
+constexpr size_t PEER_WINDOW = (size_t)1 << 31;
+__device__ __forceinline__ v4u_t peer_ld16(const unsigned char *base_uniform, uint32_t off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(peer_rsrc(base_uniform), (int)off, 0, PEER_AUX);
+}
+__device__ __forceinline__ void peer_st16(unsigned char *base_uniform, uint32_t off, v4u_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, peer_rsrc(base_uniform), (int)off, 0, PEER_AUX);
+}
 // push: bytes [q * src_stride, q * src_stride + bytes) of src  ->  window q at dst_off   (blockIdx.y = destination rank)
-__global__ __launch_bounds__(256) void peer_push_kernel(PeerWin w, size_t dst_off, const unsigned char *src, size_t bytes, size_t src_stride, int rank) {
+static __global__ __launch_bounds__(256) void peer_push_kernel(PeerWin w, size_t dst_off, const unsigned char *src, size_t bytes, size_t src_stride, int rank) {
     if (peer_aborted(w.p[rank])) return;   // after a time-out nothing is pushed any more (the peers may still read the slots)
     const int q = blockIdx.y;
     const unsigned char *s = src + (size_t)q * src_stride;
     unsigned char *d = w.p[q] + dst_off;
     if ((((uintptr_t)s | (uintptr_t)d | bytes) & 15) == 0) {
-        const size_t nv = bytes / 16;
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
-            const v4u_t v = reinterpret_cast<const v4u_t *>(s)[i];
-            // (64-bit address arithmetic per access instead of one descriptor for the slot: a slot may exceed 4 GiB of offsets)
-            __builtin_amdgcn_raw_buffer_store_b128(v, peer_rsrc(d + i * 16), 0, 0, PEER_AUX);
+        const uint32_t stride = gridDim.x * blockDim.x;
+        for (size_t w0 = 0; w0 < bytes; w0 += PEER_WINDOW) {
+            const uint32_t nv = (uint32_t)(((bytes - w0 < PEER_WINDOW) ? bytes - w0 : PEER_WINDOW) / 16);
+            const v4u_t *sw = reinterpret_cast<const v4u_t *>(s + w0);
+            unsigned char *dw = d + w0;
+            uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+            for (; i + 3 * stride < nv; i += 4 * stride) {   // four loads in flight per lane
+                const v4u_t v0 = sw[i], v1 = sw[i + stride], v2 = sw[i + 2 * stride], v3 = sw[i + 3 * stride];
+                peer_st16(dw, i * 16u, v0);
+                peer_st16(dw, (i + stride) * 16u, v1);
+                peer_st16(dw, (i + 2 * stride) * 16u, v2);
+                peer_st16(dw, (i + 3 * stride) * 16u, v3);
+            }
+            for (; i < nv; i += stride) peer_st16(dw, i * 16u, sw[i]);
         }
     } else {
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += (size_t)gridDim.x * blockDim.x)
@@ -166,14 +187,14 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PeerWin w, size_t dst_of
     }
 }
 // signal: "everything this rank pushed for collective `seq` has left" -> flag[rank] = seq in every window (lane q -> rank q)
-__global__ void peer_signal_kernel(PeerWin w, int rank, int n, unsigned seq) {
+static __global__ void peer_signal_kernel(PeerWin w, int rank, int n, unsigned seq) {
     if (peer_aborted(w.p[rank])) return;   // ... and nothing is signalled: a peer that has not failed yet times out on this rank's flag
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     const int q = threadIdx.x;
     if (q < n) peer_store_u32(reinterpret_cast<unsigned *>(w.p[q] + PEER_FLAG_OFF) + rank, seq);
 }
 // wait (ONE block): until every rank's flag has reached seq; bounded by the wall clock (100 MHz ticks)
-__global__ void peer_wait_kernel(PeerWin w, int rank, int n, unsigned seq, unsigned long long timeout_ticks) {
+static __global__ void peer_wait_kernel(PeerWin w, int rank, int n, unsigned seq, unsigned long long timeout_ticks) {
     const int q = threadIdx.x;
     unsigned char *mine = w.p[rank];
     unsigned *abortw = reinterpret_cast<unsigned *>(mine + PEER_ABORT_OFF);
@@ -205,14 +226,24 @@ __global__ __launch_bounds__(256) void peer_reduce_kernel(T *dst, const unsigned
     }
 }
 // read, gathering: dst[q * bytes + i] = slot_q[i]
-__global__ __launch_bounds__(256) void peer_gather_kernel(unsigned char *dst, const unsigned char *mine, size_t region_off, size_t slot_bytes, size_t bytes) {
+static __global__ __launch_bounds__(256) void peer_gather_kernel(unsigned char *dst, const unsigned char *mine, size_t region_off, size_t slot_bytes, size_t bytes) {
     const int q = blockIdx.y;
     const unsigned char *s = mine + region_off + (size_t)q * slot_bytes;
     unsigned char *d = dst + (size_t)q * bytes;
     if ((((uintptr_t)s | (uintptr_t)d | bytes) & 15) == 0) {
-        const size_t nv = bytes / 16;
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x)
-            reinterpret_cast<v4u_t *>(d)[i] = __builtin_amdgcn_raw_buffer_load_b128(peer_rsrc(s + i * 16), 0, 0, PEER_AUX);
+        const uint32_t stride = gridDim.x * blockDim.x;
+        for (size_t w0 = 0; w0 < bytes; w0 += PEER_WINDOW) {
+            const uint32_t nv = (uint32_t)(((bytes - w0 < PEER_WINDOW) ? bytes - w0 : PEER_WINDOW) / 16);
+            const unsigned char *sw = s + w0;
+            v4u_t *dw = reinterpret_cast<v4u_t *>(d + w0);
+            uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+            for (; i + 3 * stride < nv; i += 4 * stride) {
+                const v4u_t v0 = peer_ld16(sw, i * 16u), v1 = peer_ld16(sw, (i + stride) * 16u), v2 = peer_ld16(sw, (i + 2 * stride) * 16u),
+                            v3 = peer_ld16(sw, (i + 3 * stride) * 16u);
+                dw[i] = v0; dw[i + stride] = v1; dw[i + 2 * stride] = v2; dw[i + 3 * stride] = v3;
+            }
+            for (; i < nv; i += stride) dw[i] = peer_ld16(sw, i * 16u);
+        }
     } else {
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += (size_t)gridDim.x * blockDim.x)
             d[i] = __builtin_amdgcn_raw_buffer_load_b8(peer_rsrc(s + i), 0, 0, PEER_AUX);
@@ -496,6 +527,15 @@ struct PeerComm : Comm {
     size_t direct_off(size_t off) const { return region(seq + 1) + (size_t)rank * slot_bytes + off; }   // offset of direct_dst inside every window
     unsigned char *direct_dst(int q, size_t off) const { return win.p[q] + region(seq + 1) + (size_t)rank * slot_bytes + off; }
     const unsigned char *direct_src(int q, size_t off) const { return mine + region(seq + 1) + (size_t)q * slot_bytes + off; }
+    // PULL form of a reserved member: every rank stores its contribution into ITS OWN window (direct_dst(rank, off)), the consumers behind
+    // group_end() read rank q's contribution out of q's window: pull_src(q, off).  Buffer re-use is the push form's argument with the
+    // roles swapped: a rank overwrites its slot of parity s & 1 for collective s + 2 after it passed the wait of s + 1, i.e. after
+    // every peer signalled s + 1, which a peer's stream issues behind its own reads of s.
+    // (timing stand-in: every window is this rank's, slot q holds nothing -- the own slot stands in for all of them)
+    const unsigned char *pull_src(int q, size_t off) const {
+        const int qq = sim ? rank : q;
+        return win.p[qq] + region(seq + 1) + (size_t)qq * slot_bytes + off;
+    }
 };
 
 }  // namespace nmfx

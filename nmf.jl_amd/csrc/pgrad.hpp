@@ -179,7 +179,7 @@ __device__ __forceinline__ void pg_block_sum3(const double *partial, int n, doub
 // use themselves: the rank-LOCAL sums of a sharded sub-solve on a transport without the in-kernel all-reduce (RCCL, the in-process
 // group).  The collective that follows then moves nslot doubles whatever the ranks' block counts are -- all-reducing the per-block
 // partials themselves (round 3) used a rank-dependent count as soon as ragged column shards straddle a 256-column boundary.
-__global__ void pg_local_sum_kernel(const double *partial, int n, int nslot, double *out) {
+static __global__ void pg_local_sum_kernel(const double *partial, int n, int nslot, double *out) {
     __shared__ double sm[4];
     if (nslot == 3) { pg_block_sum3(partial, n, out); return; }
     const double s = pg_block_sum(partial, n, 1, 0, sm);
@@ -213,7 +213,7 @@ template <typename T> __global__ void pg_begin_kernel(PgState *st, const double 
 }
 
 // the host finished a halted line search: speculation may continue
-__global__ void pg_resume_kernel(PgState *st) {
+static __global__ void pg_resume_kernel(PgState *st) {
     st->halt = 0;
     st->gate = st->converged ? 1 : 0;
 }
@@ -277,7 +277,7 @@ template <typename T> __global__ void pg_apply_kernel(T *Z, const T *G, int64_t 
         for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) z[r] = pg_trial(z[r], g[r], a);
     }
 }
-__global__ void pg_clear_apply_kernel(PgState *st) { st->apply = 0; }
+static __global__ void pg_clear_apply_kernel(PgState *st) { st->apply = 0; }
 
 // Start of an inner iteration after the first: serve the pending accept (Z <- Zn(alpha_apply), G <- G + Gram*D of that trial
 // point, which its step left in GD[gd_sel]) and reduce projgradnorm^2 of the new (Z, G) -- one pass over Z, G, GD instead of

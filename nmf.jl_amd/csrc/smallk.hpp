@@ -374,7 +374,7 @@ __global__ __launch_bounds__(SMALLK_THREADS) void smallk_w_kernel(const float *X
 // After a stripe kernel, ONE launch: blocks [0, 128) sum the stripes' Gram contributions, blocks [128, 128 + 32) sum the statistics
 // partials (128 values, a wave per value as in finalize_partials_kernel).
 constexpr int SMALLK_GRAM_BLOCKS = 128;
-__global__ __launch_bounds__(256) void smallk_finish_kernel(float *gram, const float *slabs, int nstripes, const double *stat_part, double *stat_out,
+static __global__ __launch_bounds__(256) void smallk_finish_kernel(float *gram, const float *slabs, int nstripes, const double *stat_part, double *stat_out,
                                                            const int *done, Ctrl *ctrl = nullptr, const double *hstat = nullptr, int k = 0, float tol = 0.f,
                                                            long long t = 0, unsigned *ticket = nullptr) {
     if (done && *done) return;

@@ -148,6 +148,7 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = dev_env("NMFX_POTRS_STRIP")) strip_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_W_BLOCKED")) blk_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_P2P_PULL")) peer_pull_enabled = std::atoi(e) != 0;
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
@@ -303,7 +304,8 @@ template <typename T> class Solver : public SolverBase {
     // new W: the all-gather chunk), two k x k Grams, the k-vectors and the statistics
     size_t p2p_slot_bytes() const {
         const size_t piece = std::max((size_t)std::max<int64_t>(Pc, 0) * K * sizeof(T) + 4096, ag_chunk_bytes + 4096);
-        return piece + 2 * ((size_t)K * K * sizeof(T) + 256) + 8 * ((size_t)K * sizeof(double) + 256) + 4096;
+        // (+ the statistics tail of a blocked-residency chunk: up to 64 chunks of 2K partials)
+        return piece + 2 * ((size_t)K * K * sizeof(T) + 256) + 8 * ((size_t)K * sizeof(double) + 256) + 4096 + (size_t)64 * 2 * K * sizeof(double);
     }
     void p2p_export(void *handle_out) override {
         HIP_TRY(hipSetDevice(device));
@@ -997,8 +999,15 @@ template <typename T> class Solver : public SolverBase {
     size_t blk_chunk = 0;
     bool w_res_blocked = false, w_std_stale = false;
     bool blk_enabled = true;         // NMFX_W_BLOCKED=0: unpack after every all-gather (A/B)
+    bool peer_pull_enabled = true;   // NMFX_P2P_PULL=0: the peer transport's second exchange as a push + unpack (round 5; A/B)
     bool blocked_residency_ok() const {
-        return blk_enabled && rs_fused() && peer() == nullptr && s_h % nranks == 0 && Pc % (P / s_h) == 0 && !short_grid;
+        if (!(blk_enabled && rs_fused() && s_h % nranks == 0 && Pc % (P / s_h) == 0 && !short_grid)) return false;
+        // peer transport: the chunk and the own-rows Gram must fit one slot of the window (the pull form of the second exchange)
+        if (PeerComm *pc = peer()) {
+            const size_t chunk = ((size_t)Pc * K * sizeof(T) + (size_t)64 * 2 * K * sizeof(double) + 255) / 256 * 256;
+            return peer_pull_enabled && nranks <= EPI_MAX_PIECES && chunk + (size_t)K * K * sizeof(T) + 512 <= pc->slot_bytes;
+        }
+        return true;
     }
     void w_sync(const int *done) {   // W[wcur] <- the blocked copy
         if (!w_res_blocked || !w_std_stale) return;

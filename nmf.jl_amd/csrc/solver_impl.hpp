@@ -216,7 +216,7 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
 //   up and runs the stop rule (stats_check_kernel).
 template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, long long t) {
     if (PeerComm *pc = peer()) {
-        const size_t need = (size_t)Pc * K * sizeof(T) + 2 * ((size_t)K * K * sizeof(T) + 256) + (size_t)2 * K * sizeof(double) + 1024;
+        const size_t need = (size_t)Pc * K * sizeof(T) + 2 * ((size_t)K * K * sizeof(T) + 256) + (size_t)2 * K * sizeof(double) + 1024;   // (the pull form's larger chunk: blocked_residency_ok)
         if (nranks <= EPI_MAX_PIECES && need <= pc->slot_bytes) { multmse_w_rows_fused_peer(o, t, pc); return; }
     }
     const int *done = done_flag();
@@ -378,6 +378,83 @@ template <typename T> void Solver<T>::multmse_w_rows_fused_peer(const nmfx_opts 
             HIP_TRY(hipGetLastError());
         });
     }
+    if (blocked_residency_ok()) {
+        // ---- exchange 2 as a PULL, W resident in the all-gather's layout (round 6) ---------------------------------------------------
+        // The rank's update writes its new rows twice -- into its chunk of the blocked W buffer (cached: its own next products read them
+        // there) and into ITS OWN window slot (write-through) --, the own-rows statistics and the own-rows Gram follow them into the
+        // window, then flag -> wait -> ONE launch that copies the peers' chunks out of their windows into the blocked buffer, adds the
+        // ranks' Grams in rank order and runs the stop rule on the ranks' statistics (peer_pull_kernel).  Against the push form below:
+        // no 16 MB of uncached stores (42 us at the 8-rank shard shape), no unpack of 16 MB out of the own window (25 us), no separate
+        // one-block stop-rule launch, and the next W'X contracts over the blocked buffer in place.  Same arithmetic in the same order:
+        // bit-identical to the push form and to the in-process group (tests/test_gpu_peer.py).
+        const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(64 / nranks, Pc / 1024));   // statistics chunks per row block
+        const bool fuse_check = o.track_objective == 0 && o.stop_sums == 0;
+        blk_cpp = cpp;
+        blk_chunk = ((size_t)Pc * K * sizeof(T) + (size_t)cpp * 2 * K * sizeof(double) + 255) / 256 * 256;
+        for (auto &b : Wblk) b.ensure(blk_chunk * (size_t)nranks);
+        const int64_t blk_el = (int64_t)(blk_chunk / sizeof(T));
+        const T *Wo_own = w_res_blocked ? reinterpret_cast<const T *>(Wblk[wb].p) + (int64_t)rank * blk_el : Wo + row0;
+        const int64_t ldo = w_res_blocked ? Pc : P;
+        unsigned char *mine_b = Wblk[wb ^ 1].p + (size_t)rank * blk_chunk;
+        T *mine = reinterpret_cast<T *>(mine_b);
+        double *tail = reinterpret_cast<double *>(mine_b + (size_t)Pc * K * sizeof(T));
+        pc->group_start();
+        pc->group_stream = stream;
+        const size_t o_w = pc->direct_reserve(blk_chunk), o_gw = o.update_H ? pc->direct_reserve(gram_b) : 0;
+        unsigned char *pub = pc->direct_dst(rank, o_w);                       // this rank's slot in its own window
+        T *pub_gram = reinterpret_cast<T *>(pc->direct_dst(rank, o_gw));
+        PullSrc ps;
+        std::memset(&ps, 0, sizeof ps);
+        for (int q = 0; q < G; ++q) { ps.chunk[q] = pc->pull_src(q, o_w); ps.gram[q] = pc->pull_src(q, o_gw); }
+        EpiMultUpdateRows<T> e{rs_out.p, Pc, Wo_own, ldo, mine, (T)o.lambda_w, (T)o.delta};               // multupd.jl:110-114
+        e.out2 = reinterpret_cast<T *>(pub);
+        gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo_own, ldo, Pc, K, 1, false, e, done, 3.0 * Pc * K * sizeof(T));
+        int sg = 0;
+        bool gram_pub = false;
+        if (o.update_H) {
+            sg = pick_splits((int)((K / 64) * (K / 64)), Pc);
+            EpiStore<T> eg{slabs.p + gram_slab_off, K, (int64_t)K * K, nullptr};
+            force_quarter_tiles = true;
+            gemm<KCONTIG, KCONTIG>("gemm_WtW_rows", mine, Pc, K, mine, Pc, K, Pc, sg, true, eg, done, (double)(Pc * K) * sizeof(T));
+            force_quarter_tiles = false;
+            // (16 or more slabs keep their own combine launch -- reduce_many_slabs_kernel's fixed order, like every other form of this step)
+            if (sg >= 16) { reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, sg, done); sg = 0; gram_pub = true; }
+        }
+        timed("stats_W_rows+reduce_WtW", 0.0, (2.0 * Pc * K + (double)K * K * (sg + 1)) * sizeof(T), [&] {
+            constexpr int V = 16 / (int)sizeof(T);
+            const int64_t gnvec = (int64_t)K * K / V;
+            const unsigned nbs = (unsigned)(cpp * K), nbr = sg > 0 ? (unsigned)((gnvec + 255) / 256) : 0u;
+            hipLaunchKernelGGL(rows_tail_kernel<T>, dim3(nbs + nbr), dim3(256), 0, stream, Wo_own - (int64_t)rank * (w_res_blocked ? blk_el : Pc), Wblk[wb ^ 1].p, blk_chunk,
+                               P, Pc, cpp, (int)K, tail, w_res_blocked ? blk_el : Pc, ldo, rank, nbs, gramW_p, slabs.p + gram_slab_off, gnvec, sg, (int64_t)K * K, done,
+                               reinterpret_cast<double *>(pub + (size_t)Pc * K * sizeof(T)), pub_gram);
+            if (gram_pub) {   // the Gram came out of its own combine launch: one more copy, into the own window only
+                PeerWin self;
+                for (auto &q : self.p) q = nullptr;
+                self.p[0] = pc->mine;
+                hipLaunchKernelGGL(peer_push_kernel, dim3(PeerComm::grid_for(gram_b / 16 + 1), 1), dim3(256), 0, stream, self, pc->direct_off(o_gw),
+                                   reinterpret_cast<const unsigned char *>(gramW_p), gram_b, (size_t)0, 0);
+            }
+            HIP_TRY(hipGetLastError());
+        });
+        timed("comm_p2p_flag_wait_W", 0.0, (double)(P * K) * sizeof(T), [&] { pc->group_end(); });
+        gramw_sharded_valid = o.update_H != 0;
+        timed("pull_W_rows+stats_check", 0.0, ((double)(G - 1) * 2.0 * Pc * K + (double)G * K * K) * sizeof(T), [&] {
+            const unsigned nbc = (unsigned)std::max<size_t>(1, std::min<size_t>((blk_chunk / 16 + 1023) / 1024, 128));   // blocks per peer chunk
+            const unsigned nbg = o.update_H ? (unsigned)std::min<int64_t>(((int64_t)K * K * sizeof(T) / 16 + 255) / 256, 256) : 0u;
+            hipLaunchKernelGGL(peer_pull_kernel<T>, dim3((unsigned)G * nbc + nbg + 1u), dim3(256), 0, stream, ps, rank, G, Wblk[wb ^ 1].p, blk_chunk, nbc, gramW_p,
+                               (size_t)K * K, nbg, (size_t)Pc * K * sizeof(T), cpp, (int)K, wstat.p, ctrl, o.update_H ? hstat.p : (const double *)nullptr, (int)k,
+                               (T)o.tol, t, fuse_check ? 1 : 0, fuse_check ? (const int *)nullptr : done, done);
+            HIP_TRY(hipGetLastError());
+        });
+        check_fused = fuse_check;
+        wb ^= 1;
+        w_res_blocked = true;
+        w_std_stale = true;
+        wcur ^= 1;
+        return;
+    }
+    w_sync(done);
+    w_res_blocked = false;
     const size_t chunk = piece_b;
     T *mine = reinterpret_cast<T *>(ag_recv.p + (size_t)rank * chunk);
     EpiMultUpdateRows<T> e{rs_out.p, Pc, Wo + row0, P, mine, (T)o.lambda_w, (T)o.delta};                  // multupd.jl:110-114
@@ -390,7 +467,7 @@ template <typename T> void Solver<T>::multmse_w_rows_fused_peer(const nmfx_opts 
         force_quarter_tiles = false;
         reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, sg, done);
     }
-    // ---- exchange 2
+    // ---- exchange 2 (push form; NMFX_P2P_PULL=0 or shapes the blocked residency does not cover)
     pc->group_start();
     pc->group_stream = stream;
     const size_t o_w = pc->direct_reserve(piece_b), o_gw = o.update_H ? pc->direct_reserve(gram_b) : 0;

@@ -5,9 +5,17 @@
 # points that `ccall` the C ABI of include/nmfx.h and hand back an `NMF.Result{T}` holding the SAME W and H
 # arrays, updated in place, exactly like `nmf_skeleton!` does (src/common.jl:88).
 #
+# The drop-in itself needs NO edit of NMF.jl: wrap the data matrix once, `Xd = NMFX.DeviceMatrix(X)`, and the unmodified
+# `nnmf(Xd, k; alg=..., init=..., replicates=...)` / `NMF.solve!(alg, Xd, W, H)` run on the GPU -- `DeviceMatrix{T} <: AbstractMatrix{T}`
+# (accepted by `nnmf`, src/interf.jl:3), and the methods of `NMF.solve!`, `NMF.nndsvd`, `NMF.spa`, `NMF.alspgrad_updateh!/w!` added
+# below are more specific in X than the reference's untyped ones (src/multupd.jl:45, projals.jl:37, alspgrad.jl:381, coorddesc.jl:49,
+# greedycd.jl:33), so Julia's dispatch picks them inside `solve_replicates!` (src/interf.jl:85-101) without anybody passing a keyword.
+#
 # NOTE: the build image has no Julia toolchain, so this shim is untested there; it is kept trivially thin
 # (one ccall per C entry point, no logic beyond marshalling and status -> exception mapping).  The Python
-# twin nmf.jl_amd/nmfx/api.py exercises the same C entry points in the test-suite.
+# twin nmf.jl_amd/nmfx/api.py exercises the same C entry points in the test-suite, tests/test_julia_shim.py checks the
+# struct layouts and every ccall signature of this file against include/nmfx.h, and julia/test/runtests.jl is what a maintainer
+# with Julia and a GPU runs (ports of the reference's test/multupd.jl, test/alspgrad.jl, test/interf.jl through the wrapper).
 module NMFX
 
 using NMF
@@ -180,6 +188,97 @@ function iter_trace(ctx::Context, niters::Integer)
     check(ccall((:nmfx_get_iter_trace, libnmfx), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint, Ref{Cint}),
                 ctx.h, el, rc, niters + 1, m), ctx.h)
     el[1:m[]], rc[1:m[]]
+end
+
+get_factors!(ctx::Context{T}, W::Matrix{T}, H::Matrix{T}) where T =
+    check(ccall((:nmfx_get_factors, libnmfx), Cint, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), ctx.h, W, H), ctx.h)
+
+# alspgrad_updateh!(X, W, H) / alspgrad_updatew!(X, W, H) (src/alspgrad.jl:69-84, 225-240) on the resident X: which = 0 updates H,
+# which = 1 updates W; returns the executed inner iterations
+function alspgrad_subsolve!(ctx::Context{T}, which::Integer, W::Matrix{T}, H::Matrix{T}; maxiter::Integer=1000, traceiter::Integer=20,
+                            tolg::Real=cbrt(eps(T)), beta::Real=T(0.2), sigma::Real=T(0.01)) where T
+    o = COpts(1, 1, 0, maxiter, traceiter, 0, cbrt(eps(T)), 0.0, 0.0, sqrt(eps(T)), tolg, beta, sigma, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0)
+    res = Ref(CResult(0, 0, 0, 0.0, 0.0, 0, 0, 0.0))
+    check(ccall((:nmfx_alspgrad_subsolve, libnmfx), Cint, (Ptr{Cvoid}, Cint, Ref{COpts}, Ptr{T}, Ptr{T}, Ref{CResult}),
+                ctx.h, which, o, W, H, res), ctx.h)
+    Int(res[].niters)
+end
+
+# ---- DeviceMatrix: the zero-edit drop-in (see the header) ---------------------------------------------------------------
+"""
+    DeviceMatrix(X; device=0)
+
+`X` as NMF.jl sees it (an `AbstractMatrix{T}` backed by the host array) plus its device-resident copies, created on first use --
+one `Context` per component count `k` -- and kept for every later `solve!` / replicate / initialisation on the same matrix.
+`NMFX.release!(Xd)` frees the device memory early (otherwise the finalizers do).
+"""
+mutable struct DeviceMatrix{T<:Union{Float32,Float64}} <: AbstractMatrix{T}
+    X::Matrix{T}
+    device::Int
+    ctxs::Dict{Int,Context{T}}
+end
+DeviceMatrix(X::Matrix{T}; device::Integer=0) where {T<:Union{Float32,Float64}} = DeviceMatrix{T}(X, Int(device), Dict{Int,Context{T}}())
+DeviceMatrix(X::AbstractMatrix{T}; device::Integer=0) where {T<:Union{Float32,Float64}} = DeviceMatrix(Matrix{T}(X); device=device)
+Base.size(A::DeviceMatrix) = size(A.X)
+Base.IndexStyle(::Type{<:DeviceMatrix}) = IndexLinear()
+Base.getindex(A::DeviceMatrix, i::Int) = A.X[i]
+Base.parent(A::DeviceMatrix) = A.X
+context(A::DeviceMatrix{T}, k::Integer) where T = get!(() -> Context{T}(A.X, k; device=A.device), A.ctxs, Int(k))
+function release!(A::DeviceMatrix)
+    foreach(finalize, values(A.ctxs))
+    empty!(A.ctxs)
+    A
+end
+
+# NMF.solve!(alg, X, W, H) for every iterative algorithm (one method per type: a Union in the first argument would be ambiguous
+# with the reference's methods, which are more specific there and less specific in X)
+NMF.solve!(alg::NMF.MultUpdate{T}, X::DeviceMatrix{T}, W::Matrix{T}, H::Matrix{T}) where T = solve!(context(X, size(W, 2)), alg, W, H)
+NMF.solve!(alg::NMF.ProjectedALS{T}, X::DeviceMatrix{T}, W::Matrix{T}, H::Matrix{T}) where T = solve!(context(X, size(W, 2)), alg, W, H)
+NMF.solve!(alg::NMF.ALSPGrad{T}, X::DeviceMatrix{T}, W::Matrix{T}, H::Matrix{T}) where T = solve!(context(X, size(W, 2)), alg, W, H)
+NMF.solve!(alg::NMF.CoordinateDescent{T}, X::DeviceMatrix{T}, W::Matrix{T}, H::Matrix{T}) where T = solve!(context(X, size(W, 2)), alg, W, H)
+NMF.solve!(alg::NMF.GreedyCD{T}, X::DeviceMatrix{T}, W::Matrix{T}, H::Matrix{T}) where T = solve!(context(X, size(W, 2)), alg, W, H)
+
+# nndsvd(X, k; zeroh, variant, initdata) (src/initialization.jl:74-101) next to the resident X: rsvd's sketch / orthogonalisation /
+# projection and _nndsvd! run on the device, the k x k eigenproblem in Julia's LAPACK.  The sketch and the :ar fill are drawn by the
+# library's Philox generator keyed by ONE draw from Julia's RNG, so `Random.seed!` still makes a run repeatable.
+# (`randinit(X, k)` needs no method: it only asks for size and eltype, and keeps Julia's own random stream.)
+function NMF.nndsvd(X::DeviceMatrix{T}, k::Integer; zeroh::Bool=false, variant::Symbol=:std, initdata=nothing) where T
+    p, n = size(X)
+    variant in (:std, :a, :ar) || throw(ArgumentError("Invalid value for variant"))
+    ctx = context(X, k)
+    seed = rand(UInt64)
+    if initdata === nothing
+        rsvd!(ctx, k; seed=seed)
+        nndsvd_resident!(ctx; variant=variant, zeroh=zeroh, seed=seed, n_total=n)
+    else
+        nndsvd!(ctx, Matrix{T}(initdata.U[:, 1:k]), Vector{T}(initdata.S[1:k]), Matrix{T}(initdata.V[:, 1:k]);
+                variant=variant, zeroh=zeroh, seed=seed, n_total=n)
+    end
+    W = Matrix{T}(undef, p, k)
+    H = Matrix{T}(undef, k, n)
+    get_factors!(ctx, W, H)
+    return (W, H)
+end
+
+# spa(X, k) (src/spa.jl:41-63; the reference's method is typed on Matrix{T}, so `nnmf(Xd, k; init=:spa)` needs this one)
+function NMF.spa(X::DeviceMatrix{T}, k::Integer; nnls_alg::Tuple{Symbol,Symbol}=(:pivot, :cache)) where T
+    p, n = size(X)
+    W = Matrix{T}(undef, p, k)
+    H = Matrix{T}(undef, k, n)
+    spa!(context(X, k), W, H)
+    return W, H
+end
+
+# the exported sub-solvers (src/alspgrad.jl:69-84, 225-240; test/alspgrad.jl:10-20); like the reference they return (H, t) / (W, t)
+function NMF.alspgrad_updateh!(X::DeviceMatrix{T}, W::Matrix{T}, H::Matrix{T}; maxiter::Int=1000, traceiter::Int=20, tolg::T=cbrt(eps(T)),
+                               beta::T=convert(T, 0.2), sigma::T=convert(T, 0.01), verbose::Bool=false) where T
+    t = alspgrad_subsolve!(context(X, size(W, 2)), 0, W, H; maxiter=maxiter, traceiter=traceiter, tolg=tolg, beta=beta, sigma=sigma)
+    return (H, t)
+end
+function NMF.alspgrad_updatew!(X::DeviceMatrix{T}, W::Matrix{T}, H::Matrix{T}; maxiter::Int=1000, traceiter::Int=20, tolg::T=cbrt(eps(T)),
+                               beta::T=convert(T, 0.2), sigma::T=convert(T, 0.01), verbose::Bool=false) where T
+    t = alspgrad_subsolve!(context(X, size(W, 2)), 1, W, H; maxiter=maxiter, traceiter=traceiter, tolg=tolg, beta=beta, sigma=sigma)
+    return (W, t)
 end
 
 # ---- nnmf front end on the device (include/nmfx.h; src/interf.jl:15,28,31,85-101; src/initialization.jl:4-17) ----------

@@ -59,6 +59,15 @@ def test_bench_gpus_2_launches_its_own_ranks(built):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert d["multi_gpu_consistency"] == {"W_identical_on_all_ranks": True, "objective_identical_on_all_ranks": True, "finite": True}
     assert "cpu_baseline" not in d      # rank 0 at N = 1 only
+    # the transport is chosen BY THE CLOCK (round 6): every exchange candidate that passed its verification was also timed before the
+    # timed region, the times are in the line, and the region ran on the fastest one
+    ev = d["exchange_verification"]
+    cands = ev["candidates"]
+    assert len(cands) >= 2 and ev["selected_by"].startswith("fastest")
+    timed = [c for c in cands if c["ok"]]
+    assert timed and all(isinstance(c["ms_per_step"], float) and c["ms_per_step"] > 0 for c in timed)
+    assert ev["ran"] == min(timed, key=lambda c: c["ms_per_step"])["candidate"]
+    assert all(c["ms_per_step"] is None for c in cands if not c["ok"])
 
 
 def test_bench_gpus_n_without_a_launcher_spawns_torch_distributed_run(monkeypatch):

@@ -116,7 +116,9 @@ typedef struct {
      * default -- since round 5 the reference's potrs! route wherever the strip kernel exists (padded k <= 512 in Float32, 256 in Float64: csrc/chol.hpp,
      * potrs_strip_kernel: 29-36 us against 55 for the product form at 16384 columns, k = 256, Float32), the product form beyond;
      * NMFX_HSOLVE_PRODUCT (1): Uinv (Uinv' B), two products with the inverted factor; NMFX_HSOLVE_POTRS (2): forward and back
-     * substitution with the factor itself at every k (beyond the strip kernel: potrs_panel_kernel while its panel fits the LDS). */
+     * substitution with the factor itself (beyond the strip kernel: potrs_panel_kernel while its panel fits the LDS; where neither
+     * kernel exists -- padded k > 512 in Float32 with a panel beyond the LDS -- the call fails with NMFX_ERR_UNSUPPORTED instead of
+     * running another route silently). */
     int32_t h_solve;
     /* stop_condition's four sums per component (src/common.jl:95-104).  0 (default): the T-rounded terms summed in Float64 in a fixed
      * tree order, inside the update launches (free; differs from the reference's totals by <= ~eps(T) sqrt(length) relative, so the

@@ -768,31 +768,54 @@ __global__ __launch_bounds__(256) void rows_tail_kernel(const T *Wold, const uns
         reduce_slabs_vec_body<T>(gdst, gsrc, gnvec, gslabs, gstride, (int64_t)(blockIdx.x - nbs) * blockDim.x + threadIdx.x, gdst2);
     }
 }
-template <typename T>
-// grp > 0: the partials arrive in groups of grp chunks, group q at partial + q * grp_stride doubles (the ranks' statistics tails
-// behind their row blocks in the blocked W buffer); summed in the same chunk order either way.
-__global__ __launch_bounds__(256) void stats_check_kernel(const double *partial, int nchunks, int K, double *wstat, Ctrl *ctrl, const double *hstat,
-                                                          int k, T tol, long long t, int do_check, const int *done, int grp = 0, int64_t grp_stride = 0) {
-    NMFX_DONE_GUARD(done);
-    // (sixteen loads in flight, then the adds in chunk order: as a plain `s += partial[...]` loop every load waited for the add before it --
-    // 16 dependent HBM round trips, 17 us for 64 KB at the 8-rank shard shape)
-    for (int e = threadIdx.x; e < 2 * K; e += blockDim.x) {
+// The ranks' (or chunks') stop_condition partials added in chunk order, then the stop rule -- by NB = gridDim blocks (round 6; one block
+// before): block b owns the outputs e in [b * 2K / NB, (b + 1) * 2K / NB), one thread per output, 32 of the output's chunk values
+// requested before the first add (the adds stay in chunk order: the bits of the one-block form, whose 2K sums of 64 values each were
+// four dependent round trips per thread, 10.5 us at the 8-rank shard shape), and the LAST block to arrive (a ticket: NB agent-scope
+// atomics) runs check_body on the complete wstat.  `ld(c, e)` = partial of chunk c, output e.
+template <typename T, typename LD>
+__device__ __forceinline__ void stats_sum_check(LD ld, int nchunks, int K, double *wstat, unsigned *ticket, unsigned b, unsigned nb, Ctrl *ctrl, const double *hstat,
+                                                int k, T tol, long long t, int do_check) {
+    const int per = (2 * K + (int)nb - 1) / (int)nb;
+    const int e0 = (int)b * per, e1 = (e0 + per < 2 * K) ? e0 + per : 2 * K;
+    for (int e = e0 + (int)threadIdx.x; e < e1; e += (int)blockDim.x) {
         double s = 0.0;
-        for (int c0 = 0; c0 < nchunks; c0 += 16) {
-            double v[16];
+        for (int c0 = 0; c0 < nchunks; c0 += 32) {
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int c = (c0 + u < nchunks) ? c0 + u : nchunks - 1;
-                v[u] = (grp > 0) ? partial[(int64_t)(c / grp) * grp_stride + (int64_t)(c % grp) * 2 * K + e] : partial[(int64_t)c * 2 * K + e];
-            }
+            for (int u = 0; u < 32; ++u) v[u] = ld((c0 + u < nchunks) ? c0 + u : nchunks - 1, e);
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+            for (int u = 0; u < 32; ++u)
                 if (c0 + u < nchunks) s += v[u];
         }
         wstat[e] = s;
     }
+    __shared__ int last_sm;
     __syncthreads();
-    if (do_check) check_body<T>(ctrl, wstat, hstat, k, tol, t, nullptr);
+    if (threadIdx.x == 0) {
+        int last = 1;
+        if (nb > 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (old % nb) == nb - 1;    // (the counter only ever grows: every launch adds exactly nb, or nothing behind the stop)
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        last_sm = last;
+    }
+    __syncthreads();
+    if (last_sm && do_check) check_body<T>(ctrl, wstat, hstat, k, tol, t, nullptr);
+}
+template <typename T>
+// grp > 0: the partials arrive in groups of grp chunks, group q at partial + q * grp_stride doubles (the ranks' statistics tails
+// behind their row blocks in the blocked W buffer); summed in the same chunk order either way.
+__global__ __launch_bounds__(256) void stats_check_kernel(const double *partial, int nchunks, int K, double *wstat, Ctrl *ctrl, const double *hstat,
+                                                          int k, T tol, long long t, int do_check, const int *done, int grp = 0, int64_t grp_stride = 0,
+                                                          unsigned *ticket = nullptr) {
+    NMFX_DONE_GUARD(done);
+    auto ld = [&](int c, int e) {
+        return (grp > 0) ? partial[(int64_t)(c / grp) * grp_stride + (int64_t)(c % grp) * 2 * K + e] : partial[(int64_t)c * 2 * K + e];
+    };
+    stats_sum_check<T>(ld, nchunks, K, wstat, ticket, blockIdx.x, gridDim.x, ctrl, hstat, k, tol, t, do_check);
 }
 
 // The second exchange of the row-sharded MultUpdate-MSE step on the peer-to-peer transport as a PULL, ONE launch behind the flag wait
@@ -802,8 +825,8 @@ __global__ __launch_bounds__(256) void stats_check_kernel(const double *partial,
 //                                  once) into this rank's blocked W buffer -- the layout the next W'X contracts over in place; the own
 //                                  chunk is already there (cached copy written by the update's epilogue)
 //   blocks [n * nbc, .. + nbg)   : W'W = the ranks' own-rows Grams added in rank order (peer_sum_slots' order)
-//   the last block               : the ranks' statistics partials added in chunk order straight out of the windows and, with do_check,
-//                                  the stop rule -- stats_check_kernel's arithmetic (same bits), without its launch
+//   the last STAT_BLOCKS blocks  : the ranks' statistics partials added in chunk order straight out of the windows and, with do_check,
+//                                  the stop rule -- stats_check_kernel's arithmetic (stats_sum_check: same bits), without its launch
 // No push launch and no unpack launch: 2 MB per link are READ once, where the push form wrote 16 MB of uncached stores and read them
 // back.  The copy / Gram blocks carry no `done` guard when the stop rule runs in this very launch (the last block may raise the flag
 // while they are still being dispatched); behind a stop they re-deliver what the windows still hold, which nothing reads.
@@ -814,7 +837,7 @@ struct PullSrc {
 template <typename T>
 __global__ __launch_bounds__(256) void peer_pull_kernel(PullSrc ps, int rank, int n, unsigned char *dst, size_t chunk_bytes, unsigned nbc, T *gram, size_t ngram,
                                                         unsigned nbg, size_t tail_off, int cpp, int K, double *wstat, Ctrl *ctrl, const double *hstat, int k,
-                                                        T tol, long long t, int do_check, const int *done_copy, const int *done) {
+                                                        T tol, long long t, int do_check, const int *done_copy, const int *done, unsigned *ticket) {
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     // system-scope 16-byte load at base + off: descriptor from the WAVE-UNIFORM base, the lane's part as the 32-bit offset operand (a
     // descriptor built from a per-lane pointer is wrapped in a waterfall loop: 64 serial one-lane loads per instruction; peer.hpp)
@@ -855,25 +878,11 @@ __global__ __launch_bounds__(256) void peer_pull_kernel(PullSrc ps, int rank, in
         }
     } else {
         NMFX_DONE_GUARD(done);
-        const int nchunks = n * cpp;
-        for (int e = threadIdx.x; e < 2 * K; e += blockDim.x) {
-            double s = 0.0;
-            for (int c0 = 0; c0 < nchunks; c0 += 16) {
-                double v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int c = (c0 + u < nchunks) ? c0 + u : nchunks - 1;
-                    v[u] = __hip_atomic_load(reinterpret_cast<const double *>(ps.chunk[c / cpp] + tail_off) + (int64_t)(c % cpp) * 2 * K + e, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (c0 + u < nchunks) s += v[u];
-            }
-            wstat[e] = s;
-        }
-        __syncthreads();
-        if (do_check) check_body<T>(ctrl, wstat, hstat, k, tol, t, nullptr);
+        auto ld = [&](int c, int e) {
+            return __hip_atomic_load(reinterpret_cast<const double *>(ps.chunk[c / cpp] + tail_off) + (int64_t)(c % cpp) * 2 * K + e, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_SYSTEM);
+        };
+        stats_sum_check<T>(ld, n * cpp, K, wstat, ticket, b - ((unsigned)n * nbc + nbg), gridDim.x - ((unsigned)n * nbc + nbg), ctrl, hstat, k, tol, t, do_check);
     }
 }
 

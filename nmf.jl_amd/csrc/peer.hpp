@@ -20,8 +20,8 @@
 //   data     2 parities x nranks slots of slot_bytes: collective s uses parity s & 1, slot q receives rank q's contribution
 // A collective (or a group of them: PeerComm::group_start / group_end) with sequence number s is
 //   push    : every rank stores its contribution(s) into slot[s & 1][rank] of the destination windows (write-through stores)
-//   signal  : one tiny launch behind the push: flag[rank] = s in every destination window (system-scope store)
-//   wait    : ONE single-block launch spins until flag[q] >= s for every q (bounded: wall clock), system-scope acquire
+//   signal  : behind the push: flag[rank] = s in every destination window (system-scope store behind a release fence)
+//   wait    : the SAME single-block launch then spins until flag[q] >= s for every q (bounded: wall clock), system-scope acquire
 //   read    : the consumer sums / copies the slots in RANK ORDER q = 0 .. n-1 -- the order LocalComm's kernels use, so the two
 //             transports agree bit for bit (tests/test_gpu_peer.py).
 // Only single-block launches ever spin: a grid-wide consumer that polled would occupy the whole GPU while the peers it waits for
@@ -186,18 +186,18 @@ static __global__ __launch_bounds__(256) void peer_push_kernel(PeerWin w, size_t
             __builtin_amdgcn_raw_buffer_store_b8(s[i], peer_rsrc(d + i), 0, 0, PEER_AUX);
     }
 }
-// signal: "everything this rank pushed for collective `seq` has left" -> flag[rank] = seq in every window (lane q -> rank q)
-static __global__ void peer_signal_kernel(PeerWin w, int rank, int n, unsigned seq) {
-    if (peer_aborted(w.p[rank])) return;   // ... and nothing is signalled: a peer that has not failed yet times out on this rank's flag
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    const int q = threadIdx.x;
-    if (q < n) peer_store_u32(reinterpret_cast<unsigned *>(w.p[q] + PEER_FLAG_OFF) + rank, seq);
-}
 // wait (ONE block): until every rank's flag has reached seq; bounded by the wall clock (100 MHz ticks)
-static __global__ void peer_wait_kernel(PeerWin w, int rank, int n, unsigned seq, unsigned long long timeout_ticks) {
+// signal != 0: the launch signals first (round 6: signal and wait of a collective in ONE launch -- a launch boundary less per exchange,
+// ~3 us at the 8-rank shard shape; still a single block that spins, so ranks that share a device keep scheduling each other)
+static __global__ void peer_wait_kernel(PeerWin w, int rank, int n, unsigned seq, unsigned long long timeout_ticks, int signal, int wait) {
     const int q = threadIdx.x;
     unsigned char *mine = w.p[rank];
     unsigned *abortw = reinterpret_cast<unsigned *>(mine + PEER_ABORT_OFF);
+    if (signal && !peer_aborted(mine)) {   // (after a time-out nothing is signalled any more: a peer that has not failed yet times out on this rank's flag)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (q < n) peer_store_u32(reinterpret_cast<unsigned *>(w.p[q] + PEER_FLAG_OFF) + rank, seq);
+    }
+    if (!wait) return;
     if (q < n) {
         const unsigned *f = reinterpret_cast<const unsigned *>(mine + PEER_FLAG_OFF) + q;
         const unsigned long long t0 = wall_clock64();
@@ -428,8 +428,7 @@ struct PeerComm : Comm {
                 hipLaunchKernelGGL(peer_push_kernel, dim3(grid_for(b / 16 + 1), n), dim3(256), 0, s, win, dst, reinterpret_cast<const unsigned char *>(o.send), b, (size_t)0, rank);
             }                           // kind 3: pushed by the producer itself (direct_* below)
         }
-        hipLaunchKernelGGL(peer_signal_kernel, dim3(1), dim3(64), 0, s, win, rank, n, sq);
-        if (!sim) hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, win, rank, n, sq, timeout_ticks);
+        hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, win, rank, n, sq, timeout_ticks, 1, sim ? 0 : 1);
         for (const Op &o : ops) {
             const size_t src = reg + o.off;
             if (o.kind == 0 || o.kind == 1) {
@@ -503,8 +502,7 @@ struct PeerComm : Comm {
             unsigned char *piece = reinterpret_cast<unsigned char *>(buf) + o;
             if (rank == root)
                 hipLaunchKernelGGL(peer_push_kernel, dim3(grid_for(b / 16 + 1), nranks), dim3(256), 0, s, win, reg + (size_t)root * slot_bytes, piece, b, (size_t)0, rank);
-            hipLaunchKernelGGL(peer_signal_kernel, dim3(1), dim3(64), 0, s, win, rank, nranks, sq);
-            if (!sim) hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, win, rank, nranks, sq, timeout_ticks);
+            hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, win, rank, nranks, sq, timeout_ticks, 1, sim ? 0 : 1);
             if (rank != root)
                 hipLaunchKernelGGL(peer_gather_kernel, dim3(grid_for(b / 16 + 1), 1), dim3(256), 0, s, piece, mine, reg + (size_t)root * slot_bytes, slot_bytes, b);
             ck(hipGetLastError(), "peer broadcast launch");

@@ -185,6 +185,11 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // Float64, k = 128: 26 against 28 us).  nmfx_pdsolve, the exported pdsolve!, always takes the substitution route.
     // nmfx_opts.h_solve picks the route of the H solve (NMFX_POTRS=1 in the environment still forces substitution: A/B runs)
     // (round 5: with the strip kernel the substitution is the faster route AND the reference's, so AUTO takes it wherever that kernel exists)
+    // (an EXPLICIT request for the substitution route that cannot be honoured -- k beyond the strip kernel and a panel that does not
+    // fit the LDS -- is an error, not a silent change of arithmetic: the caller asked for the reference's potrs! and must be able to
+    // tell which route ran)
+    if (o.h_solve == NMFX_HSOLVE_POTRS && !potrs_route_ok())
+        throw StatusError{NMFX_ERR_UNSUPPORTED, "h_solve = NMFX_HSOLVE_POTRS: the substitution route does not exist for this k (use NMFX_HSOLVE_AUTO or NMFX_HSOLVE_PRODUCT)"};
     const bool subst = (o.h_solve == NMFX_HSOLVE_POTRS || (o.h_solve == NMFX_HSOLVE_AUTO && (potrs_iter || strip_ok()))) && potrs_route_ok();
     auto factor_under = [&](T *G, T lambda, const char *t1, const char *t2, bool with_potri) {
         HIP_TRY(hipEventRecord(ev_fork, stream));

@@ -551,6 +551,11 @@ template <typename T> class Solver : public SolverBase {
     int w_pieces = 1;                     // Gram tail pieces of the last fused X*H' launch
     int h_stat_chunks = 1;                // r-tiles of the last H update (chunks of its statistics partials)
     bool check_fused = false;             // the stop check of this iteration already ran inside stats_check_kernel
+    // stats_sum_check's arrival ticket (kernels.hpp): the partial sums of the row-sharded step's stop statistics are taken by
+    // STAT_BLOCKS blocks, the last one to arrive runs the rule
+    static constexpr unsigned STAT_BLOCKS = 8;
+    DevBuf<unsigned> stat_ticket_buf;
+    unsigned *stat_ticket() { stat_ticket_buf.ensure(32); return stat_ticket_buf.p; }
     bool rs_fused() const { return rs_fused_enabled && row_sharded() && fuse_gram && K % 128 == 0 && !use_bf16x3(); }
     bool row_sharded() const { return sharded() && comm_mode != NMFX_COMM_REPLICATED_W && Pc > 0 && Pc % 128 == 0; }
     // Pipelined exchange (pipeline_impl.hpp; NMFX_COMM_PIPELINED, MultUpdate-MSE): the W side runs per row super-chunk, chunk

@@ -284,9 +284,9 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
         });
         gramw_sharded_valid = o.update_H != 0;
         timed("stats_check", 0.0, 0.0, [&] {
-            hipLaunchKernelGGL(stats_check_kernel<T>, dim3(1), dim3(256), 0, stream, reinterpret_cast<const double *>(Wblk[wb ^ 1].p + (size_t)Pc * K * sizeof(T)), nranks * cpp, (int)K,
+            hipLaunchKernelGGL(stats_check_kernel<T>, dim3(STAT_BLOCKS), dim3(256), 0, stream, reinterpret_cast<const double *>(Wblk[wb ^ 1].p + (size_t)Pc * K * sizeof(T)), nranks * cpp, (int)K,
                                wstat.p, ctrl, o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done, cpp,
-                               (int64_t)(blk_chunk / sizeof(double)));
+                               (int64_t)(blk_chunk / sizeof(double)), stat_ticket());
             HIP_TRY(hipGetLastError());
         });
         check_fused = fuse_check;
@@ -441,9 +441,9 @@ template <typename T> void Solver<T>::multmse_w_rows_fused_peer(const nmfx_opts 
         timed("pull_W_rows+stats_check", 0.0, ((double)(G - 1) * 2.0 * Pc * K + (double)G * K * K) * sizeof(T), [&] {
             const unsigned nbc = (unsigned)std::max<size_t>(1, std::min<size_t>((blk_chunk / 16 + 1023) / 1024, 128));   // blocks per peer chunk
             const unsigned nbg = o.update_H ? (unsigned)std::min<int64_t>(((int64_t)K * K * sizeof(T) / 16 + 255) / 256, 256) : 0u;
-            hipLaunchKernelGGL(peer_pull_kernel<T>, dim3((unsigned)G * nbc + nbg + 1u), dim3(256), 0, stream, ps, rank, G, Wblk[wb ^ 1].p, blk_chunk, nbc, gramW_p,
+            hipLaunchKernelGGL(peer_pull_kernel<T>, dim3((unsigned)G * nbc + nbg + STAT_BLOCKS), dim3(256), 0, stream, ps, rank, G, Wblk[wb ^ 1].p, blk_chunk, nbc, gramW_p,
                                (size_t)K * K, nbg, (size_t)Pc * K * sizeof(T), cpp, (int)K, wstat.p, ctrl, o.update_H ? hstat.p : (const double *)nullptr, (int)k,
-                               (T)o.tol, t, fuse_check ? 1 : 0, fuse_check ? (const int *)nullptr : done, done);
+                               (T)o.tol, t, fuse_check ? 1 : 0, fuse_check ? (const int *)nullptr : done, done, stat_ticket());
             HIP_TRY(hipGetLastError());
         });
         check_fused = fuse_check;

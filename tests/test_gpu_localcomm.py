@@ -436,3 +436,41 @@ def test_replicates_over_ranks_on_the_peer_windows_and_update_h_false(built):
         for W, H, niters, conv, objv, best in out:
             assert best == bs and niters == rs.niters and objv == rs.objvalue
             assert np.array_equal(W, Ws) and np.array_equal(H, Hs)
+
+
+@pytest.mark.parametrize("case", ["posdef_on_one_rank", "bad_argument_and_a_rank_without_a_replicate"])
+def test_replicates_over_ranks_a_failing_replicate_fails_every_rank_instead_of_hanging(built, case):
+    """A replicate that throws (PosDefException of a ProjectedALS factorisation -- replicate 1 from an all-zero W0 with lambda = 0 --, or an
+    argument error) must not take its rank out of the collectives the other ranks enter next: every rank raises the error of the first
+    failing replicate in replicate order, like the reference's sequential loop (src/interf.jl:85-101), and nobody waits for anybody."""
+    T = np.float64
+    p, n, k = 200, 180, 5
+    X, W0, H0 = planted(p, n, k, T, seed=3, normalize=False)
+    if case == "posdef_on_one_rank":
+        alg, G, R, kw, want = "projals", 2, 4, dict(maxiter=5, tol=1e-6, lambda_w=0.0, lambda_h=0.0), nmfx.PosDefException
+        W0 = np.zeros_like(W0)
+    else:
+        alg, G, R, kw, want = "multmse", 4, 3, dict(maxiter=5, tol=1e-6, lambda_w=-1.0), nmfx.ArgumentError
+    group = nmfx.LocalGroup(G)
+    raised = [None] * G
+
+    def worker(r):
+        try:
+            with nmfx.Context(T, p, n, k) as ctx:
+                ctx.comm_init_local(group, r)
+                ctx.comm_set_mode("replicas")
+                ctx.set_X(X)
+                W, H = W0.copy(order="F"), H0.copy(order="F")
+                ctx.solve_replicates(ALG[alg], nmfx.make_opts(T, **kw), R, 99, alg == "projals", W, H)
+                raised[r] = "returned"
+        except Exception as e:  # noqa: BLE001
+            raised[r] = e
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not any(t.is_alive() for t in th), "a rank is still waiting in a collective"
+    group.close()
+    assert all(isinstance(e, want) for e in raised), raised

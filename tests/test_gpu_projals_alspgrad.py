@@ -394,3 +394,25 @@ def test_alspgrad_exact_gradient_mode(built, T):
     else:
         assert abs(r.info["inner_iters"] - ci) <= max(2, 0.02 * ci) and abs(r.info["backtracks"] - cb) <= max(4, 0.02 * cb)
         assert rel_trace_err(r.trace, ro.trace) < TOL_ALSPGRAD_F32
+
+
+def test_projals_explicit_potrs_route_that_does_not_exist_is_an_error(built):
+    """h_solve = "potrs" asks for the reference's substitution route (src/utils.jl:63-70).  Where neither substitution kernel exists
+    (padded k beyond the strip kernel's 512 and a panel that does not fit the LDS) the library used to run the product form silently;
+    it now says so (NMFX_ERR_UNSUPPORTED), while "auto" and "product" keep working on the same problem."""
+    T = np.float32
+    p, n, k = 700, 1024, 576
+    rng = np.random.default_rng(2)
+    X = np.asfortranarray(rng.random((p, n)).astype(T))
+    W0 = np.asfortranarray(rng.random((p, k)).astype(T))
+    H0 = np.zeros((k, n), dtype=T, order="F")
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        for route in ("auto", "product"):
+            ctx.set_factors(W0, H0)
+            res, _ = ctx.iterate(2, nmfx.make_opts(T, maxiter=2, tol=1e-30, lambda_w=0.5, lambda_h=0.5, h_solve=route))
+            assert res.niters == 2 and np.isfinite(res.objvalue)
+        ctx.set_factors(W0, H0)
+        with pytest.raises(Exception) as ei:
+            ctx.iterate(2, nmfx.make_opts(T, maxiter=2, tol=1e-30, lambda_w=0.5, lambda_h=0.5, h_solve="potrs"))
+        assert "NMFX_HSOLVE_POTRS" in str(ei.value)

@@ -17,14 +17,14 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     const bool wrows = !left && row_sharded();
     const int64_t Rw = wrows ? Pc : P;                                     // rows of the W block this call works on
     const int64_t rows = left ? K : Rw, cols = left ? N : K, ldz = left ? K : P;
-    work[3].ensure((size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K));
-    T *G = work[3].p + (wrows ? row0 : 0);
-    // Gram*D of the last two trial points (EpiPgStep): the accepted one turns G into the next inner iteration's gradient
-    work[4].ensure((size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K));
-    work[5].ensure((size_t)std::max<int64_t>((int64_t)K * N, (int64_t)P * K));
-    T *GD0 = work[4].p + (wrows ? row0 : 0), *GD1 = work[5].p + (wrows ? row0 : 0);
-    pg_part.ensure((size_t)3 * 65536 + 8);
-    double *pg_red = pg_part.p + (size_t)3 * 65536;                        // the rank-local sums on their way through a collective
+    // the rotating (Z, G) sets (pgrad.hpp): three of each, every set with the layout and leading dimension of Z itself
+    const int64_t set_stride = std::max<int64_t>((int64_t)K * N, (int64_t)P * K);
+    work[3].ensure((size_t)3 * set_stride);
+    work[4].ensure((size_t)3 * set_stride);
+    T *GS = work[3].p + (wrows ? row0 : 0);
+    T *ZS = work[4].p + (wrows ? row0 : 0);
+    pg_part.ensure((size_t)PG_NSUM * 65536 + 8);
+    double *pg_red = pg_part.p + (size_t)PG_NSUM * 65536;                  // the rank-local sums on their way through a collective
     if (!pg_state) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pg_state), sizeof(PgState)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pg_host), sizeof(PgState)));
@@ -38,55 +38,49 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     const bool tiny_ok = reduce_scalars && comm->tiny_capable();                 // peer transport: the scalars travel inside the decision kernels
     const T epsT = std::numeric_limits<T>::epsilon();
     const int *idle = &pg_state->idle, *gate = &pg_state->gate;
-    // G = Gram*Z - B  (+ projgradnorm^2 partials)            :124-130 / :280-286
+    // ~2048 blocks: row chunks of >= 1024 rows, the rest of the parallelism from the columns
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, rows / 1024));
+    const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cols, 2048 / gx));
+    // Z -> set 0 (base = 0 in the fresh state)
+    hipLaunchKernelGGL(pg_copy_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, Z, ZS, set_stride, rows, cols, ldz, pg_state, 0);
+    HIP_TRY(hipGetLastError());
+    // G = Gram*Z - B  (+ projgradnorm^2 partials) of the CURRENT set            :124-130 / :280-286
     auto grad = [&]() {
-        EpiGradNorm<T> e{B, Z, G, left ? K : P, pg_part.p, 0.0};
-        if (left) gemm<KCONTIG, KCONTIG>("gemm_pg_grad", Z, K, N, Gram, K, K, K, 1, true, e, gate, 4.0 * K * N * sizeof(T));
-        else gemm<KSTRIDED, KSTRIDED>("gemm_pg_grad", Gram, K, K, Z, P, Rw, K, 1, false, e, gate, 4.0 * Rw * K * sizeof(T));
+        EpiGradNorm<T> e{B, ZS, GS, left ? K : P, pg_part.p, 0.0};
+        e.st = pg_state; e.set_stride = set_stride;
+        Seg sg;
+        sg.sel = &pg_state->base;
+        if (left) { sg.a_sel = set_stride; gemm<KCONTIG, KCONTIG>("gemm_pg_grad", ZS, K, N, Gram, K, K, K, 1, true, e, gate, 4.0 * K * N * sizeof(T), sg); }
+        else { sg.b_sel = set_stride; gemm<KSTRIDED, KSTRIDED>("gemm_pg_grad", Gram, K, K, ZS, P, Rw, K, 1, false, e, gate, 4.0 * Rw * K * sizeof(T), sg); }
         return last_blocks;
     };
-    // one back-tracking step: Gram * D(alpha) with D formed in the operand loader, scalars reduced in the epilogue
+    // one back-tracking step: Gram * D(alpha) with D formed in the operand loader from the current set, the trial point and its gradient
+    // written by the epilogue into one of the other two sets, the four scalars reduced there as well
     auto step = [&](bool last_enqueued) {
-        EpiPgStep<T> e{Z, G, GD0, GD1, left ? K : P, pg_state, pg_part.p, (T)0, (T)0, 0, 0.0, 0.0, 0.0};
+        EpiPgStep<T> e{ZS, GS, set_stride, left ? K : P, pg_state, pg_part.p, (T)0, (T)0, 0, 0.0, 0.0, 0.0, 0.0};
         Seg sg;
         sg.alpha_ptr = &pg_state->alpha;
+        sg.sel = &pg_state->base;
         int nblk;
         if (left) {
-            sg.a_aux = G;
-            gemm<KCONTIG, KCONTIG, 1>("gemm_pg_step", Z, K, N, Gram, K, K, K, 1, true, e, idle, 4.0 * K * N * sizeof(T), sg);
+            sg.a_aux = GS; sg.a_sel = set_stride; sg.aaux_sel = set_stride;
+            gemm<KCONTIG, KCONTIG, 1>("gemm_pg_step", ZS, K, N, Gram, K, K, K, 1, true, e, idle, 5.0 * K * N * sizeof(T), sg);
         } else {
-            sg.b_aux = G;
-            gemm<KSTRIDED, KSTRIDED, 2>("gemm_pg_step", Gram, K, K, Z, P, Rw, K, 1, false, e, idle, 4.0 * Rw * K * sizeof(T), sg);
+            sg.b_aux = GS; sg.b_sel = set_stride; sg.baux_sel = set_stride;
+            gemm<KSTRIDED, KSTRIDED, 2>("gemm_pg_step", Gram, K, K, ZS, P, Rw, K, 1, false, e, idle, 5.0 * Rw * K * sizeof(T), sg);
         }
         nblk = last_blocks;
-        // sharded: the three sums are global (ONE step size for all of Z, alspgrad.jl:150-155).  Peer transport: the decision kernel
+        // sharded: the four sums are global (ONE step size for all of Z, alspgrad.jl:150-155).  Peer transport: the decision kernel
         // exchanges the rank-local sums itself (16-byte tagged granules, no collective launch).  Other transports: local sums by a
-        // one-block launch, all-reduce of 3 doubles (a count that does not depend on the rank's block grid), then the decision.
+        // one-block launch, all-reduce of 4 doubles (a count that does not depend on the rank's block grid), then the decision.
         if (reduce_scalars && !tiny_ok) {
-            hipLaunchKernelGGL(pg_local_sum_kernel, dim3(1), dim3(256), 0, stream, pg_part.p, nblk, 3, pg_red);
-            comm->all_reduce(pg_red, 3, CT_F64, false, stream);
+            hipLaunchKernelGGL(pg_local_sum_kernel, dim3(1), dim3(256), 0, stream, pg_part.p, nblk, PG_NSUM, pg_red);
+            comm->all_reduce(pg_red, PG_NSUM, CT_F64, false, stream);
             hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_red, 1, beta, sigma, epsT, traceiter, last_enqueued ? 1 : 0, TinyAR());
         } else {
             hipLaunchKernelGGL(pg_decide_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, nblk, beta, sigma, epsT, traceiter, last_enqueued ? 1 : 0,
                                reduce_scalars ? comm->tiny() : TinyAR());
         }
-    };
-    // ~2048 blocks: row chunks of >= 1024 rows, the rest of the parallelism from the columns
-    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, rows / 1024));
-    const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cols, 2048 / gx));
-    // H <- Hn / H <- Hp of the step that broke the loop (no-op while the loop is still running or unchanged)
-    auto apply = [&](bool with_clear) {
-        hipLaunchKernelGGL(pg_apply_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, Z, G, rows, cols, ldz, pg_state, with_clear ? 0 : 1);
-        if (with_clear) hipLaunchKernelGGL(pg_clear_apply_kernel, dim3(1), dim3(1), 0, stream, pg_state);
-        HIP_TRY(hipGetLastError());
-    };
-    // the same accept fused with the gradient of the point it leads to: G += Gram*D(accepted), projgradnorm^2 partials
-    auto advance = [&]() {
-        timed("pg_advance", 0.0, 5.0 * rows * cols * sizeof(T), [&] {
-            hipLaunchKernelGGL(pg_advance_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, Z, G, GD0, GD1, rows, cols, ldz, pg_state, pg_part.p);
-            HIP_TRY(hipGetLastError());
-        });
-        return (int)(gx * gy);
     };
     // A full product G = Gram*Z - B every REFRESH inner iterations bounds the rounding drift of the running sum
     // (the first iteration of a sub-solve always: Gram and B are new)
@@ -129,14 +123,12 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
     while (!converged && t < maxiter) {
         const int batch = (int)std::min<long long>(AHEAD, (long long)maxiter - t);
         for (int b = 0; b < batch; ++b) {
-            int nblk;
-            if ((t + b) % REFRESH == 0) {
-                if (t + b > 0) apply(false);   // pg_begin_kernel clears the request
-                nblk = grad();
-            } else {
-                nblk = advance();
-            }
-            if (reduce_scalars && !tiny_ok) {
+            // (the accepted trial point of the search before already IS the current set, its projgradnorm^2 sits in PgState::red[3]:
+            // between two full products an inner iteration starts without any pass over Z and G)
+            const int nblk = ((t + b) % REFRESH == 0) ? grad() : 0;
+            if (nblk == 0) {
+                hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_part.p, 0, tolg, TinyAR());
+            } else if (reduce_scalars && !tiny_ok) {
                 hipLaunchKernelGGL(pg_local_sum_kernel, dim3(1), dim3(256), 0, stream, pg_part.p, nblk, 1, pg_red);
                 comm->all_reduce(pg_red, 1, CT_F64, false, stream);
                 hipLaunchKernelGGL(pg_begin_kernel<T>, dim3(1), dim3(256), 0, stream, pg_state, pg_red, 1, tolg, TinyAR());
@@ -162,7 +154,9 @@ long long Solver<T>::pg_subsolve(bool left, T *Z, const T *Gram, const T *B, int
         converged = pg_host->converged != 0;
         retune();
     }
-    apply(true);                                                           // the accept of the last executed search, if any
+    // the current set back into Z (the accept of the last executed search, if any, is part of it)
+    hipLaunchKernelGGL(pg_copy_kernel<T>, dim3(gx, gy), dim3(256), 0, stream, Z, ZS, set_stride, rows, cols, ldz, pg_state, 1);
+    HIP_TRY(hipGetLastError());
     if (const char *e = dev_env("NMFX_PG_HIST"); e && e[0] == '1' && pg_host) {
         std::fprintf(stderr, "[nmfx] pg_subsolve(%s): %lld inner iterations, searches by steps:", left ? "H" : "W", t);
         for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %d", pg_host->hist[i]);

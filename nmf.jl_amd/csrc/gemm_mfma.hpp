@@ -83,7 +83,17 @@ template <typename T> struct GemmArgs {
     // with leading dimension ldb = b_blk_k, block q starting b_blk_stride elements after block q - 1 (the row-sharded W as the
     // all-gather delivers it: rank q's rows x k, contiguous).  A block's k-range must not straddle blocks (b_blk_k % kchunk == 0).
     int64_t b_blk_k = 0, b_blk_stride = 0;
+    // Operands that live in one of several equally spaced buffer SETS whose index is only known on the device (the projected-gradient
+    // sub-solver's rotating (Z, G) sets, pgrad.hpp): set = *sel, read once at kernel start; the operand's base moves by set * stride
+    // elements (a stride of 0 leaves an operand alone).
+    const int *sel = nullptr;
+    int64_t a_sel = 0, b_sel = 0, aaux_sel = 0, baux_sel = 0;
 };
+
+// Epilogues that stage their output through the block's LDS (free behind the main loop) declare `static constexpr bool USES_LDS`: the
+// kernel hands them the buffer before the first apply() and calls row_done(i) behind every row of MFMA tiles (EpiStorePeer).
+template <typename E, typename = void> struct epi_uses_lds : std::false_type {};
+template <typename E> struct epi_uses_lds<E, std::void_t<decltype(E::USES_LDS)>> : std::true_type {};
 
 // what an epilogue may need to know about the block / wave it runs in
 struct TileCtx {
@@ -357,6 +367,13 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
     using LoadB = TileLoader<T, LB, BC, NT>;
 
     if (g.done != nullptr && *reinterpret_cast<const volatile int *>(g.done) != 0) return;
+    if (g.sel != nullptr) {
+        const int64_t set = *g.sel;
+        g.A += set * g.a_sel;
+        g.B += set * g.b_sel;
+        if (g.a_aux != nullptr) g.a_aux += set * g.aaux_sel;
+        if (g.b_aux != nullptr) g.b_aux += set * g.baux_sel;
+    }
     // Two blocks share a CU for the whole launch (one wave of each per SIMD).  With equal priorities the SIMD's issue arbiter
     // alternates between them; raising ONE of the two lets that wave run as if it were alone (an in-order wave keeps the matrix
     // pipe ~85-90 % busy by itself) while the other fills its gaps.  1: second half of the grid; 2: odd blocks; 3: every block.
@@ -612,6 +629,7 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
         __syncthreads();   // the staging buffers are re-used by the next segment / the epilogue reductions
 
         // Epilogue.
+        if constexpr (epi_uses_lds<Epi>::value) epi.set_lds(smem, wave, WTC, lane);
         epi.begin();
         // Two phases per ROW of MFMA tiles: issue every global load the epilogue needs for the row (prefetch), then
         // compute and store (apply).  (Inputs and outputs of an epilogue may alias as far as the compiler knows, so a
@@ -628,10 +646,13 @@ __global__ __launch_bounds__(WGR *WGC * 64, (BR * BC <= 64 * 128) ? 2 : 1) void 
 #pragma unroll
                 for (int reg = 0; reg < M::NACC; ++reg)
                     epi.apply(i * MT + reg_row(reg), j * MT, acc[i][j][reg], j, pre[i & 1][j][reg]);
+            if constexpr (epi_uses_lds<Epi>::value) epi.row_done(i * MT);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!EARLY && i + 1 < TR)
                 prefetch_row(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
         });
+        // (the next segment's prologue stages operands into the buffer such an epilogue may still be reading in a slower wave)
+        if constexpr (epi_uses_lds<Epi>::value) __syncthreads();
     }
     epi.template finish<MT, TC, WGR, WGC>(reinterpret_cast<double *>(smem), tctx);
 }
@@ -690,6 +711,30 @@ template <typename T> struct EpiStorePeer {
     rsrc_t rd;
     LaneAddr<T> la;
     bool remote;
+    // Round 6: the remote stores leave as 16-BYTE write-through stores.  The MFMA result layout gives a lane one element per output row
+    // (lanes run along c), so a direct store is 4 bytes per lane -- and a system-scope 4-byte store is a fabric write of its own (the
+    // hardware guide prices `dword sc1` stores at ~6x the time per byte of `dwordx4`; over xGMI a 16-byte packet payload is the
+    // difference between a fifth and most of a link's rate).  The wave therefore stages every row of MFMA tiles (32 rows x its 64
+    // columns) in the block's LDS -- free behind the main loop -- and reads it back row-wise: 16 lanes x 16 bytes = one 256-byte row
+    // segment per store instruction.  Float32 with 64-wide wave tiles (the 128 x 128 block tile of the big products); anything else keeps
+    // the direct stores.
+    // MEASURED ON THE ONE-GPU STAND-IN AND NOT ENABLED (stage16 = false): with every window in local uncached memory the staged form is
+    // SLOWER -- X_g H_g' 137.5 -> 147.6 us at the 8-rank shard shape, the sequence 0.330 -> 0.340 ms
+    // (profiles/r06_simranks8_p2p_staged_16_byte_peer_stores_rejected_all_events.json): local memory takes 4-byte write-through stores
+    // at the rate the epilogue issues them, and the LDS round trip is pure cost.  Whether xGMI changes the sign cannot be measured on
+    // this box; the path stays behind the flag for the first run on a node where it can.
+    static constexpr bool USES_LDS = true;
+    static constexpr int LDS_PITCH = 72;           // floats per staged row: rows 4 apart (the two half-waves of a store) fall into disjoint banks
+    T *lds = nullptr;
+    bool staged = false;
+    bool stage16 = false;                          // NMFX_P2P_STAGE16=1 (development switch, Solver::times_ht)
+    int lane_ = 0;
+    int64_t ldc_ = 0;
+    __device__ __forceinline__ void set_lds(T *smem, int wave, int wtc, int lane) {
+        staged = stage16 && sizeof(T) == 4 && wtc == 64;
+        lds = smem + wave * (32 * LDS_PITCH);
+        lane_ = lane;
+    }
     struct Pre {};
     static constexpr bool EARLY = false, HEAVY = false;
     __device__ __forceinline__ void setup(int split, const TileCtx &t) {
@@ -703,13 +748,35 @@ template <typename T> struct EpiStorePeer {
         } else { dst = C2 + (int64_t)(-1 - split) * stride2 - (c_off + r_off * ld2); ldc = ld2; remote = false; }
         rd = tile_rsrc(dst, ldc, t);
         la.init(t, ldc);
+        ldc_ = ldc;
     }
     __device__ __forceinline__ void begin() {}
     __device__ __forceinline__ Pre prefetch(int, int) const { return Pre{}; }
+    // behind the apply() calls of the MFMA tile row that starts at wave-tile row `row0`: the staged 32 x 64 block leaves as 16-byte stores
+    __device__ __forceinline__ void row_done(int row0) {
+        if constexpr (sizeof(T) == 4) {
+            if (!(remote && staged)) return;
+            typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = lane_ + 64 * q, row = idx >> 4, c4 = (idx & 15) * 4;
+                const v4u_t v = *reinterpret_cast<const v4u_t *>(lds + row * LDS_PITCH + c4);
+                const uint32_t off = (uint32_t)(((int64_t)(row0 + row) * ldc_ + c4) * (int64_t)sizeof(T));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rd, (int)off, 0, 17);
+            }
+        }
+    }
     __device__ __forceinline__ void apply(int ro, int co, T v, int /*jt*/, const Pre &) {
         if (remote) {
-            if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, (int)la.lb, (int)la.soff(ro, co), 17);
-            else {
+            if constexpr (sizeof(T) == 4) {
+                if (staged) {
+                    // (wave-tile row ro + rl, column co + cl; the lane part is the same for every element: la.lb = (cl + rl * ldc) * 4)
+                    const int rl = 4 * (lane_ >> 5), cl = lane_ & 31;
+                    lds[((ro & 31) + rl) * LDS_PITCH + co + cl] = v;
+                    return;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, (int)la.lb, (int)la.soff(ro, co), 17);
+            } else {
                 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, v), rd, (int)la.lb, (int)la.soff(ro, co), 17);
             }

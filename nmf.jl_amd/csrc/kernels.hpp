@@ -560,6 +560,61 @@ __global__ void gathered_to_full_kernel(T *full, const unsigned char *recv, int 
         }
 }
 
+// The ranks' (or chunks') stop_condition partials added in chunk order, then the stop rule -- by NB = gridDim blocks (round 6; one block
+// before): block b owns the outputs e in [b * 2K / NB, (b + 1) * 2K / NB), one thread per output, 32 of the output's chunk values
+// requested before the first add (the adds stay in chunk order: the bits of the one-block form, whose 2K sums of 64 values each were
+// four dependent round trips per thread, 10.5 us at the 8-rank shard shape), and the LAST block to arrive (a ticket: NB agent-scope
+// atomics) runs check_body on the complete wstat.  `ld(c, e)` = partial of chunk c, output e.
+template <typename T, typename LD>
+__device__ __forceinline__ void stats_sum_check(LD ld, int nchunks, int K, double *wstat, unsigned *ticket, unsigned b, unsigned nb, Ctrl *ctrl, const double *hstat,
+                                                int k, T tol, long long t, int do_check) {
+    const int per = (2 * K + (int)nb - 1) / (int)nb;
+    const int e0 = (int)b * per, e1 = (e0 + per < 2 * K) ? e0 + per : 2 * K;
+    for (int e = e0 + (int)threadIdx.x; e < e1; e += (int)blockDim.x) {
+        double s = 0.0;
+        for (int c0 = 0; c0 < nchunks; c0 += 32) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = ld((c0 + u < nchunks) ? c0 + u : nchunks - 1, e);
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (c0 + u < nchunks) s += v[u];
+        }
+        wstat[e] = s;
+    }
+    __shared__ int last_sm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int last = 1;
+        if (nb > 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (old % nb) == nb - 1;    // (the counter only ever grows: every launch adds exactly nb, or nothing behind the stop)
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        last_sm = last;
+    }
+    __syncthreads();
+    if (last_sm && do_check) check_body<T>(ctrl, wstat, hstat, k, tol, t, nullptr);
+}
+// The stop rule of the PREVIOUS iteration, riding in this iteration's combine launch (round 6): the row-sharded fused
+// step no longer ends in a one-block launch that adds the ranks' statistics and decides -- the next iteration's w_side_combine_kernel
+// carries nb extra blocks that do it (stats_sum_check on the statistics tails of the blocked W buffer).  Everything the next iteration
+// enqueued in front of its combine launch wrote ping-pong partners or scratch only, so a stop found here leaves iteration t's factors
+// intact.  nb == 0: nothing deferred.
+template <typename T> struct DeferChk {
+    const double *tails;     // statistics tail of rank 0's chunk in the blocked W buffer of iteration t
+    int nchunks, grp;        // chunks in total, chunks per rank
+    int64_t grp_stride;      // doubles between two ranks' tails
+    double *wstat;
+    Ctrl *ctrl;
+    const double *hstat;     // iteration t's H statistics (all-reduced), or nullptr
+    unsigned *ticket;
+    int K, k;
+    T tol;
+    long long t;
+    unsigned nb;
+};
 // Everything between the X_g H_g' launch and the exchange of the row-sharded MultUpdate-MSE step in ONE launch (three launches of
 // 6-17 us each at the 8-rank shard shape of the headline problem, where an iteration is 0.4 ms):
 //   blocks [0, nb1)         : split-K combine of the numerator slabs into the blocked send buffer (reduce_slabs_blocked_kernel)
@@ -579,9 +634,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void w_side_combine_kernel(T *dst_blk, const T *slabs, int64_t P, int64_t K, int64_t Pc, int nslab, int64_t stride,
                                                              T *gram, const T *gsrc, int64_t gcount, int gslabs, int64_t gstride,
                                                              const double *hpart, int hchunks, int hcount, double *hstat, unsigned nb1,
-                                                             unsigned nb2, const int *done, CombineDst<T> pd) {
+                                                             unsigned nb2, const int *done, CombineDst<T> pd, DeferChk<T> dc) {
     NMFX_DONE_GUARD(done);
     __shared__ T sm[4][64];
+    if (blockIdx.x >= gridDim.x - dc.nb) {   // the deferred stop rule of the iteration before (see DeferChk)
+        auto ld = [&](int c, int e) { return dc.tails[(int64_t)(c / dc.grp) * dc.grp_stride + (int64_t)(c % dc.grp) * 2 * dc.K + e]; };
+        stats_sum_check<T>(ld, dc.nchunks, dc.K, dc.wstat, dc.ticket, blockIdx.x - (gridDim.x - dc.nb), dc.nb, dc.ctrl, dc.hstat, dc.k, dc.tol, dc.t, 1);
+        return;
+    }
     if (blockIdx.x < nb1) {
         // 256 consecutive rows of one column per block (P is a multiple of 256): 32-bit index arithmetic, no 64-bit division
         const unsigned rb = (unsigned)(P / 256), a = blockIdx.x / rb, i = (blockIdx.x % rb) * 256u + threadIdx.x;
@@ -767,43 +827,6 @@ __global__ __launch_bounds__(256) void rows_tail_kernel(const T *Wold, const uns
     } else {
         reduce_slabs_vec_body<T>(gdst, gsrc, gnvec, gslabs, gstride, (int64_t)(blockIdx.x - nbs) * blockDim.x + threadIdx.x, gdst2);
     }
-}
-// The ranks' (or chunks') stop_condition partials added in chunk order, then the stop rule -- by NB = gridDim blocks (round 6; one block
-// before): block b owns the outputs e in [b * 2K / NB, (b + 1) * 2K / NB), one thread per output, 32 of the output's chunk values
-// requested before the first add (the adds stay in chunk order: the bits of the one-block form, whose 2K sums of 64 values each were
-// four dependent round trips per thread, 10.5 us at the 8-rank shard shape), and the LAST block to arrive (a ticket: NB agent-scope
-// atomics) runs check_body on the complete wstat.  `ld(c, e)` = partial of chunk c, output e.
-template <typename T, typename LD>
-__device__ __forceinline__ void stats_sum_check(LD ld, int nchunks, int K, double *wstat, unsigned *ticket, unsigned b, unsigned nb, Ctrl *ctrl, const double *hstat,
-                                                int k, T tol, long long t, int do_check) {
-    const int per = (2 * K + (int)nb - 1) / (int)nb;
-    const int e0 = (int)b * per, e1 = (e0 + per < 2 * K) ? e0 + per : 2 * K;
-    for (int e = e0 + (int)threadIdx.x; e < e1; e += (int)blockDim.x) {
-        double s = 0.0;
-        for (int c0 = 0; c0 < nchunks; c0 += 32) {
-            double v[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) v[u] = ld((c0 + u < nchunks) ? c0 + u : nchunks - 1, e);
-#pragma unroll
-            for (int u = 0; u < 32; ++u)
-                if (c0 + u < nchunks) s += v[u];
-        }
-        wstat[e] = s;
-    }
-    __shared__ int last_sm;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int last = 1;
-        if (nb > 1) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (old % nb) == nb - 1;    // (the counter only ever grows: every launch adds exactly nb, or nothing behind the stop)
-            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        last_sm = last;
-    }
-    __syncthreads();
-    if (last_sm && do_check) check_body<T>(ctrl, wstat, hstat, k, tol, t, nullptr);
 }
 template <typename T>
 // grp > 0: the partials arrive in groups of grp chunks, group q at partial + q * grp_stride doubles (the ranks' statistics tails

@@ -149,6 +149,7 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = dev_env("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_W_BLOCKED")) blk_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_P2P_PULL")) peer_pull_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_DEFER_CHECK")) defer_enabled = std::atoi(e) != 0;
         HIP_TRY(hipEventCreate(&ev_beg));
         HIP_TRY(hipEventCreate(&ev_end));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctrl), sizeof(Ctrl)));
@@ -206,7 +207,7 @@ template <typename T> class Solver : public SolverBase {
         stat_chunks_h = (int)std::max<int64_t>(1, std::min<int64_t>(1024, N / 16));   // 4 chips' worth of workgroups for the column-chunked passes over H
         stat_part.alloc((size_t)std::max<int64_t>(std::max(stat_chunks_w, stat_chunks_h), std::max(N, P) / 16) * 3 * K);   // smallk: one partial per 16-wide stripe; multdiv: 3 values per (chunk, component)
         wstat.alloc((size_t)2 * K);
-        hstat.alloc((size_t)2 * K);
+        hstat.alloc((size_t)4 * K);   // (x 2: by iteration parity while the stop rule is deferred, see defer_pending)
         svec.alloc((size_t)K);
         obj_part.alloc((size_t)2 * (P / 128) * (N / 128) + 4096);
         obj_extra.alloc(4);
@@ -556,6 +557,37 @@ template <typename T> class Solver : public SolverBase {
     static constexpr unsigned STAT_BLOCKS = 8;
     DevBuf<unsigned> stat_ticket_buf;
     unsigned *stat_ticket() { stat_ticket_buf.ensure(32); return stat_ticket_buf.p; }
+    // The stop rule of the row-sharded fused step (blocked residency) DEFERRED into the next iteration's combine launch (kernels.hpp:
+    // DeferChk): iteration t leaves its statistics in the tails of the blocked W buffer and sets defer_pending; the next combine launch
+    // -- or, at the host's poll points and at the end of the solve, a launch of its own (defer_flush) -- runs the rule for t.
+    // hstat is double-buffered by iteration parity while this is on (the combine launch that checks t writes t + 1's H statistics).
+    // NMFX_DEFER_CHECK=0: the rule in a launch of its own behind every iteration (round 5; A/B).
+    bool defer_enabled = true, defer_pending = false;
+    long long defer_t = 0;
+    nmfx_opts defer_opts;
+    double *hstat_of(long long t) { return hstat.p + ((defer_enabled && (t & 1)) ? (size_t)2 * K : (size_t)0); }
+    DeferChk<T> defer_args(unsigned nb) {
+        DeferChk<T> dc;
+        std::memset(&dc, 0, sizeof dc);
+        if (nb == 0 || !defer_pending) return dc;
+        dc.tails = reinterpret_cast<const double *>(Wblk[wb].p + (size_t)Pc * K * sizeof(T));
+        dc.nchunks = nranks * blk_cpp; dc.grp = blk_cpp;
+        dc.grp_stride = (int64_t)(blk_chunk / sizeof(double));
+        dc.wstat = wstat.p; dc.ctrl = ctrl;
+        dc.hstat = defer_opts.update_H ? hstat_of(defer_t) : (const double *)nullptr;
+        dc.ticket = stat_ticket();
+        dc.K = (int)K; dc.k = (int)k;
+        dc.tol = (T)defer_opts.tol; dc.t = defer_t; dc.nb = nb;
+        return dc;
+    }
+    void defer_flush() {
+        if (!defer_pending) return;
+        const DeferChk<T> dc = defer_args(STAT_BLOCKS);
+        hipLaunchKernelGGL(stats_check_kernel<T>, dim3(STAT_BLOCKS), dim3(256), 0, stream, dc.tails, dc.nchunks, (int)K, wstat.p, ctrl, dc.hstat, (int)k, dc.tol, dc.t, 1,
+                           done_flag(), dc.grp, dc.grp_stride, dc.ticket);
+        HIP_TRY(hipGetLastError());
+        defer_pending = false;
+    }
     bool rs_fused() const { return rs_fused_enabled && row_sharded() && fuse_gram && K % 128 == 0 && !use_bf16x3(); }
     bool row_sharded() const { return sharded() && comm_mode != NMFX_COMM_REPLICATED_W && Pc > 0 && Pc % 128 == 0; }
     // Pipelined exchange (pipeline_impl.hpp; NMFX_COMM_PIPELINED, MultUpdate-MSE): the W side runs per row super-chunk, chunk
@@ -683,6 +715,8 @@ template <typename T> class Solver : public SolverBase {
         const T *a_aux = nullptr, *b_aux = nullptr;   // operand computed on the fly (projected-gradient trial step)
         const double *alpha_ptr = nullptr;
         int64_t b_blk_k = 0, b_blk_stride = 0;        // B operand blocked along the contraction (GemmArgs)
+        const int *sel = nullptr;                     // operands in device-indexed buffer sets (GemmArgs::sel)
+        int64_t a_sel = 0, b_sel = 0, aaux_sel = 0, baux_sel = 0;
     };
     template <int LA, int LB, int AUX = 0, typename Epi>
     void gemm(const char *name, const T *A, int64_t lda, int64_t R, const T *B, int64_t ldb, int64_t C, int64_t Kdim,
@@ -696,6 +730,7 @@ template <typename T> class Solver : public SolverBase {
         g.tail_main = seg.tail_main; g.tail_per = seg.tail_per;
         g.a_aux = seg.a_aux; g.b_aux = seg.b_aux; g.alpha_ptr = seg.alpha_ptr;
         g.b_blk_k = seg.b_blk_k; g.b_blk_stride = seg.b_blk_stride;
+        g.sel = seg.sel; g.a_sel = seg.a_sel; g.b_sel = seg.b_sel; g.aaux_sel = seg.aaux_sel; g.baux_sel = seg.baux_sel;
         g.splits = splits;
         g.kchunk = (int)(Kdim / splits);
         g.c_fastest = c_fastest ? 1 : 0;
@@ -1083,6 +1118,7 @@ template <typename T> class Solver : public SolverBase {
                 for (int g = 0; g < EPI_MAX_PIECES; ++g) e.piece[g] = (g < nranks) ? peer_dst->num[g] : nullptr;
                 e.piece_rows = Pc;
                 e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = (int64_t)K * K; e.r_off = 0; e.c_off = P;
+                if (const char *ev = dev_env("NMFX_P2P_STAGE16")) e.stage16 = std::atoi(ev) != 0;   // 16-byte staged peer stores (gemm_mfma.hpp: measured slower on the stand-in)
                 big(sw, e, (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
             } else {
             EpiStore<T> e{direct ? numW_p : reg, direct ? Pc : P, w_stride, nullptr};

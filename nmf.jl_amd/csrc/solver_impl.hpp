@@ -227,21 +227,25 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
     times_ht(X.p, Hp, true, done, false, ht_active ? Ht[hcur].p : nullptr);
     w_blocked = false; w_defer_combine = false;
     const unsigned nb1 = w_direct ? 0u : (unsigned)(P / 256 * K), nb2 = (unsigned)((K * K + 63) / 64), nb3 = o.update_H ? (unsigned)((2 * K + 3) / 4) : 0u;
+    const bool fuse_check = o.track_objective == 0 && o.stop_sums == 0;
+    const bool defer = fuse_check && defer_enabled && blocked_residency_ok();   // the stop rule of this iteration rides in the NEXT combine launch
+    double *hs = defer ? hstat_of(t) : hstat.p;
     timed("combine_W", 0.0, ((double)P * K * (w_nslab + 1) + (double)K * K * (w_pieces + 1)) * sizeof(T), [&] {
-        hipLaunchKernelGGL(w_side_combine_kernel<T>, dim3(nb1 + nb2 + nb3), dim3(256), 0, stream, numW_p, slabs.p + slab_w_off, P, K, Pc, w_nslab,
+        const unsigned nbd = defer_pending ? STAT_BLOCKS : 0u;
+        hipLaunchKernelGGL(w_side_combine_kernel<T>, dim3(nb1 + nb2 + nb3 + nbd), dim3(256), 0, stream, numW_p, slabs.p + slab_w_off, P, K, Pc, w_nslab,
                            w_stride, gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, w_pieces, (int64_t)K * K, stat_part.p, h_stat_chunks,
-                           (int)(2 * K), hstat.p, nb1, nb2, done, CombineDst<T>{{}, {}, {}, 0});
+                           (int)(2 * K), hs, nb1, nb2, done, CombineDst<T>{{}, {}, {}, 0}, defer_args(nbd));
         HIP_TRY(hipGetLastError());
+        defer_pending = false;
     });
     timed("comm_reduce_scatter_numW", 0.0, (double)(P * K + K * K) * sizeof(T), [&] {
         comm->group_start();
         comm->reduce_scatter(numW_p, rs_out.p, (size_t)Pc * K, CT, stream);
         comm->all_reduce(gramH_p, (size_t)K * K, CT, false, stream);
-        if (o.update_H) comm->all_reduce(hstat.p, (size_t)2 * K, CT_F64, false, stream);
+        if (o.update_H) comm->all_reduce(hs, (size_t)2 * K, CT_F64, false, stream);
         comm->group_end();
     });
     const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(64 / nranks, Pc / 1024));   // statistics chunks per row block
-    const bool fuse_check = o.track_objective == 0 && o.stop_sums == 0;
     if (blocked_residency_ok()) {
         // ---- W stays in the all-gather's layout between iterations (solver.hpp: Wblk): no unpack launch ----------------------------
         blk_cpp = cpp;
@@ -283,12 +287,16 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
             comm->group_end();
         });
         gramw_sharded_valid = o.update_H != 0;
+        if (defer) {
+            defer_pending = true; defer_t = t; defer_opts = o;
+        } else {
         timed("stats_check", 0.0, 0.0, [&] {
             hipLaunchKernelGGL(stats_check_kernel<T>, dim3(STAT_BLOCKS), dim3(256), 0, stream, reinterpret_cast<const double *>(Wblk[wb ^ 1].p + (size_t)Pc * K * sizeof(T)), nranks * cpp, (int)K,
-                               wstat.p, ctrl, o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done, cpp,
+                               wstat.p, ctrl, o.update_H ? hs : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done, cpp,
                                (int64_t)(blk_chunk / sizeof(double)), stat_ticket());
             HIP_TRY(hipGetLastError());
         });
+        }
         check_fused = fuse_check;
         wb ^= 1;
         w_res_blocked = true;
@@ -323,7 +331,7 @@ template <typename T> void Solver<T>::multmse_w_rows_fused(const nmfx_opts &o, l
         hipLaunchKernelGGL(gather_stats_kernel<T>, dim3((unsigned)(nranks * cpp), (unsigned)K), dim3(256), 0, stream, Wn, Wo, ag_recv.p, chunk, P, Pc, cpp, (int)K,
                            stat_part.p, done);
         hipLaunchKernelGGL(stats_check_kernel<T>, dim3(1), dim3(256), 0, stream, stat_part.p, nranks * cpp, (int)K, wstat.p, ctrl,
-                           o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done);
+                           o.update_H ? hs : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done);
         HIP_TRY(hipGetLastError());
     });
     check_fused = fuse_check;
@@ -348,6 +356,9 @@ template <typename T> void Solver<T>::multmse_w_rows_fused_peer(const nmfx_opts 
     pc->group_start();
     pc->group_stream = stream;
     const size_t o_num = pc->direct_reserve(piece_b), o_gram = pc->direct_reserve(gram_b), o_hs = o.update_H ? pc->direct_reserve(hs_b) : 0;
+    const bool fuse_check0 = o.track_objective == 0 && o.stop_sums == 0;
+    const bool defer = fuse_check0 && defer_enabled && blocked_residency_ok();   // the stop rule of this iteration rides in the NEXT combine launch
+    double *hs = defer ? hstat_of(t) : hstat.p;
     CombineDst<T> pd;
     std::memset(&pd, 0, sizeof pd);
     pd.n = G;
@@ -363,17 +374,19 @@ template <typename T> void Solver<T>::multmse_w_rows_fused_peer(const nmfx_opts 
     {
         const unsigned nb1 = w_direct ? 0u : (unsigned)(P / 256 * K), nb2 = (unsigned)((K * K + 63) / 64), nb3 = o.update_H ? (unsigned)((2 * K + 3) / 4) : 0u;
         timed("combine_W", 0.0, ((double)P * K * (w_nslab + 1) + (double)K * K * (w_pieces + 1)) * sizeof(T), [&] {
-            hipLaunchKernelGGL(w_side_combine_kernel<T>, dim3(nb1 + nb2 + nb3), dim3(256), 0, stream, numW_p, slabs.p + slab_w_off, P, K, Pc, w_nslab,
+            const unsigned nbd = defer_pending ? STAT_BLOCKS : 0u;
+            hipLaunchKernelGGL(w_side_combine_kernel<T>, dim3(nb1 + nb2 + nb3 + nbd), dim3(256), 0, stream, numW_p, slabs.p + slab_w_off, P, K, Pc, w_nslab,
                                w_stride, gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, w_pieces, (int64_t)K * K, stat_part.p, h_stat_chunks,
-                               (int)(2 * K), hstat.p, nb1, nb2, done, pd);
+                               (int)(2 * K), hs, nb1, nb2, done, pd, defer_args(nbd));
             HIP_TRY(hipGetLastError());
+            defer_pending = false;
         });
     }
     timed("comm_p2p_flag_wait_numW", 0.0, (double)(P * K + K * K) * sizeof(T), [&] { pc->group_end(); });
     {
         const unsigned nb1 = (unsigned)std::min<int64_t>((Pc * K + 1023) / 1024, 2048), nb2 = (unsigned)std::min<int64_t>((K * K + 255) / 256, 256), nb3 = o.update_H ? 2u : 0u;
         timed("sum_numW_slots", 0.0, (double)G * (Pc * K + K * K) * sizeof(T), [&] {
-            hipLaunchKernelGGL(peer_sum3_kernel<T>, dim3(nb1 + nb2 + nb3), dim3(256), 0, stream, rs_out.p, s_num, (size_t)Pc * K, gramH_p, s_gram, (size_t)K * K, hstat.p,
+            hipLaunchKernelGGL(peer_sum3_kernel<T>, dim3(nb1 + nb2 + nb3), dim3(256), 0, stream, rs_out.p, s_num, (size_t)Pc * K, gramH_p, s_gram, (size_t)K * K, hs,
                                s_hs, o.update_H ? (size_t)2 * K : (size_t)0, pc->slot_bytes, G, nb1, nb2, done);
             HIP_TRY(hipGetLastError());
         });
@@ -441,11 +454,14 @@ template <typename T> void Solver<T>::multmse_w_rows_fused_peer(const nmfx_opts 
         timed("pull_W_rows+stats_check", 0.0, ((double)(G - 1) * 2.0 * Pc * K + (double)G * K * K) * sizeof(T), [&] {
             const unsigned nbc = (unsigned)std::max<size_t>(1, std::min<size_t>((blk_chunk / 16 + 1023) / 1024, 128));   // blocks per peer chunk
             const unsigned nbg = o.update_H ? (unsigned)std::min<int64_t>(((int64_t)K * K * sizeof(T) / 16 + 255) / 256, 256) : 0u;
-            hipLaunchKernelGGL(peer_pull_kernel<T>, dim3((unsigned)G * nbc + nbg + STAT_BLOCKS), dim3(256), 0, stream, ps, rank, G, Wblk[wb ^ 1].p, blk_chunk, nbc, gramW_p,
-                               (size_t)K * K, nbg, (size_t)Pc * K * sizeof(T), cpp, (int)K, wstat.p, ctrl, o.update_H ? hstat.p : (const double *)nullptr, (int)k,
-                               (T)o.tol, t, fuse_check ? 1 : 0, fuse_check ? (const int *)nullptr : done, done, stat_ticket());
+            // (deferred stop rule: no statistics blocks here -- the next combine launch, or defer_flush, runs the rule on the tails this launch
+            // copies into the blocked buffer; the copy blocks then keep their `done` guard)
+            hipLaunchKernelGGL(peer_pull_kernel<T>, dim3((unsigned)G * nbc + nbg + (defer ? 0u : STAT_BLOCKS)), dim3(256), 0, stream, ps, rank, G, Wblk[wb ^ 1].p, blk_chunk, nbc, gramW_p,
+                               (size_t)K * K, nbg, (size_t)Pc * K * sizeof(T), cpp, (int)K, wstat.p, ctrl, o.update_H ? hs : (const double *)nullptr, (int)k,
+                               (T)o.tol, t, fuse_check ? 1 : 0, (fuse_check && !defer) ? (const int *)nullptr : done, done, stat_ticket());
             HIP_TRY(hipGetLastError());
         });
+        if (defer) { defer_pending = true; defer_t = t; defer_opts = o; }
         check_fused = fuse_check;
         wb ^= 1;
         w_res_blocked = true;
@@ -493,7 +509,7 @@ template <typename T> void Solver<T>::multmse_w_rows_fused_peer(const nmfx_opts 
                                (const unsigned char *)nullptr, (size_t)0, (double *)nullptr, (const unsigned char *)nullptr, (size_t)0, pc->slot_bytes, G,
                                (unsigned)std::min<int64_t>((K * K + 255) / 256, 256), 0u, done);
         hipLaunchKernelGGL(stats_check_kernel<T>, dim3(1), dim3(256), 0, stream, stat_part.p, nranks * cpp, (int)K, wstat.p, ctrl,
-                           o.update_H ? hstat.p : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done);
+                           o.update_H ? hs : (const double *)nullptr, (int)k, (T)o.tol, t, fuse_check ? 1 : 0, done);
         HIP_TRY(hipGetLastError());
     });
     check_fused = fuse_check;
@@ -638,6 +654,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     if (o.h_solve < NMFX_HSOLVE_AUTO || o.h_solve > NMFX_HSOLVE_POTRS) throw StatusError{NMFX_ERR_BAD_ARG, "Invalid value for h_solve."};
     precision = o.precision;
     pipe_pending = false;
+    defer_pending = false;
     check_fused = false;
     gramw_sharded_valid = false;
     w_res_blocked = w_std_stale = false;
@@ -696,6 +713,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         // it.  Anything that needs the complete W (objective tracking, the host's poll) flushes the pipeline first.
         const bool poll = (t == next_poll) || t == o.maxiter;
         if (pipe_pending && (track || poll)) pipe_flush(o);
+        if (defer_pending && (track || poll)) defer_flush();   // the deferred stop rule of this iteration, before the host looks at the flag
         // common.jl:79 -- enqueued BEFORE the stop check: the check raises the `done` flag that turns every later kernel
         // into a no-op, and the objective of the converging iteration itself must still be evaluated
         if (track) { w_sync(done_flag()); enqueue_objective(alg, o, trace_dev.p + t, done_flag()); }

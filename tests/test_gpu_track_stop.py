@@ -162,3 +162,30 @@ def test_exact_stop_sums_niters_without_a_margin(built):
             ctx.set_X(X)
             res, _ = ctx.solve(0, nmfx.make_opts(T, maxiter=400, tol=tol, exact_stop=True), Wg, Hg)
         assert abs(res.niters - ro.niters) <= 1 and bool(res.converged) == ro.converged
+
+
+@pytest.mark.parametrize("alg,shape", [("multmse", (300, 260, 6)), ("multmse", (512, 512, 64)), ("multdiv", (300, 260, 6)), ("projals", (300, 260, 6)),
+                                       ("alspgrad", (200, 180, 5)), ("cd", (300, 260, 6)), ("greedycd", (300, 260, 6))])
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+def test_exact_stop_sums_see_the_previous_iterate_for_every_algorithm(built, alg, shape, T):
+    """stop_sums = 1 evaluates stop_condition (src/common.jl:92-111) on the factors of iteration t against those of t - 1, which it takes
+    from the ping-pong partners of the live buffers.  That holds by construction for MultUpdate; here it is CHECKED for every algorithm
+    (ProjectedALS, CoordinateDescent, GreedyCD, ALSPGrad's explicit preW / preH copies) and for the small-k path of MultUpdate-MSE
+    (512 x 512, k = 64): the relchange column of iteration 3 must be, bit for bit, what the sequential T-precision sums give on the
+    factors the DEVICE returned after 3 and after 2 iterations (runs are bit-reproducible) -- no oracle trajectory involved."""
+    p, n, k = shape
+    X, W0, H0 = planted(p, n, k, T, seed=31, normalize=(alg != "projals"))
+    algid = {"multmse": 0, "multdiv": 1, "projals": 2, "alspgrad": 3, "cd": 4, "greedycd": 5}[alg]
+    lam = 0.05 if alg == "projals" else (float(np.sqrt(np.finfo(T).eps)) if alg == "multdiv" else 0.0)
+    got = {}
+    with nmfx.Context(T, p, n, k) as ctx:
+        ctx.set_X(X)
+        for iters in (2, 3):
+            Wg, Hg = W0.copy(order="F"), H0.copy(order="F")
+            res, _ = ctx.solve(algid, nmfx.make_opts(T, maxiter=iters, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True, exact_stop=True), Wg, Hg)
+            assert res.niters == iters
+            _, rc = ctx.iter_trace(iters + 1)
+            got[iters] = (Wg, Hg, rc)
+    _, devmax = orc.stop_condition_dev(got[3][0], got[2][0], got[3][1], got[2][1], 1e-30)
+    assert T(got[3][2][3]) == T(devmax), (alg, got[3][2][3], devmax)
+    assert T(got[3][2][2]) == T(got[2][2][2])          # ... and the run is reproducible: iteration 2's value is the same in both runs

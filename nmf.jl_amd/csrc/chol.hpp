@@ -198,6 +198,380 @@ __global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// potrf! with the trailing matrix RESIDENT IN REGISTERS (round 6).  potrf_upper_kernel above keeps A in global memory: every block step
+// re-reads its diagonal block and row panel from L2 and sends the trailing update through a global read-modify-write -- 20 us per step
+// at k = 256, of which the one-wave factorisation of the 32 x 32 diagonal block is 7-11 us and the one-column-per-thread panel solve
+// 5 us (profiles/r04_potrf_bench_standalone.log).  Here one workgroup of 8 waves owns the whole upper triangle as 32 x 32 blocks in MFMA
+// accumulator layout (block t = bj (bj + 1) / 2 + bi lives in slot t / 8 of wave t % 8: 36 blocks = 5 slots x 16 registers at k = 256
+// in Float32), global memory is read once and written once, and a block step is
+//   A  the owners of block row b write their blocks to LDS as column images (E[block][column][row]);
+//   B  ELIMINATION: wave w < NBLK - 1 - b takes the diagonal block in lanes 0-31 and panel block (b, b + 1 + w) in lanes 32-63, lane =
+//      column, the 32 rows of the column in registers, and runs the 32 right-looking steps  u_j = a_j / sqrt(a_jj),  a_r -= u_jr u_j  on
+//      all 64 lanes at once: the multipliers u_jr are v_readlane broadcasts from the diagonal lanes.  Every wave repeats the factorisation
+//      of the diagonal block (same instructions, same bits) and gets the triangular solve of ITS 32 panel columns out of the very same
+//      instruction stream -- the panel solve costs nothing beyond the diagonal block's dependency chain, instead of following it.
+//      The scaling multiplies by 1 / sqrt(a_jj) (one correctly rounded division per step, as OpenBLAS' potf2 / trsm kernels do) and the
+//      updates are fused multiply-adds.  The solved panel goes to LDS in the MFMA operand image Rp[l][column] and to global memory.
+//      An idle wave inverts the PREVIOUS diagonal block meanwhile (Dinv != nullptr: what trtri_diag_kernel computes, one launch less).
+//   C  trailing update: every wave subtracts R'R from the blocks it owns, 16 v_mfma_f32_32x32x2 per block, operands from Rp.
+// Two workgroup barriers per block step, no global round trip inside the loop.  adddiag! (src/utils.jl:15-24) is fused into the load.
+// 512 threads: the workgroup fits the half of a CU that ProjectedALS' short-grid products leave free (projals_impl.hpp).
+// NBLK = K / 32 at compile time (the accumulator slots are indexed statically): Float32 up to 8 (k <= 256), Float64 up to 4.
+// ---------------------------------------------------------------------------------------------
+template <typename F, int... I> __device__ __forceinline__ void strip_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void strip_static_for(F &&f) { strip_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{}); }
+// empty asm statements that pin values to a place in the instruction stream (as functions: an asm operand inside a generic lambda cannot
+// name a variable of the enclosing function)
+template <typename A> __device__ __forceinline__ void pin_v(A &a) { asm volatile("" : "+v"(a)); }
+template <typename A, typename B> __device__ __forceinline__ void pin_v(A &a, B &b) { asm volatile("" : "+v"(a), "+v"(b)); }
+template <typename A, typename B, typename C> __device__ __forceinline__ void pin_v(A &a, B &b, C &c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+template <int FROM, int N, typename T> __device__ __forceinline__ void pin_from(T (&c)[N]) {
+    if constexpr (FROM < N) {
+        asm volatile("" : "+v"(c[FROM]));
+        pin_from<FROM + 1>(c);
+    }
+}
+__device__ __forceinline__ float nmfx_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double nmfx_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// s = sqrt(d), r = 1 / s for a pivot.  Float32: the hardware's 1-ulp estimates (v_sqrt_f32, v_rcp_f32) and one Newton step each with
+// the residuals formed exactly by fused multiply-adds -- a chain of 6 dependent instructions instead of the 28 of the correctly rounded
+// sqrtf + division sequences, which were a third of the elimination's 32 dependent steps.  Exact where the arithmetic is (a perfect
+// square gives residual 0 or a correction that rounds onto the root), within an ulp of the correctly rounded values otherwise (near
+// ties only); pivots in the Float32 denormal range come out non-finite and are reported as not positive definite.
+__device__ __forceinline__ void pivot_sqrt_rcp(float d, float &s, float &r) {
+    const float s0 = __builtin_amdgcn_sqrtf(d);
+    const float r0 = __builtin_amdgcn_rcpf(s0);
+    const float e = __builtin_fmaf(-s0, s0, d);
+    s = __builtin_fmaf(e, 0.5f * r0, s0);
+    const float e2 = __builtin_fmaf(-s, r0, 1.0f);
+    r = __builtin_fmaf(r0, e2, r0);
+}
+__device__ __forceinline__ void pivot_sqrt_rcp(double d, double &s, double &r) {
+    s = sqrt(d);
+    r = 1.0 / s;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also releases global memory, i.e. waits for every outstanding global
+// store of the wave (s_waitcnt vmcnt(0): a 1-2 us round trip); the factorisation's stores of finished parts of U are never read back
+// inside the kernel, so its barriers must not wait for them.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <typename T, int NBLK> struct PotrfReg {
+    static constexpr int NW = 8, NB = 32, NT = NBLK * (NBLK + 1) / 2, NS = (NT + NW - 1) / NW;
+    static constexpr int LDE = NB + 16 / (int)sizeof(T);            // column stride of a column image (16-byte aligned rows of 32 + pad)
+    static constexpr int KP = (NBLK > 1 ? NBLK - 1 : 1) * NB + 1;   // row stride of the panel image (odd: read along a column without bank conflicts too)
+    static constexpr size_t lds_bytes() { return ((size_t)(NBLK + 1) * NB * LDE + (size_t)NB * KP + NBLK * NB) * sizeof(T) + 16; }
+};
+
+// Upper triangle (diagonal included) of a 32 x 32 block from its LDS column image Ub[c * LDE + r] to global memory G[r + c * ld], columns
+// c < ncols only.  Store INSTRUCTIONS are what costs here (one wave, ~130 cycles each whatever their width): 16-byte stores with
+// 32 / V lanes per column cover every V-row group that lies wholly above the diagonal (32 / (2 V) instructions), one or two scalar store
+// instructions the V x V triangles on the diagonal -- 6 instructions in Float32 instead of one per pair of columns (16).
+template <typename T, int LDE> __device__ __forceinline__ void store_upper32(T *G, int64_t ld, const T *Ub, int ncols, int lane) {
+    constexpr int V = 16 / (int)sizeof(T), LPC = 32 / V, CPI = 64 / LPC, NI = 32 / CPI;
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const int q = lane % LPC, cc = lane / LPC;
+    vec_t v[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) v[it] = *reinterpret_cast<const vec_t *>(Ub + (CPI * it + cc) * LDE + V * q);
+    constexpr int TRI = V * (V + 1) / 2, NP = (32 / V * TRI + 63) / 64;
+    T d[NP];
+    int dr[NP], dc[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+        const int idx = lane + 64 * ps, sb = idx / TRI, e = idx % TRI;      // element e of the triangle of diagonal sub-block sb
+        const int c = (e >= 1) + (e >= 3) + (e >= 6);      // (V <= 4: e < 10)
+        dr[ps] = (sb < 32 / V) ? V * sb + e - c * (c + 1) / 2 : 32;
+        dc[ps] = V * sb + c;
+        d[ps] = (sb < 32 / V) ? Ub[dc[ps] * LDE + dr[ps]] : (T)0;
+    }
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int c = CPI * it + cc;
+        if (V * q + V - 1 < V * (c / V) && c < ncols) *reinterpret_cast<vec_t *>(G + V * q + (int64_t)c * ld) = v[it];      // the whole group above sub-block c / V
+    }
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps)
+        if (dr[ps] < 32 && dc[ps] < ncols) G[dr[ps] + (int64_t)dc[ps] * ld] = d[ps];
+}
+
+#ifdef NMFX_POTRF_TIMING
+extern __device__ long long nmfx_potrf_dbg[];
+#endif
+template <typename T, int NBLK>
+__global__ __launch_bounds__(512) void potrf_reg_kernel(T *A, int64_t ld, int k, T lambda, T *Dinv, Ctrl *ctrl, int posdef_status) {
+    if (ctrl != nullptr && ctrl->done) return;
+    __builtin_amdgcn_s_setprio(3);       // co-resident with a block of the big product: see potrf_upper_kernel
+    using M = Mfma<T>;
+    using P = PotrfReg<T, NBLK>;
+    using vec_t = typename M::vec_t;
+    constexpr int NW = P::NW, NB = P::NB, NT = P::NT, NS = P::NS, LDE = P::LDE, KP = P::KP;
+    constexpr int MT = M::MT, KS = M::KS, SUB = NB / MT, V = M::VEC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
+    // NBLK + 1 column images of 32 x 32 blocks: step b reads block row b from slots 0 .. NBLK - 1 - b (slot bj - b: E[c * LDE + r] =
+    // A(32 b + r, 32 bj + c)); the factored diagonal block b' is kept in slot NBLK - b' (never a slot a later step's block row uses) for
+    // the copy to global memory and for its inverse, which overwrites it there
+    T *E = reinterpret_cast<T *>(chol_smem);
+    T *Rp = E + (size_t)(NBLK + 1) * NB * LDE;        // Rp[l * KP + c] = U(32 b + l, 32 (b + 1) + c)
+    T *rinvs = Rp + (size_t)NB * KP;                  // rinvs[b * NB + j] = 1 / U(32 b + j, 32 b + j)
+    int *failp = reinterpret_cast<int *>(rinvs + NBLK * NB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane % MT, ks = lane / MT;
+    auto acc_row = [&](int reg) { return (sizeof(T) == 4) ? ((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) : ((lane >> 4) + 4 * reg); };
+    if (tid == 0) *failp = 0;
+    // the blocks of this wave
+    int sbi[NS], sbj[NS];
+    typename M::acc_t acc[NS][SUB][SUB];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int t = s * NW + wave;
+        int bj = 0;
+        while ((bj + 1) * (bj + 2) / 2 <= t) ++bj;
+        sbj[s] = (t < NT) ? bj : -1;
+        sbi[s] = (t < NT) ? t - bj * (bj + 1) / 2 : -1;
+        // (every load of the wave in flight before the first use)
+#pragma unroll
+        for (int si = 0; si < SUB; ++si)
+#pragma unroll
+            for (int sj = 0; sj < SUB; ++sj)
+#pragma unroll
+                for (int reg = 0; reg < M::NACC; ++reg) {
+                    const int gr = NB * sbi[s] + si * MT + li, gc = NB * sbj[s] + sj * MT + acc_row(reg);
+                    const bool in = t < NT && gr < k && gc < k;         // (clamped, unconditional loads: conditional ones are waited for one by one)
+                    T v = A[in ? gr + (int64_t)gc * ld : 0];
+                    v = in ? v : (T)0;
+                    if (gr == gc) v = (gr < k) ? v + lambda : (T)1;      // adddiag!; identity padding beyond k
+                    acc[s][si][sj][reg] = v;
+                }
+    }
+    lds_barrier();
+#ifdef NMFX_POTRF_TIMING
+#define PTR(i) if (lane == 0) nmfx_potrf_dbg[256 + (b * 8 + wave) * 8 + (i)] = (long long)__builtin_readcyclecounter();
+#else
+#define PTR(i)
+#endif
+    T myrinv = (T)0;
+    int next_inv = 0;      // next diagonal block to invert (same count in every wave)
+    for (int b = 0; b < NBLK || (Dinv != nullptr && next_inv < NBLK); ++b) {      // (iterations >= NBLK: only the last inverses)
+        const int nrem = NBLK - 1 - b;
+        PTR(0)
+        // A: block row b as column images
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (sbi[s] == b) {
+                T *Eb = E + (size_t)(sbj[s] - b) * NB * LDE;
+#pragma unroll
+                for (int si = 0; si < SUB; ++si)
+#pragma unroll
+                    for (int sj = 0; sj < SUB; ++sj)
+#pragma unroll
+                        for (int reg = 0; reg < M::NACC; ++reg) Eb[(sj * MT + acc_row(reg)) * LDE + si * MT + li] = acc[s][si][sj][reg];
+            }
+        PTR(1)
+        lds_barrier();
+        PTR(2)
+        // B: elimination of [diagonal block | panel block wave]
+        // The inverses of the finished diagonal blocks (Dinv != nullptr) are dealt to waves 0 .. 3 on the SIMDs that have NO elimination wave
+        // in this step (wave w runs on SIMD w % 4): two of these instruction-bound chains on one SIMD take 1.5x as long as one (measured:
+        // 15 k cycles against 10.5 k), and the elimination is the critical path of the step.  At k = 256 that is from step 4 on:
+        // inv(0) | inv(1), inv(2) | inv(3), inv(4), inv(5) | inv(6) | inv(7).
+        const int nel = (b < NBLK) ? (nrem > 0 ? nrem : 1) : 0;
+        int my_inv = -1;
+        if (Dinv != nullptr)
+            for (int w = nel; w < 4; ++w)
+                if (next_inv < b && next_inv < NBLK) {
+                    if (wave == w) my_inv = next_inv;
+                    ++next_inv;
+                }
+        if (wave < nel) {
+            const T *src = (lane < NB || nrem == 0) ? E + (size_t)(lane & 31) * LDE : E + (size_t)(1 + wave) * NB * LDE + (size_t)(lane - NB) * LDE;
+            T col[NB];
+#pragma unroll
+            for (int q = 0; q < NB / V; ++q) {
+                const vec_t v = *reinterpret_cast<const vec_t *>(src + q * V);
+#pragma unroll
+                for (int u = 0; u < V; ++u) col[q * V + u] = v[u];
+            }
+            bool bad = false;
+            // Software-pipelined over the steps: the pivot of step j + 1 (broadcast, square root, reciprocal: a chain of ten dependent
+            // instructions with two transcendental latencies) is started as soon as column j + 1 has its update from step j, and runs
+            // under the 30 - j independent updates of the other columns.
+            T dj, rj;
+            {
+                const T d0 = lane_bcast(col[0], 0);
+                bad = !(d0 > (T)0);
+                pivot_sqrt_rcp(d0, dj, rj);
+            }
+            strip_static_for<NB>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                int lj = lane;
+                pin_v(lj);     // (keeps the 32 masks lane == j out of the scalar registers: hoisted out of the block loop they spill)
+                const bool diag = lj == j;
+                if (diag) myrinv = rj;
+                col[j] = diag ? dj : col[j] * rj;
+                if constexpr (j + 1 < NB) {
+                    col[j + 1] = nmfx_fma(-lane_bcast(col[j], j + 1), col[j], col[j + 1]);
+                    const T d = lane_bcast(col[j + 1], j + 1);
+                    bad = bad || !(d > (T)0);
+                    pivot_sqrt_rcp(d, dj, rj);
+                }
+                // (the broadcasts eight at a time into scalar registers BEFORE the updates that use them: a scalar written by v_readlane is
+                // not available to the next vector instruction for several cycles, and broadcast / update pairs issued back to back ran at
+                // ~16 cycles per pair)
+                strip_static_for<(NB - j - 2 > 0 ? (NB - j - 2 + 7) / 8 : 0)>([&](auto gc_) {
+                    constexpr int r0 = j + 2 + 8 * decltype(gc_)::value;
+                    T m[8];
+                    strip_static_for<8>([&](auto uc) {
+                        constexpr int u = decltype(uc)::value;
+                        if constexpr (r0 + u < NB) m[u] = lane_bcast(col[j], r0 + u); else m[u] = (T)0;
+                    });
+                    asm volatile("" : "+s"(m[0]), "+s"(m[1]), "+s"(m[2]), "+s"(m[3]), "+s"(m[4]), "+s"(m[5]), "+s"(m[6]), "+s"(m[7]));
+                    strip_static_for<8>([&](auto uc) {
+                        constexpr int u = decltype(uc)::value;
+                        if constexpr (r0 + u < NB) col[r0 + u] = nmfx_fma(-m[u], col[j], col[r0 + u]);
+                    });
+                });
+                // RIGHT-looking as written: the updates of a step are independent of each other.  Left alone, instruction selection sinks
+                // every update to its use (left-looking: column r takes its r updates as one dependent chain right before its own pivot,
+                // with the multipliers of all earlier steps parked in -- and spilled from -- scalar registers); the empty asm statements
+                // pin each updated value, and the next pivot, to their step
+                pin_from<j + 2>(col);
+                pin_v(dj, rj);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (nrem > 0 && lane >= NB) {
+                const int c = NB * wave + lane - NB;                      // column of the panel
+#pragma unroll
+                for (int l = 0; l < NB; ++l) Rp[l * KP + c] = col[l];
+            }
+            if (wave == 0 && lane < NB) {
+                // the factored diagonal block: to LDS as a column image -- copied to global memory in phase C, inverted in a later step
+                T *Ub = E + (size_t)(NBLK - b) * NB * LDE;
+#pragma unroll
+                for (int q = 0; q < NB / V; ++q) {
+                    vec_t v;
+#pragma unroll
+                    for (int u = 0; u < V; ++u) v[u] = col[q * V + u];
+                    *reinterpret_cast<vec_t *>(Ub + lane * LDE + q * V) = v;
+                }
+                rinvs[b * NB + lane] = myrinv;
+                if (bad && lane == 0) *failp = 1;
+            }
+        } else if (my_inv >= 0) {
+            // inverse of a finished diagonal block: column `lane` of inv(U_bb) by back-substitution on e_lane (trtri_diag_kernel), the
+            // divisions by the diagonal as multiplications by the reciprocals the factorisation formed (as LAPACK's trti2 does)
+            const int pb = my_inv;
+            T *Ub = E + (size_t)(NBLK - pb) * NB * LDE;
+            const T *src = Ub + (size_t)(lane & 31) * LDE;
+            T col[NB], v[NB];
+#pragma unroll
+            for (int q = 0; q < NB / V; ++q) {
+                const vec_t x = *reinterpret_cast<const vec_t *>(src + q * V);
+#pragma unroll
+                for (int u = 0; u < V; ++u) col[q * V + u] = x[u];
+            }
+            const T ri = rinvs[pb * NB + (lane & 31)];
+            strip_static_for<NB>([&](auto ic) {
+                constexpr int i = NB - 1 - decltype(ic)::value;
+                // (every U(i, l) is known up front: left alone, the compiler broadcasts all 496 of them ahead of the recurrence and spills the
+                // scalars; tying row i to the result of row i + 1 keeps each broadcast next to its use -- and the 32 masks out of the scalars)
+                int lj = lane & 31;
+                T ci = col[i];
+                if constexpr (i < NB - 1) pin_v(lj, ci, v[i + 1 < NB ? i + 1 : i]);
+                else pin_v(lj, ci);
+                T s = (lj == i) ? (T)1 : (T)0;
+                strip_static_for<(NB - i - 1 + 7) / 8>([&](auto gc_) {      // (broadcasts eight at a time ahead of their uses, as in the elimination)
+                    constexpr int l0 = i + 1 + 8 * decltype(gc_)::value;
+                    T m[8];
+                    strip_static_for<8>([&](auto uc) {
+                        constexpr int u = decltype(uc)::value;
+                        if constexpr (l0 + u < NB) m[u] = lane_bcast(ci, l0 + u); else m[u] = (T)0;
+                    });
+                    asm volatile("" : "+s"(m[0]), "+s"(m[1]), "+s"(m[2]), "+s"(m[3]), "+s"(m[4]), "+s"(m[5]), "+s"(m[6]), "+s"(m[7]));
+                    strip_static_for<8>([&](auto uc) {
+                        constexpr int u = decltype(uc)::value;
+                        if constexpr (l0 + u < NB) s = nmfx_fma(-m[u], v[l0 + u], s);
+                    });
+                });
+                v[i] = s * lane_bcast(ri, i);
+            });
+            // out through the block's own LDS image (this wave is its last reader), then with a run-time triangle test (32 compile-time
+            // masks r <= lane end up hoisted out of the block loop and spilled); the 16 LDS reads first, then the 16 stores
+            if (lane < NB) {
+#pragma unroll
+                for (int q = 0; q < NB / V; ++q) {
+                    vec_t x;
+#pragma unroll
+                    for (int u = 0; u < V; ++u) x[u] = v[q * V + u];
+                    *reinterpret_cast<vec_t *>(Ub + lane * LDE + q * V) = x;
+                }
+            }
+            store_upper32<T, LDE>(Dinv + (int64_t)NB * pb + (int64_t)NB * pb * ld, ld, Ub, k - NB * pb, lane);
+        }
+        PTR(3)
+        lds_barrier();
+        PTR(4)
+        if (*failp) break;
+        if (wave == NW - 1 && b < NBLK) {      // the factored diagonal block to global memory (upper triangle), off the elimination waves
+            store_upper32<T, LDE>(A + (int64_t)NB * b + (int64_t)NB * b * ld, ld, E + (size_t)(NBLK - b) * NB * LDE, k - NB * b, lane);
+            PTR(6)
+        }
+        // ... and the solved row panel, from its LDS image, 16 bytes per lane with 32 / V lanes per column: an instruction writes 2 V whole
+        // columns of the block row.  (Stored from the elimination's registers -- lane = column -- every instruction touched 32 lines, and
+        // the CU's store path took 5-6 k cycles per step to drain them; as 4-byte stores there were 4x as many instructions.)
+        if (b < NBLK) {
+            constexpr int LPC = NB / V, CPI = 64 / LPC, NIT = (NB * (NBLK - 1) / CPI + NW - 1) / NW;
+            const int q = lane % LPC, cc = lane / LPC;
+            vec_t pv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = CPI * (wave + NW * it) + cc;
+#pragma unroll
+                for (int u = 0; u < V; ++u) pv[it][u] = (c < NB * nrem) ? Rp[(V * q + u) * KP + c] : (T)0;
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = CPI * (wave + NW * it) + cc, gc = NB * (b + 1) + c;
+                if (c < NB * nrem && gc < k) *reinterpret_cast<vec_t *>(A + (NB * b + V * q) + (int64_t)gc * ld) = pv[it];
+            }
+        }
+        // C: trailing update of the blocks below block row b
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (sbi[s] > b && b < NBLK) {
+                const T *pa = Rp + (size_t)NB * (sbj[s] - b - 1) + li, *pb_ = Rp + (size_t)NB * (sbi[s] - b - 1) + li;
+#pragma unroll
+                for (int kk = 0; kk < NB / KS; ++kk) {
+                    T af[SUB], bf[SUB];
+#pragma unroll
+                    for (int q = 0; q < SUB; ++q) {
+                        af[q] = -pa[(kk * KS + ks) * KP + q * MT];      // D rows (registers) <-> matrix column
+                        bf[q] = pb_[(kk * KS + ks) * KP + q * MT];      // D columns (lanes)  <-> matrix row
+                    }
+#pragma unroll
+                    for (int si = 0; si < SUB; ++si)
+#pragma unroll
+                        for (int sj = 0; sj < SUB; ++sj) acc[s][si][sj] = M::mma(af[sj], bf[si], acc[s][si][sj]);
+                }
+            }
+        PTR(5)
+    }
+    if (*failp) {
+        if (tid == 0 && ctrl != nullptr) {
+            ctrl->status = posdef_status;
+            ctrl->done = 1;
+        }
+        return;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Triangular inverse Uinv = inv(U) (what potri!'s first half, trtri, computes), blocked by 32:
 //   Uinv[b,b] = inv(U[b,b])                                              -- trtri_diag_kernel
 //   Uinv[a,b] = -Uinv[a,a] * sum_{c=a+1..b} U[a,c] * Uinv[c,b],  a < b    -- trtri_offdiag_kernel
@@ -557,10 +931,6 @@ __global__ __launch_bounds__(POTRS_THREADS) void potrs_panel_kernel(const T *Tm,
 // NBLK = K / 32 at compile time (every loop is unrolled: the strip's registers are indexed statically): 2, 4, 6, 8, and in Float32 -- where
 // the strip of K = 512 is 128 registers of a one-wave-per-SIMD budget of 512 -- also 10, 12, 14, 16.
 // ---------------------------------------------------------------------------------------------
-template <typename F, int... I> __device__ __forceinline__ void strip_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F> __device__ __forceinline__ void strip_static_for(F &&f) { strip_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{}); }
 template <typename T> __host__ __device__ inline int strip_rho(int kk, int g) {
     return sizeof(T) == 4 ? 16 * (kk >> 2) + 4 * g + (kk & 3) : 16 * (kk >> 2) + g + 4 * (kk & 3);
 }

@@ -23,7 +23,29 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
     const size_t lds_tri = (size_t)(std::min(nblk_t, nfit) + 4) * 1024 * sizeof(T);
     const bool gpanel = lds32 > 160 * 1024;   // the row panel no longer fits one workgroup's LDS: keep it in a global scratch buffer
     if (gpanel) potrf_panel.ensure(lds32 / sizeof(T));
+    // register-resident factorisation (chol.hpp: potrf_reg_kernel): adddiag! and the diagonal blocks' inverses in the same launch
+    // (Float64 keeps the LDS-panel kernel when the factorisation shares its CU with a block of the product -- potrf_nt == 512: its
+    // register-resident form needs 256 registers per lane and would not be placed beside that block)
+    const bool reg = potrf_reg_ok() && !(sizeof(T) == 8 && potrf_nt == 512);
     timed(tag_potrf, (double)k * k * k / 3.0, 0.0, [&] {
+        if (reg) {
+            HIP_TRY(hipMemsetAsync(Uinv, 0, kk * sizeof(T), stream));
+            auto go = [&](auto nblk) {
+                constexpr int NBLK = decltype(nblk)::value;
+                const size_t lds = PotrfReg<T, NBLK>::lds_bytes();
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_reg_kernel<T, NBLK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((potrf_reg_kernel<T, NBLK>), dim3(1), dim3(512), lds, stream, A, K, (int)k, lambda, Uinv, ctrl, (int)NMFX_ERR_NOT_POSDEF);
+            };
+            const int nblk = (int)(K / 32);
+            if (nblk == 2) go(std::integral_constant<int, 2>{});
+            else if (nblk == 4) go(std::integral_constant<int, 4>{});
+            else if constexpr (sizeof(T) == 4) {
+                if (nblk == 6) go(std::integral_constant<int, 6>{});
+                else go(std::integral_constant<int, 8>{});
+            }
+            HIP_TRY(hipGetLastError());
+            return;
+        }
         if (lambda != (T)0)   // adddiag! skips lambda == 0 (src/utils.jl:18)
             hipLaunchKernelGGL(adddiag_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, stream, A, K, (int)k, lambda, done);
         if (gpanel) {
@@ -38,11 +60,13 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
         HIP_TRY(hipGetLastError());
     });
     timed(tag_trtri, (double)k * k * k / 3.0, 0.0, [&] {
-        HIP_TRY(hipMemsetAsync(Uinv, 0, kk * sizeof(T), stream));
+        const unsigned nblk = (unsigned)((k + 31) / 32);
+        if (!reg) {
+            HIP_TRY(hipMemsetAsync(Uinv, 0, kk * sizeof(T), stream));
+            hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3(nblk), dim3(64), 0, stream, A, Uinv, K, (int)k, done);
+        }
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&trtri_offdiag_kernel<T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tri));
-        const unsigned nblk = (unsigned)((k + 31) / 32);
-        hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3(nblk), dim3(64), 0, stream, A, Uinv, K, (int)k, done);
         if (Tm != nullptr && strip_ok())   // ... packed block by block in the order potrs_strip_kernel's sweeps consume them
             hipLaunchKernelGGL((potrs_strip_pack_kernel<T>), dim3((unsigned)std::min<int64_t>((strip_pack_elems((int)(K / 32)) + 255) / 256, 1024)), dim3(256), 0, stream, A, Uinv, Tm, K,
                                (int)k, (int)(K / 32), done);
@@ -177,7 +201,11 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // CU).  Sharing its CU with a GEMM block the chain runs 4x slower (potrf 650 us, trtri 400 us), which still fits under the
     // 1.02 ms product: 2.75 -> 2.36 ms per iteration at 16384 x 16384, k = 256.  Replicated-W multi-GPU mode keeps the serial
     // order (its Gram travels inside the one packed all-reduce that follows the product).
-    const bool under = chol_slots > 0 && !use_bf16x3() && K % 128 == 0 && (!sharded() || rs);
+    // (round 6: only under a product long enough to cover the chain.  Sharing its CU the register-resident potrf takes 0.6-0.8 ms at
+    // k = 256 -- ten times its stand-alone 77 us: it is bound by instruction issue, which the product's waves contend for -- so under
+    // a 60 us product (4096 x 4096, k = 256) the chain WAS the iteration: 0.69 ms; in stream order, with the fast factorisation, 0.48)
+    const double prod_us = 2.0 * (double)P * (double)N * (double)K / (sizeof(T) == 4 ? 150e6 : 70e6);
+    const bool under = chol_slots > 0 && !use_bf16x3() && K % 128 == 0 && (!sharded() || rs) && prod_us >= chol_under_min_us;
     if (under) ensure_fstream();
     // H solve by triangular substitution (potrs!, the reference's route) instead of Uinv (Uinv' B): opt-in for the ITERATION
     // (NMFX_POTRS=1) -- a panel's two sweeps are a chain of 2 K / 32 dependent block steps that one workgroup per CU cannot overlap

@@ -146,6 +146,9 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = dev_env("NMFX_K_GRANULE")) k_granule = (std::atoi(e) == 128) ? 128 : 64;
         if (const char *e = dev_env("NMFX_POTRS")) { potrs_enabled = std::atoi(e) != 0; potrs_iter = std::atoi(e) == 1; }
         if (const char *e = dev_env("NMFX_POTRS_STRIP")) strip_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_POTRF_REG")) potrf_reg_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_CHOL_UNROLLED")) chol_unrolled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_CHOL_UNDER_US")) chol_under_min_us = std::atof(e);
         if (const char *e = dev_env("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_W_BLOCKED")) blk_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_P2P_PULL")) peer_pull_enabled = std::atoi(e) != 0;
@@ -596,6 +599,7 @@ template <typename T> class Solver : public SolverBase {
     int64_t Rc = 0, Pcc = 0;              // rows per super-chunk, rows per (super-chunk, rank)
     size_t agc_bytes = 0;
     hipStream_t cstream = nullptr;        // the collectives of the pipelined mode
+    double chol_under_min_us = 700.0;     // ProjectedALS hides its factorisations under a product only if the product is estimated this long (projals_impl.hpp)
     int chol_slots = 8;                   // block slots (half CUs) the big products of ProjectedALS leave to the factorisation stream
     bool short_grid = false;              // set around the products that must leave those slots
     int potrf_nt = 1024;                  // threads of the Cholesky workgroup (512 when it has to fit beside a GEMM block)
@@ -697,7 +701,7 @@ template <typename T> class Solver : public SolverBase {
         // issue slots the product leaves, and the unrolled loop leaves fewer -- potrf 590 -> 915 us co-resident, which put the chain
         // back on the critical path: 2.21 -> 2.30 ms per iteration)
         constexpr int BUFV = (sizeof(T) == 4 && LA == KCONTIG && LB == KCONTIG && BR == 128 && BC == 128 && AUX == 0) ? 2 : 1;
-        if (BUFV == 2 && !short_grid)
+        if (BUFV == 2 && (!short_grid || (chol_unrolled && potrf_reg_ok())))
             hipLaunchKernelGGL((gemm_mfma_kernel<T, LA, LB, BR, BC, WGR, WGC, Epi, AUX, BUFV>), dim3(blocks), dim3(WGR * WGC * 64), 0,
                                stream, g, epi);
         else
@@ -1276,6 +1280,13 @@ template <typename T> class Solver : public SolverBase {
     bool strip_ok() const { return strip_enabled && potrs_enabled && K % 64 == 0 && K <= STRIP_KMAX && N % STRIP_COLS == 0; }
     size_t potrs_pack_elems() const { return std::max((size_t)K * K, strip_ok() ? (size_t)strip_pack_elems((int)(K / 32)) : (size_t)0); }
     bool potrs_route_ok() const { return strip_ok() || potrs_ok(); }
+    // potrf! with the trailing matrix in registers (chol.hpp: potrf_reg_kernel): K / 32 blocks per side at compile time, Float32 up to 8
+    // (k <= 256), Float64 up to 4; beyond that the LDS-panel kernel.  NMFX_POTRF_REG=0 (development switch): the LDS-panel kernel everywhere.
+    bool potrf_reg_enabled = true;
+    bool potrf_reg_ok() const { return potrf_reg_enabled && K % 64 == 0 && K / 32 <= (sizeof(T) == 4 ? 8 : 4); }
+    // the products that share their CUs with the factorisation keep the k-loop unrolled by two when the factorisation is the short
+    // register-resident one (launch_gemm_cfg); NMFX_CHOL_UNROLLED=0: the rolled loop as before (A/B)
+    bool chol_unrolled = true;
     int spd_solve_left_potrs(const T *Tm, const T *B, T *out, bool clamp, const T *old, const int *done);
     void spd_solve_left(const T *Uinv, const T *B, T *Y, T *out, bool clamp, const int *done);
     void spd_solve_right(const T *Uinv, T *invA, const T *A, T *out, int64_t rows, bool clamp, const int *done);

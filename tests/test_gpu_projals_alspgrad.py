@@ -265,6 +265,8 @@ def test_projals_factorisation_under_the_products(built, T, shape, monkeypatch):
     lam = 0.5
     alg = nmfx.ProjectedALS(T, maxiter=4, tol=1e-30, lambda_w=lam, lambda_h=lam)
     runs = {}
+    monkeypatch.setenv("NMFX_DEV", "1")
+    monkeypatch.setenv("NMFX_CHOL_UNDER_US", "0")   # (round 6: by default only products estimated >= 0.7 ms hide the chain; these are 60 us)
     for slots in ("8", "0"):
         monkeypatch.setenv("NMFX_CHOL_SLOTS", slots)
         W, H = W0.copy(order="F"), H0.copy(order="F")

@@ -168,7 +168,7 @@ template <typename T> void Solver<T>::enqueue_cd(const nmfx_opts &o, long long t
         const bool rs = row_sharded();
         const int64_t r0 = rs ? row0 : 0, rows = rs ? std::max<int64_t>(0, std::min<int64_t>(Pc, p - row0)) : p;
         w_blocked = rs;
-        times_ht(X.p, Hp, true, done);
+        times_ht(X.p, Hp, true, done, false, ht_for(Hp, done));
         w_blocked = false;
         if (rs) scatter_w_numerator(false, done);
         else allreduce_w_side(false, done);
@@ -278,7 +278,7 @@ template <typename T> void Solver<T>::enqueue_greedycd(const nmfx_opts &o, long 
         const bool rs = row_sharded();
         const int64_t r0 = rs ? row0 : 0, rows = rs ? std::max<int64_t>(0, std::min<int64_t>(Pc, p - row0)) : p;
         w_blocked = rs;
-        times_ht(X.p, Hp, true, done);
+        times_ht(X.p, Hp, true, done, false, ht_for(Hp, done));
         w_blocked = false;
         if (rs) scatter_w_numerator(false, done);
         else allreduce_w_side(false, done);

@@ -38,7 +38,7 @@ struct StreamArgs {
 // epilogue arithmetic runs in the 64-cycle shadow of its own MFMAs instead of forming MFMA-free runs (with two in-order waves
 // per SIMD sharing the matrix pipe, every cycle in which BOTH are inside such a run is a lost pipe cycle: measured +7 % on the
 // ratio pass with the 12-instruction division issued as one run per element).
-template <typename T> struct SEpiRatio {   // Q = X ./ (acc + delta)
+template <typename T, int FAST = 0> struct SEpiRatio {   // Q = X ./ (acc + delta); FAST: ratio_div_fast's arithmetic (gemm_mfma.hpp), cut into the same three stages
     const T *X;
     T *Q;
     int64_t ld;
@@ -60,7 +60,17 @@ template <typename T> struct SEpiRatio {   // Q = X ./ (acc + delta)
     // Bit-identical to `x / d` (checked element by element against the block-per-tile kernel: scripts/kbench/stream_bench.hip).
     template <int S> __device__ __forceinline__ void stage(const Tile &t, int ro, int co, T v, const Pre &p, St &st) {
         static_assert(sizeof(T) == 4, "f32");
-        if constexpr (S == 0) {
+        if constexpr (FAST != 0) {
+            if constexpr (S == 0) {
+                st.d = v + delta;
+                st.r = __builtin_amdgcn_rcpf(st.d);
+            } else if constexpr (S == 1) {
+                st.mul = p.x * st.r;
+                st.f2 = __builtin_fmaf(-st.d, st.mul, p.x);
+            } else {
+                buf_st(t.rq, la.lb, la.soff(ro, co), __builtin_fmaf(st.f2, st.r, st.mul));
+            }
+        } else if constexpr (S == 0) {
             st.d = v + delta;
             bool unused;
             st.ds = __builtin_amdgcn_div_scalef(p.x, st.d, false, &unused);

@@ -396,6 +396,97 @@ __global__ void check_kernel(Ctrl *ctrl, const double *wstat, const double *hsta
     check_body<T>(ctrl, wstat, hstat, k, tol, t, dev_out);
 }
 
+// One-GPU MultUpdate-MSE, nothing tracked: the four launches around the stop rule of an iteration -- stop_condition's H statistics
+// finalised from the H update's per-tile partials (finalize_partials_kernel, behind the H update), col_stats_kernel and its
+// finalize_partials_kernel behind the W update, check_kernel -- as TWO launches behind the W update (round 6):
+//   col_stats_hfin_kernel : every block (chunk, j) column j's sums over its row chunk, as col_stats_kernel (same bits); blocks
+//                           0 .. (2K + 3) / 4 - 1 also four of the 2K H statistics each, a wave per output as finalize_partials_kernel
+//                           (same bits) -- work that fits beside 4096 blocks of column sums for free
+//   wfin_check_kernel     : ONE block: the W partials added up in chunk order (a thread per output, every load of a thread in flight
+//                           at once), then check_body
+// (Measured first as ONE launch whose last-arriving block did the second half: 4096 blocks taking an agent-scope ticket on one
+// address cost 80 us -- ~20 ns per contended atomic -- against the 23.5 us of the four launches.)
+template <typename T>
+__global__ __launch_bounds__(256) void col_stats_hfin_kernel(const T *Wn, const T *Wo, int64_t rows, int64_t ld, int K, double *wpart, const double *hpart,
+                                                             int hchunks, double *hstat, const int *done) {
+    NMFX_DONE_GUARD(done);
+    __shared__ double sm[8];
+    const int j = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const unsigned flat = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int64_t per = (rows + nchunks - 1) / nchunks;
+        const int64_t beg = chunk * per, end = (beg + per < rows) ? beg + per : rows;
+        double dev = 0.0, sum = 0.0;
+        const int64_t step = blockDim.x;
+        const T *wn = Wn + (int64_t)j * ld, *wo = Wo + (int64_t)j * ld;
+        for (int64_t i0 = beg + threadIdx.x; i0 < end; i0 += 4 * step) {
+            T a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = (i0 + u * step < end) ? i0 + u * step : i0;
+                a[u] = wn[i];
+                b[u] = wo[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * step < end) {
+                    const T d = a[u] - b[u], s = a[u] + b[u];
+                    dev += (double)(T)(d * d);
+                    sum += (double)(T)(s * s);
+                }
+        }
+        for (int off = 32; off > 0; off >>= 1) { dev += __shfl_down(dev, off, 64); sum += __shfl_down(sum, off, 64); }
+        const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sm[w] = dev; sm[4 + w] = sum; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double d = 0.0, s = 0.0;
+            for (int q = 0; q < nw; ++q) { d += sm[q]; s += sm[4 + q]; }
+            wpart[((int64_t)chunk * K + j) * 2] = d;
+            wpart[((int64_t)chunk * K + j) * 2 + 1] = s;
+        }
+    }
+    if (hpart != nullptr) {
+        const int e = (int)flat * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+        if (e < 2 * K) {
+            const int lane = threadIdx.x & 63;
+            double s = 0.0;
+            for (int c0 = lane; c0 < hchunks; c0 += 64 * 4) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = (c0 + 64 * u < hchunks) ? c0 + 64 * u : c0;
+                    v[u] = hpart[(int64_t)c * 2 * K + e];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (c0 + 64 * u < hchunks) s += v[u];
+            }
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0) hstat[e] = s;
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void wfin_check_kernel(const double *wpart, int nchunks, int K, double *wstat, const double *hstat, Ctrl *ctrl, int k, T tol,
+                                                         long long t, const int *done) {
+    NMFX_DONE_GUARD(done);
+    for (int e = threadIdx.x; e < 2 * K; e += blockDim.x) {
+        double s = 0.0;
+        for (int c0 = 0; c0 < nchunks; c0 += 32) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = wpart[(int64_t)((c0 + u < nchunks) ? c0 + u : nchunks - 1) * 2 * K + e];
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (c0 + u < nchunks) s += v[u];
+        }
+        wstat[e] = s;
+    }
+    __syncthreads();
+    check_body<T>(ctrl, wstat, hstat, k, tol, t, nullptr);
+}
+
 // objective finalisation (evaluate_objv): s = sum of block partials (ascending);
 //   mode 0: out = T(0.5*s + extra)   (src/multupd.jl:81, src/projals.jl:65-74, src/alspgrad.jl:398)
 //   mode 1: out = T(s)               (gkldiv, src/multupd.jl:148)

@@ -143,13 +143,15 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = dev_env("NMFX_STREAM_WH")) stream_wh = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_SMALLK")) smallk_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_DIV_FUSED")) div_fused = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_STATS_FUSED")) stats_fused_enabled = std::atoi(e) != 0;
+        if (const char *e = std::getenv("NMFX_DIV_IEEE")) div_ieee = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_K_GRANULE")) k_granule = (std::atoi(e) == 128) ? 128 : 64;
         if (const char *e = dev_env("NMFX_POTRS")) { potrs_enabled = std::atoi(e) != 0; potrs_iter = std::atoi(e) == 1; }
         if (const char *e = dev_env("NMFX_POTRS_STRIP")) strip_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_POTRF_REG")) potrf_reg_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_CHOL_UNROLLED")) chol_unrolled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_CHOL_UNDER_US")) chol_under_min_us = std::atof(e);
-        if (const char *e = dev_env("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
+        if (const char *e = std::getenv("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_W_BLOCKED")) blk_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_P2P_PULL")) peer_pull_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_DEFER_CHECK")) defer_enabled = std::atoi(e) != 0;
@@ -488,8 +490,15 @@ template <typename T> class Solver : public SolverBase {
     void ensure_xt() {
         if (xt_valid || !want_xt()) return;
         if (Xt.count < (size_t)P * N) {
+            // The image doubles the memory held for X (+ p*n elements).  It is an optimisation, so it must never be what makes a problem
+            // that fits without it run out of memory later: it is only taken if, after it, there is still room for what the iteration
+            // allocates lazily behind it (H' twice, the split-K slabs / work arrays: a few (p + n) k, bounded here by 8 (P + N) K elements
+            // + 256 MiB); otherwise -- or if the allocation itself fails -- the row-contiguous product stays.
+            size_t free_b = 0, total_b = 0;
+            const size_t need = (size_t)P * N * sizeof(T), headroom = (size_t)8 * (size_t)(P + N) * K * sizeof(T) + ((size_t)256 << 20);
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + headroom) { (void)hipGetLastError(); xt_enabled = false; return; }
             T *q = nullptr;
-            if (hipMalloc(reinterpret_cast<void **>(&q), (size_t)P * N * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); xt_enabled = false; return; }   // no room: keep the row-contiguous product
+            if (hipMalloc(reinterpret_cast<void **>(&q), need) != hipSuccess) { (void)hipGetLastError(); xt_enabled = false; return; }   // no room: keep the row-contiguous product
             Xt.release(); Xt.p = q; Xt.count = (size_t)P * N;
         }
         hipLaunchKernelGGL(transpose_kernel<T>, dim3((unsigned)((P / 64) * (N / 64))), dim3(256), 0, stream, Xt.p, N, X.p, P, P, N, (const int *)nullptr);
@@ -497,10 +506,36 @@ template <typename T> class Solver : public SolverBase {
         xt_valid = true;
     }
     // H' of the current H (start of a solve; afterwards the update epilogue keeps it current)
-    void refresh_ht() {
-        for (auto &h : Ht) h.ensure((size_t)N * K);
+    // (false: no room for H' -- the caller keeps the row-contiguous product)
+    bool refresh_ht() {
+        try {
+            for (auto &h : Ht) h.ensure((size_t)N * K);
+        } catch (const HipError &) {      // (DevBuf::alloc: hipMalloc failed)
+            (void)hipGetLastError();
+            for (auto &h : Ht) h.release();
+            xt_enabled = false;
+            return false;
+        }
         hipLaunchKernelGGL(transpose_kernel<T>, dim3((unsigned)((K / 64) * (N / 64))), dim3(256), 0, stream, Ht[hcur].p, N, H[hcur].p, K, K, N, (const int *)nullptr);
         HIP_TRY(hipGetLastError());
+        return true;
+    }
+    // H' of `Hp` for ONE X*H' product on the transposed images (the coordinate-descent updaters: their sweeps write H, not H'), or
+    // nullptr: not Float32, sharded, or no room for the images.  One 2 K N element transpose pass (~10 us at 16384 columns, k = 256)
+    // buys the contraction-contiguous kernel for the product: 1043 -> ~930 us at 16384 x 16384 (round 6).
+    const T *ht_for(const T *Hp, const int *done) {
+        if (!want_xt() || sharded()) return nullptr;
+        ensure_xt();
+        if (!xt_valid) return nullptr;
+        try {
+            Ht[0].ensure((size_t)N * K);
+        } catch (const HipError &) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        hipLaunchKernelGGL(transpose_kernel<T>, dim3((unsigned)((K / 64) * (N / 64))), dim3(256), 0, stream, Ht[0].p, N, Hp, K, K, N, done);
+        HIP_TRY(hipGetLastError());
+        return Ht[0].p;
     }
     T *numH_p = nullptr, *gramW_p = nullptr;
     T *numW_p = nullptr, *gramH_p = nullptr, *sH_p = nullptr;
@@ -883,7 +918,7 @@ template <typename T> class Solver : public SolverBase {
     // f32, K a multiple of 128, an output of many tiles per block slot: the persistent cross-tile pipeline of gemm_stream.hpp
     // (tile i's epilogue runs under tile i + 1's MFMAs).  NMFX_STREAM_WH=0 keeps the block-per-tile kernel.
     bool stream_wh = true;
-    static SEpiRatio<float> to_stream(const EpiRatio<float> &e) { return SEpiRatio<float>{e.X, e.Q, e.ld, e.delta}; }
+    template <int FAST> static SEpiRatio<float, FAST> to_stream(const EpiRatio<float, FAST> &e) { return SEpiRatio<float, FAST>{e.X, e.Q, e.ld, e.delta}; }
     template <int KL> static SEpiObjective<float, KL> to_stream(const EpiObjective<float, KL> &e) { return SEpiObjective<float, KL>{e.X, e.ld, e.partial, 0.0}; }
     template <typename Epi>
     void gemm_wh(const char *name, const T *Hp, const T *Wp, const Epi &epi, const int *done, double bytes) {
@@ -1202,6 +1237,22 @@ template <typename T> class Solver : public SolverBase {
         return w_in_slabs ? w_nslab : 1;
     }
 
+    // the two-launch form of [H finalize, W column sums, W finalize, stop rule] for the one-GPU MultUpdate-MSE step (kernels.hpp:
+    // col_stats_hfin_kernel, wfin_check_kernel); NMFX_STATS_FUSED=0 (development switch): the four launches
+    bool stats_fused_enabled = true;
+    DevBuf<double> stat_part_w;
+    bool stats_fuse_ok(const nmfx_opts &o) const { return stats_fused_enabled && !sharded() && o.track_objective == 0 && o.stop_sums == 0; }
+    void stats_w_check_fused(const T *Wn, const T *Wo, const nmfx_opts &o, long long t, const int *done) {
+        stat_part_w.ensure((size_t)stat_chunks_w * 2 * K);
+        timed("stats_W_check", 0.0, 2.0 * P * K * sizeof(T), [&] {
+            hipLaunchKernelGGL(col_stats_hfin_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wn, Wo, P, P, (int)K, stat_part_w.p,
+                               o.update_H ? stat_part.p : (const double *)nullptr, h_stat_chunks, hstat.p, done);
+            hipLaunchKernelGGL(wfin_check_kernel<T>, dim3(1), dim3(256), 0, stream, stat_part_w.p, stat_chunks_w, (int)K, wstat.p,
+                               o.update_H ? hstat.p : (const double *)nullptr, ctrl, (int)k, (T)o.tol, t, done);
+            HIP_TRY(hipGetLastError());
+        });
+        check_fused = true;
+    }
     void stats_w(const T *Wn, const T *Wo, const int *done) {
         timed("stats_W", 0.0, 2.0 * P * K * sizeof(T), [&] {
             hipLaunchKernelGGL(col_stats_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wn, Wo, P, P,
@@ -1260,6 +1311,7 @@ template <typename T> class Solver : public SolverBase {
     // multdiv on one GPU: the passes behind each numerator product fused (kernels.hpp: div_h_fused_kernel / div_w_fused_kernel);
     // svec / sH_p then carry sum(W, dims=1) / sum(H, dims=2) of the CURRENT factors from one side's pass to the other's
     bool div_fused = true, div_sw_valid = false, div_sh_valid = false;
+    bool div_ieee = false;                // NMFX_DIV_IEEE=1: the ratio pass divides with the correctly rounded IEEE sequence (gemm_mfma.hpp: ratio_div_fast)
     void enqueue_projals(const nmfx_opts &o, long long t);
     void spd_factor(T *A, T lambda, T *Uinv, const char *tag_potrf, const char *tag_trtri, const int *done, T *Tm = nullptr);
     // pdsolve!'s potrs! by blocked triangular substitution (chol.hpp: potrs_panel_kernel): the K x NB panel of the right-hand side lives in

@@ -175,7 +175,8 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
         gemm<KCONTIG, KCONTIG>("gemm_WtWH_updH", Ho, K, N, gramW_p, K, K, K, 1, true, e, done, (3.0 + h_num_nslab()) * K * N * sizeof(T));
         }
         h_stat_chunks = last_tiles_r;
-        if (!fusedrs) stats_h_finalize(last_tiles_r, done);   // fused row-sharded step: finalised by the W side's combine launch
+        // (fused row-sharded step: finalised by the W side's combine launch; one GPU, nothing tracked: by the launch behind the W update)
+        if (!fusedrs && !stats_fuse_ok(o)) stats_h_finalize(last_tiles_r, done);
         hcur ^= 1;
     }
     const T *Hp = H[hcur].p;
@@ -203,7 +204,8 @@ template <typename T> void Solver<T>::enqueue_multmse(const nmfx_opts &o, long l
     allreduce_w_side(o.update_H != 0, done);
     EpiMultUpdate<T, 0> e{w_num(), w_num_nslab(), w_stride, Wo, Wn, P, (T)o.lambda_w, (T)o.delta, nullptr, 0};   // :110-114
     gemm<KSTRIDED, KSTRIDED>("gemm_WHHt_updW", gramH_p, K, K, Wo, P, P, K, 1, false, e, done, 3.0 * P * K * sizeof(T));
-    stats_w(Wn, Wo, done);
+    if (stats_fuse_ok(o)) stats_w_check_fused(Wn, Wo, o, t, done);
+    else stats_w(Wn, Wo, done);
     wcur ^= 1;
 }
 
@@ -534,8 +536,8 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
         const T *Wp = W[wcur].p;
         const T *Ho = H[hcur].p;
         T *Hn = H[hcur ^ 1].p;
-        EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                           // :172-174
-        gemm_wh("gemm_WH_ratio", Ho, Wp, er, done, qbytes);
+        if (div_ieee) { EpiRatio<T, 0> er{X.p, Q.p, P, (T)o.delta}; gemm_wh("gemm_WH_ratio", Ho, Wp, er, done, qbytes); }    // :172-174
+        else { EpiRatio<T, 1> er{X.p, Q.p, P, (T)o.delta}; gemm_wh("gemm_WH_ratio", Ho, Wp, er, done, qbytes); }
         if (fused) {
             // single GPU: the slab sum, the scaling, stop_condition's sums and sum(H, dims=2) for the W side in one pass
             wt_times(Wp, Q.p, false, done, /*keep_slabs=*/true);           // :175
@@ -574,8 +576,8 @@ template <typename T> void Solver<T>::enqueue_multdiv(const nmfx_opts &o, long l
     const T *Hp = H[hcur].p;
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
-    EpiRatio<T> er{X.p, Q.p, P, (T)o.delta};                               // :184-186
-    gemm_wh("gemm_WH_ratio", Hp, Wo, er, done, qbytes);
+    if (div_ieee) { EpiRatio<T, 0> er{X.p, Q.p, P, (T)o.delta}; gemm_wh("gemm_WH_ratio", Hp, Wo, er, done, qbytes); }       // :184-186
+    else { EpiRatio<T, 1> er{X.p, Q.p, P, (T)o.delta}; gemm_wh("gemm_WH_ratio", Hp, Wo, er, done, qbytes); }
     const bool rs = row_sharded();
     if (fused) {
         times_ht(Q.p, Hp, false, done, /*keep_slabs=*/true);               // :187
@@ -689,7 +691,7 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     ht_active = false;
     if (alg == NMFX_ALG_MULTMSE && !smallk_ok() && !pipelined() && want_xt()) {
         ensure_xt();
-        if (xt_valid) { refresh_ht(); ht_active = true; }
+        if (xt_valid) ht_active = refresh_ht();
     }
     if (alg == NMFX_ALG_CD && o.cd_shuffle != 0) prepare_cd_permutations(o);
     const int w0 = wcur, h0 = hcur;

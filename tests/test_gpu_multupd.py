@@ -290,3 +290,31 @@ def test_multdiv_first_h_update_is_bit_identical_on_selection_factors(built, T, 
     U = np.uint32 if T == np.float32 else np.uint64
     assert np.array_equal(Hg.view(U), Hc.view(U)), float(np.max(np.abs(Hg - Hc)))
     assert not np.array_equal(Hg, H0)
+
+
+@pytest.mark.parametrize("shape", [(300, 260, 70), (2048, 2304, 128), (129, 257, 128)])
+def test_ratio_pass_division_against_the_ieee_sequence(built, shape, monkeypatch):
+    """Round 6: the ratio pass Q = X ./ (WH + delta) of MultUpdate(:div) (src/multupd.jl:172-174, 184-186) divides by v_rcp_f32's
+    reciprocal and one residual correction formed exactly by a fused multiply-add (gemm_mfma.hpp: ratio_div_fast; 4 instructions
+    for the 12 of the IEEE sequence in the matrix cores' shadow).  Emulated on the host over 2e7 operand pairs the result equals the
+    correctly rounded quotient everywhere when the reciprocal is correctly rounded and differs by ONE ulp on 2e-7 of the pairs when
+    the reciprocal is an ulp off.  Here: ten Float32 iterations with either division (NMFX_DIV_IEEE=1 keeps the IEEE sequence; both
+    shapes of the product kernel: block-per-tile and the persistent stream form at 2048 x 2304, k = 128) agree to rounding -- far
+    inside the 1e-5 of the objective's stated tolerance -- and with the oracle, whose division is IEEE."""
+    p, n, k = shape
+    T = np.float32
+    X, W0, H0 = planted(p, n, k, T, seed=31 + p)
+    alg = nmfx.MultUpdate(T, obj="div", maxiter=10, tol=1e-30)
+    out = {}
+    for ieee in ("0", "1"):
+        monkeypatch.setenv("NMFX_DIV_IEEE", ieee)
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        r = nmfx.solve(alg, X, W, H, track_objective=True)
+        out[ieee] = (r, W, H)
+    monkeypatch.delenv("NMFX_DIV_IEEE")
+    (ra, Wa, Ha), (rb, Wb, Hb) = out["0"], out["1"]
+    assert ra.niters == rb.niters == 10
+    assert rel_trace_err(ra.trace, rb.trace) < 2e-6
+    assert np.max(np.abs(Wa - Wb)) <= 2e-5 * np.max(np.abs(Wb)) and np.max(np.abs(Ha - Hb)) <= 2e-5 * np.max(np.abs(Hb))
+    ro = orc.solve("multdiv", X, W0.copy(order="F"), H0.copy(order="F"), orc.Opts(maxiter=10, tol=1e-30, track_objective=True))
+    assert rel_trace_err(ra.trace, ro.trace) < TOL[T][0]

@@ -106,6 +106,10 @@ def test_projals_substitution_route(built, T, shape, lam, monkeypatch):
     ro = orc.solve("projals", X, Wc, Hc, orc.Opts(maxiter=10, tol=1e-30, lambda_w=lam, lambda_h=lam, track_objective=True))
     assert all(r.niters == 10 for r, _, _ in res.values()) and ro.niters == 10
     tol = 1e-6 if T == np.float64 else 2e-2      # cond(Gram) * eps: 4e4 * 1.2e-7 at k = 70 in f32; k = 130 of p = 200 rows: 2e-8 measured in f64
+    if T == np.float32 and k > 256:
+        # k = 300, 500 of ~1000 rows: the Gram's condition number grows with k, and which launch forms it (alone, or as tail pieces of the
+        # W'X launch: round 6 runs these short products in stream order) already moves the Float32 trajectory by 2.3e-2 between the two routes
+        tol = 4e-2
     for route in ("strip", "panel"):
         r, Wb, Hb = res[route]
         assert rel_trace_err(r.trace, res["product"][0].trace) < tol, route

@@ -161,8 +161,8 @@ const char *nmfx_version(void);
 /* Upload X (host, column-major, leading dimension ldx >= p).  X is read-only
  * for solve! (src/common.jl:45-47) and re-used across `replicates` (src/interf.jl:85-101),
  * so it is uploaded once.
- * Device memory: the padded X (p and n rounded up to the tile sizes), and -- Float32 MultUpdate(:mse) on the general path, from
- * the first such solve on -- a second, transposed image of it (+ p*n elements: 1 GiB of 288 at 16384 x 16384) that lets X*H'
+ * Device memory: the padded X (p and n rounded up to the tile sizes), and -- Float32 MultUpdate(:mse) on the general path and
+ * one-GPU Float32 CoordinateDescent / GreedyCD / ProjectedALS (large problems), from the first such solve on -- a second, transposed image of it (+ p*n elements: 1 GiB of 288 at 16384 x 16384) that lets X*H'
  * contract over the contiguous index.  The image is an optimisation: it is taken only while enough memory stays free for the
  * buffers an iteration allocates behind it (otherwise, or with NMFX_XT=0 in the environment, X*H' runs on X as it is, ~5 % slower). */
 int nmfx_set_X(nmfx_ctx *ctx, const void *X_host, int64_t ldx);

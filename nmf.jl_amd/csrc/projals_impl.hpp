@@ -29,7 +29,10 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
     const bool reg = potrf_reg_ok() && !(sizeof(T) == 8 && potrf_nt == 512);
     timed(tag_potrf, (double)k * k * k / 3.0, 0.0, [&] {
         if (reg) {
-            HIP_TRY(hipMemsetAsync(Uinv, 0, kk * sizeof(T), stream));
+            // Uinv must be zero outside the blocks this launch and trtri write.  In stream order: zeroed here.  Under a product (potrf_nt
+            // == 512): zeroed ONCE per solve by iterate() -- the 64-block memset launch waited 363 us on average for block slots on the
+            // factorisation stream, in front of a potrf that takes 75-340 us -- and it stays zero: both writers only touch their own blocks
+            if (potrf_nt != 512) HIP_TRY(hipMemsetAsync(Uinv, 0, kk * sizeof(T), stream));
             auto go = [&](auto nblk) {
                 constexpr int NBLK = decltype(nblk)::value;
                 const size_t lds = PotrfReg<T, NBLK>::lds_bytes();
@@ -67,9 +70,15 @@ template <typename T> void Solver<T>::spd_factor(T *A, T lambda, T *Uinv, const 
         }
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&trtri_offdiag_kernel<T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tri));
-        if (Tm != nullptr && strip_ok())   // ... packed block by block in the order potrs_strip_kernel's sweeps consume them
-            hipLaunchKernelGGL((potrs_strip_pack_kernel<T>), dim3((unsigned)std::min<int64_t>((strip_pack_elems((int)(K / 32)) + 255) / 256, 1024)), dim3(256), 0, stream, A, Uinv, Tm, K,
-                               (int)k, (int)(K / 32), done);
+        if (Tm != nullptr && strip_ok() && defer_pack) {
+            // (enqueue_projals launches the pack itself, on the main stream behind the product: see there)
+        } else if (Tm != nullptr && strip_ok()) {   // ... packed block by block in the order potrs_strip_kernel's sweeps consume them
+            // (sharing its CUs with a product the pack's 288 one-trip blocks trickle through the 8 half-empty CUs in 130-170 us, against 4 us
+            // alone; 16 blocks that fit them at once were measured SLOWER, 390 us: co-resident, every instruction is ~10x slower, and then
+            // each thread loops over 18 elements)
+            const int64_t pack_blocks = std::min<int64_t>((strip_pack_elems((int)(K / 32)) + 255) / 256, 1024);
+            hipLaunchKernelGGL((potrs_strip_pack_kernel<T>), dim3((unsigned)pack_blocks), dim3(256), 0, stream, A, Uinv, Tm, K, (int)k, (int)(K / 32), done);
+        }
         else if (Tm != nullptr)   // left solve by substitution (potrs!): only the diagonal blocks' inverses are needed, packed with U and U' (chol.hpp)
             hipLaunchKernelGGL((potrs_prep_kernel<T>), dim3((unsigned)std::min<int64_t>((K * K + 255) / 256, 1024)), dim3(256), 0, stream, A, Uinv, Tm, K, (int)k, (int)K, done);
         else
@@ -201,9 +210,10 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // CU).  Sharing its CU with a GEMM block the chain runs 4x slower (potrf 650 us, trtri 400 us), which still fits under the
     // 1.02 ms product: 2.75 -> 2.36 ms per iteration at 16384 x 16384, k = 256.  Replicated-W multi-GPU mode keeps the serial
     // order (its Gram travels inside the one packed all-reduce that follows the product).
-    // (round 6: only under a product long enough to cover the chain.  Sharing its CU the register-resident potrf takes 0.6-0.8 ms at
-    // k = 256 -- ten times its stand-alone 77 us: it is bound by instruction issue, which the product's waves contend for -- so under
-    // a 60 us product (4096 x 4096, k = 256) the chain WAS the iteration: 0.69 ms; in stream order, with the fast factorisation, 0.48)
+    // (round 6: only under a product long enough to cover most of the chain.  Sharing its CU the register-resident potrf takes
+    // 0.53-0.62 ms at k = 256 -- seven times its stand-alone 77 us: it is bound by instruction issue, which the product's waves
+    // contend for -- so under a short product the chain is the iteration: 8192 x 8192: 1.70 ms under the 229 us products, 0.86 in
+    // stream order; from ~300 us on hiding wins: solver.hpp, chol_under_min_us)
     const double prod_us = 2.0 * (double)P * (double)N * (double)K / (sizeof(T) == 4 ? 150e6 : 70e6);
     const bool under = chol_slots > 0 && !use_bf16x3() && K % 128 == 0 && (!sharded() || rs) && prod_us >= chol_under_min_us;
     if (under) ensure_fstream();
@@ -245,11 +255,23 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
             // :92 W'W (W is replicated: no exchange) -- or, from the second iteration of the fused row-sharded step on, already there:
             // the sum over the ranks of W_g'W_g of their own new rows, which travelled with the all-gather of W
             if (!gramw_sharded_valid) gram_w_only(Wp, done);
-            factor_under(gramW_p, (T)o.lambda_h, "potrf_WtW", "trtri_WtW", false);   // :92 adddiag!, :94 potrf!
+            // (round 6: with the register-resident potrf the diagonal blocks' inverses come out of the factorisation launch, and the pack
+            // of the factor for the strip kernel -- 4 us alone, 130-370 us when its 288 blocks have to find slots under the product --
+            // runs on the main stream behind the product instead: the chain under W'X is the potrf alone, ~530 of the product's 930 us)
+            defer_pack = subst && strip_ok() && potrf_reg_ok();
+            try { factor_under(gramW_p, (T)o.lambda_h, "potrf_WtW", "trtri_WtW", false); } catch (...) { defer_pack = false; throw; }   // :92 adddiag!, :94 potrf!
+            const bool packed_later = defer_pack;
+            defer_pack = false;
             short_grid = true;
             try { wt_times(Wp, X.p, false, done); } catch (...) { short_grid = false; throw; }   // :93 H <- W'X
             short_grid = false;
             HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
+            if (packed_later)
+                timed("pack_WtW", 0.0, 2.0 * (double)strip_pack_elems((int)(K / 32)) * sizeof(T), [&] {
+                    hipLaunchKernelGGL((potrs_strip_pack_kernel<T>), dim3((unsigned)std::min<int64_t>((strip_pack_elems((int)(K / 32)) + 255) / 256, 1024)), dim3(256), 0, stream,
+                                       gramW_p, Uinv, invA, K, (int)k, (int)(K / 32), done);
+                    HIP_TRY(hipGetLastError());
+                });
         } else {
             wt_times(Wp, X.p, true, done);                                     // :92 W'W, :93 H <- W'X (one launch)
             spd_factor(gramW_p, (T)o.lambda_h, Uinv, "potrf_WtW", "trtri_WtW", done, subst ? invA : (T *)nullptr);
@@ -274,8 +296,15 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
         if (rs) timed("all_reduce_HHt", 0.0, (double)kk * sizeof(T), [&] { comm->all_reduce(gramH_p, kk, CT, false, stream); });   // ... summed
         factor_under(gramH_p, (T)o.lambda_w, "potrf_HHt", "trtri_HHt", true);  // :100 adddiag!, :102 potrf!, potri!, copytri!
         w_blocked = rs;
+        // (round 6, one GPU: XH' on the transposed images -- the contraction-contiguous kernel with its k-loop unrolled, as W'X runs.
+        // Round 5 measured this SLOWER: the chain beside it, 606 us of potrf + trtri + potri, fell behind the product.  With the
+        // register-resident potrf and nothing of the chain waiting for block slots any more the chain ends well inside the product)
+        // ... measured again with the pack off the chain and the memset gone: the product itself 983 -> 931 us, but trtri + potri beside the
+        // unrolled kernel take 166 + 210 instead of 89 + 155 us, the chain (952 us) ends after the product again and the iteration is
+        // SLOWER, 2.09-2.10 -> 2.14-2.17 ms.  Left off (NMFX_PROJALS_XT=1 to measure).
+        const T *HtP = (xht_images && !rs) ? ht_for(Hp, done) : nullptr;
         short_grid = true;
-        try { times_ht(X.p, Hp, false, done); } catch (...) { short_grid = false; w_blocked = false; throw; }   // :101 XH'
+        try { times_ht(X.p, Hp, false, done, false, HtP); } catch (...) { short_grid = false; w_blocked = false; throw; }   // :101 XH'
         short_grid = false;
         w_blocked = false;
         if (rs && rs_fused_enabled) {

@@ -150,6 +150,7 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = dev_env("NMFX_POTRS_STRIP")) strip_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_POTRF_REG")) potrf_reg_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_CHOL_UNROLLED")) chol_unrolled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_PROJALS_XT")) xht_images = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_CHOL_UNDER_US")) chol_under_min_us = std::atof(e);
         if (const char *e = std::getenv("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_W_BLOCKED")) blk_enabled = std::atoi(e) != 0;
@@ -634,7 +635,11 @@ template <typename T> class Solver : public SolverBase {
     int64_t Rc = 0, Pcc = 0;              // rows per super-chunk, rows per (super-chunk, rank)
     size_t agc_bytes = 0;
     hipStream_t cstream = nullptr;        // the collectives of the pipelined mode
-    double chol_under_min_us = 700.0;     // ProjectedALS hides its factorisations under a product only if the product is estimated this long (projals_impl.hpp)
+    // ProjectedALS hides its factorisations under a product only if the product is estimated at least this long (projals_impl.hpp).  Measured
+    // (scripts/r06_under_sweep.sh, k = 256, Float32, ms per iteration in stream order / under the products): 4096^2 (57 us) 0.477 / 0.463,
+    // 8192 x 4096 (115) 0.595 / 0.637, 8192^2 (229) 0.861 / 1.695, 12288 x 8192 (344) 1.211 / 1.024, 8192 x 16384 (458) 1.332 / 1.145,
+    // 16384 x 12288 (687) 2.034 / 1.827, 16384^2 (916) 2.70 / 2.095
+    double chol_under_min_us = 300.0;
     int chol_slots = 8;                   // block slots (half CUs) the big products of ProjectedALS leave to the factorisation stream
     bool short_grid = false;              // set around the products that must leave those slots
     int potrf_nt = 1024;                  // threads of the Cholesky workgroup (512 when it has to fit beside a GEMM block)
@@ -1180,7 +1185,8 @@ template <typename T> class Solver : public SolverBase {
             e.C2 = slabs.p + gram_slab_off; e.ld2 = rows; e.stride2 = rows * K; e.r_off = 0; e.c_off = r0;
             Seg sg;
             sg.tail_main = shg.leftover; sg.tail_per = shg.per;
-            gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done, (double)(P * N + K * N) * sizeof(T), sg);
+            if (xt) gemm<KCONTIG, KCONTIG>("gemm_XHt", HtP, N, K, Xt.p, N, P, N, s_w, false, e, done, (double)(P * N + K * N) * sizeof(T), sg);
+            else gemm<KSTRIDED, KSTRIDED>("gemm_XHt", Hp, K, K, Amat, P, P, N, s_w, false, e, done, (double)(P * N + K * N) * sizeof(T), sg);
             if (!w_blocked && (!keep_slabs || w_nslab > 2)) {   // pieces + slabs in one launch
                 timed("reduce_XHt", 0.0, (double)P * K * (w_nslab + 1) * sizeof(T), [&] {
                     constexpr int V = 16 / (int)sizeof(T);
@@ -1339,6 +1345,8 @@ template <typename T> class Solver : public SolverBase {
     // the products that share their CUs with the factorisation keep the k-loop unrolled by two when the factorisation is the short
     // register-resident one (launch_gemm_cfg); NMFX_CHOL_UNROLLED=0: the rolled loop as before (A/B)
     bool chol_unrolled = true;
+    bool xht_images = false;              // NMFX_PROJALS_XT=1 (development switch): ProjectedALS's XH' under the chain on the transposed images (measured slower twice)
+    bool defer_pack = false;              // set around the H side's factor_under: spd_factor leaves the pack of the factor to the caller
     int spd_solve_left_potrs(const T *Tm, const T *B, T *out, bool clamp, const T *old, const int *done);
     void spd_solve_left(const T *Uinv, const T *B, T *Y, T *out, bool clamp, const int *done);
     void spd_solve_right(const T *Uinv, T *invA, const T *A, T *out, int64_t rows, bool clamp, const int *done);

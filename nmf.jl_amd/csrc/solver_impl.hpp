@@ -694,6 +694,14 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         if (xt_valid) ht_active = refresh_ht();
     }
     if (alg == NMFX_ALG_CD && o.cd_shuffle != 0) prepare_cd_permutations(o);
+    if (alg == NMFX_ALG_PROJALS) {
+        // the buffer of the triangular inverse is zeroed ONCE per solve, here on the main stream: the register-resident factorisation
+        // writes only the upper triangles of its diagonal blocks and trtri only the blocks above them, so the rest stays zero from one
+        // iteration to the next (round 6: the per-iteration hipMemsetAsync in front of the factorisation is a 64-block launch, and on the
+        // factorisation stream it waited for block slots under the product -- 363 us on average, in front of a 75-340 us potrf)
+        work[1].ensure((size_t)K * K);
+        HIP_TRY(hipMemsetAsync(work[1].p, 0, (size_t)K * K * sizeof(T), stream));
+    }
     const int w0 = wcur, h0 = hcur;
     begin_iter_trace(o);
     HIP_TRY(hipEventRecord(ev_beg, stream));

@@ -229,6 +229,7 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     if (o.h_solve == NMFX_HSOLVE_POTRS && !potrs_route_ok())
         throw StatusError{NMFX_ERR_UNSUPPORTED, "h_solve = NMFX_HSOLVE_POTRS: the substitution route does not exist for this k (use NMFX_HSOLVE_AUTO or NMFX_HSOLVE_PRODUCT)"};
     const bool subst = (o.h_solve == NMFX_HSOLVE_POTRS || (o.h_solve == NMFX_HSOLVE_AUTO && (potrs_iter || strip_ok()))) && potrs_route_ok();
+    bool potri_on_main = false;
     auto factor_under = [&](T *G, T lambda, const char *t1, const char *t2, bool with_potri) {
         HIP_TRY(hipEventRecord(ev_fork, stream));
         HIP_TRY(hipStreamWaitEvent(fstream, ev_fork, 0));
@@ -240,7 +241,7 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
                 ~Swap() { std::swap(s.stream, s.fstream); s.potrf_nt = 1024; }
             } on_side(*this);
             spd_factor(G, lambda, Uinv, t1, t2, done, (!with_potri && subst) ? invA : (T *)nullptr);
-            if (with_potri) {            // potri! + copytri! (src/utils.jl:79-80) belong to the factorisation, not to the product
+            if (with_potri && !potri_on_main) {   // potri! + copytri! (src/utils.jl:79-80) belong to the factorisation, not to the product
                 EpiStore<T> e1{invA, K, 0, nullptr};
                 gemm<KSTRIDED, KSTRIDED>("gemm_potri", Uinv, K, K, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * K * sizeof(T));
             }
@@ -294,6 +295,9 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     if (under) {
         gram_h_only(Hp, done);                                                 // :100 HH' of this rank's columns ...
         if (rs) timed("all_reduce_HHt", 0.0, (double)kk * sizeof(T), [&] { comm->all_reduce(gramH_p, kk, CT, false, stream); });   // ... summed
+        // (with XH' on the transposed images -- NMFX_PROJALS_XT=1 -- potri!'s product runs on the main stream behind XH': 10 us there,
+        // 156-252 us beside the product)
+        potri_on_main = xht_images && !rs;
         factor_under(gramH_p, (T)o.lambda_w, "potrf_HHt", "trtri_HHt", true);  // :100 adddiag!, :102 potrf!, potri!, copytri!
         w_blocked = rs;
         // (round 6, one GPU: XH' on the transposed images -- the contraction-contiguous kernel with its k-loop unrolled, as W'X runs.
@@ -354,6 +358,10 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
         }
         if (rs) scatter_w_numerator(o.update_H != 0, done, /*with_tail=*/false);
         HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
+        if (potri_on_main) {             // (see above: potri! behind the product instead of beside it)
+            EpiStore<T> e1{invA, K, 0, nullptr};
+            gemm<KSTRIDED, KSTRIDED>("gemm_potri", Uinv, K, K, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * K * sizeof(T));
+        }
         const int64_t r0 = rs ? row0 : 0, rows = rs ? Pc : P;
         EpiClampStore<T> e2{Wn + r0, P};                                       // :102 mul!, :103 projectnn!
         gemm<KSTRIDED, KSTRIDED>("gemm_XHtInv_clampW", invA, K, K, numW_p + r0, P, rows, K, 1, false, e2, done, 2.0 * rows * K * sizeof(T));

@@ -639,31 +639,60 @@ __global__ __launch_bounds__(256) void trtri_offdiag_kernel(const T *U, T *Uinv,
             for (int sj = 0; sj < SUB; ++sj)
 #pragma unroll
                 for (int r = 0; r < M::NACC; ++r) acc[si][sj][r] = (T)0;
+        // (round 6: the operand loads of a block product are requested together, ahead of its 16 matrix-core steps -- they used to sit
+        // inside the k-loop behind a run-time `tile in LDS?` branch, i.e. one global round trip per k-step: 12.5 us per block step, 88 us
+        // for the launch at k = 256; and wave 0 requests the diagonal block of its closing product here, at the top of the step)
+        T vinv[NB / KS][SUB];
+        if (wave == 0) {
+#pragma unroll
+            for (int kk = 0; kk < NB / KS; ++kk)
+#pragma unroll
+                for (int si = 0; si < SUB; ++si) {     // A(i, l) = Vinv_a(i, l), upper triangular
+                    const int i = si * MT + li, l = kk * KS + ks;
+                    const int gr = a * NB + i, gc = a * NB + l;
+                    const bool in = i <= l && gr < k && gc < k;
+                    const T v = Uinv[in ? gr + (int64_t)gc * ld : 0];
+                    vinv[kk][si] = in ? v : (T)0;
+                }
+        }
         for (int c = a + 1 + wave; c <= b; c += 4) {
             const bool in_lds = (b - c) < nfit;
             const T *Yc = Y + (size_t)(in_lds ? (b - c) : 0) * NB * NB;
+            T afr[NB / KS][SUB];
 #pragma unroll
-            for (int kk = 0; kk < NB / KS; ++kk) {
-                const int l = kk * KS + ks;
-                T af[SUB], bf[SUB];
+            for (int kk = 0; kk < NB / KS; ++kk)
 #pragma unroll
                 for (int si = 0; si < SUB; ++si) {     // A(i, l) = U(32a + i, 32c + l)
-                    const int gr = a * NB + si * MT + li, gc = c * NB + l;
-                    af[si] = (gr < k && gc < k) ? U[gr + (int64_t)gc * ld] : (T)0;
+                    const int gr = a * NB + si * MT + li, gc = c * NB + kk * KS + ks;
+                    const bool in = gr < k && gc < k;
+                    const T v = U[in ? gr + (int64_t)gc * ld : 0];
+                    afr[kk][si] = in ? v : (T)0;
                 }
+            auto run = [&](auto in_lds_c) {
+                constexpr bool IN_LDS = decltype(in_lds_c)::value;
+                T bfr[NB / KS][SUB];
 #pragma unroll
-                for (int sj = 0; sj < SUB; ++sj) {
-                    if (in_lds) bf[sj] = Yc[l * NB + sj * MT + li];
-                    else {   // finished tile c of this column, from global memory: Uinv(32c + l, 32b + j); zero outside the matrix
-                        const int gr = c * NB + l, gc = b * NB + sj * MT + li;
-                        bf[sj] = (gr < k && gc < k) ? *reinterpret_cast<const volatile T *>(Uinv + gr + (int64_t)gc * ld) : (T)0;
+                for (int kk = 0; kk < NB / KS; ++kk)
+#pragma unroll
+                    for (int sj = 0; sj < SUB; ++sj) {
+                        const int l = kk * KS + ks;
+                        if constexpr (IN_LDS) bfr[kk][sj] = Yc[l * NB + sj * MT + li];
+                        else {   // finished tile c of this column, from global memory: Uinv(32c + l, 32b + j); zero outside the matrix
+                            const int gr = c * NB + l, gc = b * NB + sj * MT + li;
+                            const bool in = gr < k && gc < k;
+                            const T v = *reinterpret_cast<const volatile T *>(Uinv + (in ? gr + (int64_t)gc * ld : 0));
+                            bfr[kk][sj] = in ? v : (T)0;
+                        }
                     }
-                }
 #pragma unroll
-                for (int si = 0; si < SUB; ++si)
+                for (int kk = 0; kk < NB / KS; ++kk)
 #pragma unroll
-                    for (int sj = 0; sj < SUB; ++sj) acc[si][sj] = M::mma(af[si], bf[sj], acc[si][sj]);
-            }
+                    for (int si = 0; si < SUB; ++si)
+#pragma unroll
+                        for (int sj = 0; sj < SUB; ++sj) acc[si][sj] = M::mma(afr[kk][si], bfr[kk][sj], acc[si][sj]);
+            };
+            if (in_lds) run(std::true_type{});
+            else run(std::false_type{});
         }
         // write this wave's partial tile (row-major) and combine the four in a fixed order
         T *Pw = Ps + (size_t)wave * NB * NB;
@@ -694,19 +723,13 @@ __global__ __launch_bounds__(256) void trtri_offdiag_kernel(const T *U, T *Uinv,
 #pragma unroll
             for (int kk = 0; kk < NB / KS; ++kk) {
                 const int l = kk * KS + ks;
-                T af[SUB], bf[SUB];
-#pragma unroll
-                for (int si = 0; si < SUB; ++si) {     // A(i, l) = Vinv_a(i, l), upper triangular
-                    const int i = si * MT + li;
-                    const int gr = a * NB + i, gc = a * NB + l;
-                    af[si] = (i <= l && gr < k && gc < k) ? Uinv[gr + (int64_t)gc * ld] : (T)0;
-                }
+                T bf[SUB];
 #pragma unroll
                 for (int sj = 0; sj < SUB; ++sj) bf[sj] = Ps[l * NB + sj * MT + li];
 #pragma unroll
                 for (int si = 0; si < SUB; ++si)
 #pragma unroll
-                    for (int sj = 0; sj < SUB; ++sj) acc2[si][sj] = M::mma(af[si], bf[sj], acc2[si][sj]);
+                    for (int sj = 0; sj < SUB; ++sj) acc2[si][sj] = M::mma(vinv[kk][si], bf[sj], acc2[si][sj]);
             }
             const bool keep = (b - a) < nfit;
             T *Ya = Y + (size_t)(keep ? (b - a) : 0) * NB * NB;

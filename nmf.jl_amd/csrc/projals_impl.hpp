@@ -212,8 +212,8 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // order (its Gram travels inside the one packed all-reduce that follows the product).
     // (round 6: only under a product long enough to cover most of the chain.  Sharing its CU the register-resident potrf takes
     // 0.53-0.62 ms at k = 256 -- seven times its stand-alone 77 us: it is bound by instruction issue, which the product's waves
-    // contend for -- so under a short product the chain is the iteration: 8192 x 8192: 1.70 ms under the 229 us products, 0.86 in
-    // stream order; from ~300 us on hiding wins: solver.hpp, chol_under_min_us)
+    // contend for -- so under a short product the chain is the iteration (8192 x 4096: 0.58 ms under the 115 us products, 0.54 in
+    // stream order); from ~200 us on hiding wins: solver.hpp, chol_under_min_us)
     const double prod_us = 2.0 * (double)P * (double)N * (double)K / (sizeof(T) == 4 ? 150e6 : 70e6);
     const bool under = chol_slots > 0 && !use_bf16x3() && K % 128 == 0 && (!sharded() || rs) && prod_us >= chol_under_min_us;
     if (under) ensure_fstream();

@@ -636,10 +636,10 @@ template <typename T> class Solver : public SolverBase {
     size_t agc_bytes = 0;
     hipStream_t cstream = nullptr;        // the collectives of the pipelined mode
     // ProjectedALS hides its factorisations under a product only if the product is estimated at least this long (projals_impl.hpp).  Measured
-    // (scripts/r06_under_sweep.sh, k = 256, Float32, ms per iteration in stream order / under the products): 4096^2 (57 us) 0.477 / 0.463,
-    // 8192 x 4096 (115) 0.595 / 0.637, 8192^2 (229) 0.861 / 1.695, 12288 x 8192 (344) 1.211 / 1.024, 8192 x 16384 (458) 1.332 / 1.145,
-    // 16384 x 12288 (687) 2.034 / 1.827, 16384^2 (916) 2.70 / 2.095
-    double chol_under_min_us = 300.0;
+    // (scripts/r06_step11.sh, k = 256, Float32, ms per iteration in stream order / under the products, with round 6's trtri): 4096^2
+    // (57 us) 0.425 / 0.409, 8192 x 4096 (115) 0.541 / 0.583, 8192^2 (229) 0.800 / 0.686, 12288 x 8192 (344) 1.156 / 1.009; before the
+    // trtri change 8192^2 was 0.861 / 1.695 and 8192 x 16384 (458) 1.332 / 1.145, 16384 x 12288 (687) 2.034 / 1.827
+    double chol_under_min_us = 200.0;
     int chol_slots = 8;                   // block slots (half CUs) the big products of ProjectedALS leave to the factorisation stream
     bool short_grid = false;              // set around the products that must leave those slots
     int potrf_nt = 1024;                  // threads of the Cholesky workgroup (512 when it has to fit beside a GEMM block)

@@ -244,6 +244,21 @@ __global__ __launch_bounds__(256) void cd_sweep16_kernel(SampleView<const T> Wol
 // division (tests/test_host_api.py::test_greedy_division_identity checks 4e6 operand pairs incl. adversarial ones).  3 operations on
 // the greedy step's dependency chain instead of the ~12 of v_div_scale / v_rcp / fma x5 / v_div_fmas / v_div_fixup.  Float64 divides.
 __device__ __forceinline__ float greedy_div(float g, float, double rden) { return (float)((double)g * rden); }
+// The same quotient from Float32 operations only (round 6; the register form of the sweep): with r = RN(1 / den) -- ONE IEEE division per
+// component and row --  q0 = RN(g r),  e = g - den q0 (one fused multiply-add: the residual of a quotient that is within an ulp is
+// exactly representable or rounds harmlessly),  q = RN(q0 + e r)  is the correctly rounded g / den (Markstein's theorem for a correctly
+// rounded reciprocal; tests/test_host_api.py::test_greedy_division_fma_form checks it in exact rational arithmetic on random and on
+// adversarial operands -- all-ones significands, quotients next to rounding boundaries).  v_mul_f32 + 2 v_fma_f32 at 1.1 ns each
+// where v_cvt_f64_f32 + v_mul_f64 + v_cvt_f32_f64 take 1.8 + 1.9 + 1.8 ns with eight waves on a SIMD (profiles/r04_valu_rate_probe.log):
+// -9 ns on a greedy step of ~160.  Non-finite g (the lanes beyond k carry +inf) gives NaN here where the Float64 form gives inf: either way
+// the lane's D is NaN, which the arg-max skips.
+__device__ __forceinline__ float greedy_div_fma(float g, float den, float r) {
+    float q0, e, q;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(q0) : "v"(g), "v"(r));
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(den), "v"(q0), "v"(g));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(q) : "v"(e), "v"(r), "v"(q0));
+    return q;
+}
 __device__ __forceinline__ double greedy_div(double g, double den, double) { return g / den; }
 
 // ---------------------------------------------------------------------------
@@ -566,6 +581,7 @@ __device__ __forceinline__ double max3_skip_nan(double a, double b, double c) { 
 template <typename T, int KMAX> struct GreedyRow {
     T w[KMAX], g[KMAX], s[KMAX], d[KMAX], prr[KMAX], den[KMAX];   // den = eps + P(r, r) (greedycd.jl:121, :151)
     double rden[KMAX];                                              // 1 / den (Float32 rows only; dead code for Float64)
+    float r32[KMAX];                                                // RN(1 / den) in Float32 (greedy_div_fma; Float32 rows only)
     __device__ __forceinline__ void load(const SampleView<const T> &W, const SampleView<const T> &G, const T *P, int64_t ldp,
                                          int64_t i, int k, int km, int lane, T lambda, T epsT) {
 #pragma unroll
@@ -581,6 +597,7 @@ template <typename T, int KMAX> struct GreedyRow {
             prr[m] = ok ? P[(int64_t)c * ldp + c] : (T)1;
             den[m] = op_add(epsT, prr[m]);
             rden[m] = 1.0 / (double)den[m];
+            r32[m] = 1.0f / (float)den[m];
             greedy_sd(w[m], g[m], prr[m], den[m], rden[m], s[m], d[m]);
         }
     }
@@ -717,7 +734,7 @@ __device__ __forceinline__ long long greedy_sweep_row(SampleView<const T> Wold, 
 #pragma unroll
                 for (int m = 0; m < KMAX; ++m) {
                     row.g[m] = f32_add(row.g[m], f32_mul_s(sq, pq[m]));
-                    t[m] = f32_sub(row.w[m], greedy_div(row.g[m], row.den[m], row.rden[m]));
+                    t[m] = f32_sub(row.w[m], greedy_div_fma(row.g[m], row.den[m], row.r32[m]));
                 }
 #pragma unroll
                 for (int m = 0; m < KMAX; ++m) {

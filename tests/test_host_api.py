@@ -124,6 +124,56 @@ def test_greedy_division_identity():
     assert np.array_equal(q1.view(np.uint32), q2.view(np.uint32))
 
 
+def test_greedy_division_fma_form():
+    """csrc/cd.hpp::greedy_div_fma (round 6, the register form of GreedyCD's sweep): q0 = RN(g r), e = fma(-den, q0, g), q = fma(e, r, q0)
+    with r = RN(1 / den) is the correctly rounded g / den.  Every step evaluated in exact rational arithmetic and rounded once, as the
+    hardware's fused multiply-add does; operands: wide-range random ones, divisors whose significand is all ones (the worst case for a
+    reciprocal), small-integer pairs (what the bit-exact device tests feed), quotients next to a rounding boundary."""
+    import math
+    import struct
+    from fractions import Fraction
+
+    def rn32(fr):
+        if fr == 0:
+            return np.float32(0)
+        sgn = -1 if fr < 0 else 1
+        fr = abs(fr)
+        e = math.floor(math.log2(fr))
+        while Fraction(2) ** e > fr:
+            e -= 1
+        while Fraction(2) ** (e + 1) <= fr:
+            e += 1
+        scaled = fr / Fraction(2) ** (e - 23)
+        n = scaled.numerator // scaled.denominator
+        rem = scaled - n
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (n & 1)):
+            n += 1
+        return np.float32(sgn * float(n) * 2.0 ** (e - 23))
+
+    def check(g, den):
+        r = np.float32(np.float32(1) / den)
+        q0 = np.float32(g * r)
+        e = rn32(Fraction(float(g)) - Fraction(float(den)) * Fraction(float(q0)))
+        q = rn32(Fraction(float(q0)) + Fraction(float(e)) * Fraction(float(r)))
+        return q == rn32(Fraction(float(g)) / Fraction(float(den)))
+
+    rng = np.random.default_rng(3)
+    pairs = []
+    for _ in range(6000):
+        pairs.append((np.float32(rng.standard_normal() * 10 ** rng.uniform(-6, 6)), np.float32(abs(rng.standard_normal()) * 10 ** rng.uniform(-6, 6) + 1e-9)))
+    for m in range(2000):
+        den = np.frombuffer(struct.pack("<I", 0x3F800000 | (0x7FFFFF - (m % 64))), dtype=np.float32)[0]
+        pairs.append((np.float32(1 + m % 97) * np.float32(1 + 2.0 ** -(m % 23)), den))
+    for _ in range(4000):
+        pairs.append((np.float32(rng.integers(-(1 << 20), 1 << 20)), np.float32(rng.integers(1, 1 << 12))))
+    for _ in range(3000):      # g = the float nearest to (midpoint of two floats) * den
+        den = np.float32(1 + rng.random())
+        qf = np.float32(1 + rng.random())
+        pairs.append((np.float32((float(qf) + float(np.spacing(qf)) / 2) * float(den)), den))
+    bad = [(g, d) for g, d in pairs if g != 0 and not check(g, d)]
+    assert not bad, bad[:5]
+
+
 def test_alspgrad_gradient_option_validation():
     with pytest.raises(ValueError):
         nmfx.ALSPGrad(np.float32, gradient="fast")

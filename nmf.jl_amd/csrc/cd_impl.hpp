@@ -255,8 +255,19 @@ void Solver<T>::greedy_side(const char *tag, SampleView<const T> Zo, SampleView<
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&greedy_sweep_kernel<T, KMAX, FULL>), 256, 0) != hipSuccess || nb < 1) nb = 1;
                     return nb;
                 }();
-                const unsigned sweep_blocks = (unsigned)std::min<int64_t>(blocks, (int64_t)per_cu * num_cu);
-                hipLaunchKernelGGL((greedy_sweep_kernel<T, KMAX, FULL>), dim3(sweep_blocks), dim3(256), 0, stream, Zo, Zn, G, Pm, K, nsamples, (int)k,
+                // (NMFX_GREEDY_WGS_PER_CU=n, development switch: at most n resident workgroups per CU -- the occupancy probe of DESIGN.md
+                // section 3.2: is the sweep bound by latency, i.e. by how many waves interleave on a SIMD, or by instruction issue?)
+                int cap = per_cu;
+                size_t pad = 0;
+                if (const char *e = dev_env("NMFX_GREEDY_WGS_PER_CU")) {
+                    cap = std::max(1, std::min(per_cu, std::atoi(e)));
+                    if (cap < per_cu) {
+                        pad = (size_t)(160 * 1024 / (cap + 1) + 1024) / 256 * 256;   // dynamic LDS that lets `cap` workgroups onto a CU, not cap + 1
+                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_sweep_kernel<T, KMAX, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+                    }
+                }
+                const unsigned sweep_blocks = (unsigned)std::min<int64_t>(blocks, (int64_t)cap * num_cu);
+                hipLaunchKernelGGL((greedy_sweep_kernel<T, KMAX, FULL>), dim3(sweep_blocks), dim3(256), pad, stream, Zo, Zn, G, Pm, K, nsamples, (int)k,
                                    lambda, epsT, pinit, greedy_queue.p, &ctrl->inner_iters, done);
             };
             if ((k + 63) / 64 == KMAX) launch(std::true_type{});   // every slot live

@@ -257,14 +257,14 @@ void Solver<T>::greedy_side(const char *tag, SampleView<const T> Zo, SampleView<
                 }();
                 // (NMFX_GREEDY_WGS_PER_CU=n, development switch: at most n resident workgroups per CU -- the occupancy probe of DESIGN.md
                 // section 3.2: is the sweep bound by latency, i.e. by how many waves interleave on a SIMD, or by instruction issue?)
+                // (the probe's 15-iteration run has its optimum at SIX workgroups per CU, 811 / 1520 us against 821 / 1591 for the W / H
+                // sweeps; on the bench's standard run eight win again, 6.22-6.28 against 6.28-6.35 ms per iteration: the default stays all that fit)
                 int cap = per_cu;
+                if (const char *e = dev_env("NMFX_GREEDY_WGS_PER_CU")) cap = std::max(1, std::min(per_cu, std::atoi(e)));
                 size_t pad = 0;
-                if (const char *e = dev_env("NMFX_GREEDY_WGS_PER_CU")) {
-                    cap = std::max(1, std::min(per_cu, std::atoi(e)));
-                    if (cap < per_cu) {
-                        pad = (size_t)(160 * 1024 / (cap + 1) + 1024) / 256 * 256;   // dynamic LDS that lets `cap` workgroups onto a CU, not cap + 1
-                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_sweep_kernel<T, KMAX, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-                    }
+                if (cap < per_cu) {
+                    pad = (size_t)(160 * 1024 / (cap + 1) + 1024) / 256 * 256;   // dynamic LDS that lets `cap` workgroups onto a CU, not cap + 1
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_sweep_kernel<T, KMAX, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
                 }
                 const unsigned sweep_blocks = (unsigned)std::min<int64_t>(blocks, (int64_t)cap * num_cu);
                 hipLaunchKernelGGL((greedy_sweep_kernel<T, KMAX, FULL>), dim3(sweep_blocks), dim3(256), pad, stream, Zo, Zn, G, Pm, K, nsamples, (int)k,

@@ -34,190 +34,7 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// A: k x k leading block of a column-major matrix with leading dimension ld.  On a non-positive pivot sets
-// ctrl->status = posdef_status and ctrl->done = 1 (PosDefException of potrf!, src/utils.jl:68,78).
-// Dynamic LDS: 32*32 (diagonal block) + 32*kps (row panel; kps = max(32, kp - 32), kp = k rounded up to 32: the panel right of
-// the first diagonal block is the widest) elements of T (32 KiB for k = 256 in f32).
-// Per 32-column panel:  (1) wave 0 factors the diagonal block in registers (lane = column, v_readlane
-// broadcasts);  (2) the 32 x m row panel is staged through LDS with coalesced loads and solved one column per
-// thread;  (3) the trailing update A22 -= R'R runs on the matrix cores (MFMA 32x32x2 f32 / 16x16x4 f64) with
-// both operands read from the LDS panel -- the same [k][row] image the GEMM template calls KSTRIDED.
-// GPANEL: the row panel lives in a global scratch buffer (`gpanel`, 32 x kps elements, L2-resident) instead of LDS -- the fallback for
-// k beyond what one workgroup's LDS holds (k > 1248 in Float32, 608 in Float64): slower (every panel access is a global round trip,
-// ordered inside the workgroup by the barriers), but the reference's potrf! has no size limit either.
-template <typename T, bool GPANEL = false>
-__global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int k, Ctrl *ctrl, int posdef_status, T *gpanel = nullptr) {
-    if (ctrl != nullptr && ctrl->done) return;
-    // ProjectedALS runs this workgroup on a CU it shares with a block of the big product (projals_impl.hpp): its waves are the
-    // YOUNGER ones on their SIMDs and lose every issue arbitration against the GEMM's waves (4x slower than alone).  The
-    // factorisation is a latency chain that needs few issue slots, the GEMM a throughput kernel that has plenty: raise the wave
-    // priority (priority outranks age, MI355X_MICROARCH.md "Two waves per SIMD").
-    __builtin_amdgcn_s_setprio(3);
-    using M = Mfma<T>;
-    constexpr int NB = 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
-    const int kp0 = (k + 31) / 32 * 32;
-    const int kp = (kp0 > 64) ? kp0 - 32 : 32;          // row stride of the panel image (>= the widest panel, m <= k - 32)
-    T *U11 = reinterpret_cast<T *>(chol_smem);          // U11[i*NB + l] = U(jb+l, jb+i)  (transposed copy), l <= i
-    T *Rp = GPANEL ? gpanel : U11 + NB * NB;            // Rp[l*kp + c]  = U(jb+l, jb+nb+c), zero for c >= m
-    int *failp = reinterpret_cast<int *>(U11 + 1);      // (i = 0, l = 1) lies in the never-touched half of the transposed block
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
-    if (tid == 0) *failp = 0;
-    __syncthreads();
-#ifdef NMFX_POTRF_TIMING
-    extern __device__ long long nmfx_potrf_dbg[];
-#define PT(i) if (tid == 0) nmfx_potrf_dbg[(jb / NB) * 8 + (i)] = (long long)__builtin_readcyclecounter();
-#else
-#define PT(i)
-#endif
-    for (int jb = 0; jb < k; jb += NB) {
-        const int nb = (k - jb < NB) ? (k - jb) : NB;
-        const int m = k - jb - nb;
-        const int mp = (m + 31) / 32 * 32;
-        PT(0)
-        // stage the row panel (nb x m) into LDS, zero-padded to (NB x mp): thread <-> (l = tid%32, c = tid/32 + ...)
-        for (int e = tid; e < NB * mp; e += nt) {
-            const int l = e % NB, c = e / NB;
-            Rp[l * kp + c] = (l < nb && c < m) ? A[(jb + l) + (int64_t)(jb + nb + c) * ld] : (T)0;
-        }
-        if (wave == 0) {
-            // lane c holds column c of the diagonal block (rows 0..c); a partial block is padded with the identity so
-            // the 32 elimination steps below are branch-free straight-line code (entries with r > lane are never
-            // used: they may hold garbage).
-            T col[NB];
-#pragma unroll
-            for (int r = 0; r < NB; ++r) {
-                const bool in = (lane < nb) && (r <= lane);
-                col[r] = in ? A[(jb + r) + (int64_t)(jb + (in ? lane : 0)) * ld] : ((r == lane) ? (T)1 : (T)0);
-            }
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const T d = lane_bcast(col[j], j);
-                bad = bad || !(d > (T)0);
-                const T dj = nmfx_sqrt(d);
-                col[j] = (lane == j) ? dj : col[j] / dj;
-#pragma unroll
-                for (int r = j + 1; r < NB; ++r) col[r] -= lane_bcast(col[j], r) * col[j];
-            }
-#pragma unroll
-            for (int r = 0; r < NB; ++r)
-                if (lane < nb && r <= lane) {
-                    A[(jb + r) + (int64_t)(jb + lane) * ld] = col[r];
-                    U11[lane * NB + r] = col[r];       // TRANSPOSED: U11[i*NB + l] = U(jb+l, jb+i), l contiguous
-                }
-            if (bad && lane == 0) *failp = 1;
-            PT(1)
-        }
-        __syncthreads();
-        PT(2)
-        if (*failp) break;
-        // row panel: solve U11' R' = R in LDS, one column per thread (consecutive threads -> consecutive LDS words);
-        // the factor is read as 16-byte broadcast vectors along l (4 f32 / 2 f64 per ds_read_b128)
-        for (int c = tid; c < m; c += nt) {
-            using vec_t = typename M::vec_t;
-            constexpr int V = M::VEC;
-            T x[NB];
-#pragma unroll
-            for (int l = 0; l < NB; ++l) x[l] = Rp[l * kp + c];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                T s = x[i];
-#pragma unroll
-                for (int l0 = 0; l0 < i; l0 += V) {
-                    const vec_t u = *reinterpret_cast<const vec_t *>(U11 + i * NB + l0);
-#pragma unroll
-                    for (int q = 0; q < V; ++q)
-                        if (l0 + q < i) s -= u[q] * x[l0 + q];
-                }
-                const T dii = U11[i * NB + i];
-                x[i] = (i < nb) ? s / dii : s;
-            }
-#pragma unroll
-            for (int l = 0; l < NB; ++l) Rp[l * kp + c] = x[l];
-        }
-        __syncthreads();
-        PT(3)
-        // write the solved panel back (coalesced along l) ...
-        for (int e = tid; e < NB * m; e += nt) {
-            const int l = e % NB, c = e / NB;
-            if (l < nb) A[(jb + l) + (int64_t)(jb + nb + c) * ld] = Rp[l * kp + c];
-        }
-        // ... and update the trailing matrix on the matrix cores: for tiles (ti <= tj) of size MT x MT
-        //   A22(ri, cj) -= sum_l R'(l, ri) R'(l, cj).   MFMA lanes run along the matrix ROW index (contiguous in memory).
-        {
-            constexpr int MT = M::MT, KS = M::KS;
-            const int nt_t = mp / MT;
-            const int ntiles = nt_t * (nt_t + 1) / 2;
-            for (int tile = wave; tile < ntiles; tile += nwaves) {
-                // unrank (ti <= tj) from the linear index over the upper triangle, row by row of tj
-                int tj = 0, rem = tile;
-                while (rem > tj) { rem -= tj + 1; ++tj; }
-                const int ti = rem;
-                typename M::acc_t acc;
-#pragma unroll
-                for (int r = 0; r < M::NACC; ++r) acc[r] = (T)0;
-                const int ks = lane / MT, li = lane % MT;
-#pragma unroll
-                for (int kk = 0; kk < NB / KS; ++kk) {
-                    const T a = Rp[(kk * KS + ks) * kp + tj * MT + li];   // D rows <-> matrix column index cj
-                    const T b = Rp[(kk * KS + ks) * kp + ti * MT + li];   // D cols (lanes) <-> matrix row index ri
-                    acc = M::mma(a, b, acc);
-                }
-                const int ri = ti * MT + li;
-                // read-modify-write of the tile: all loads first, then all stores (A aliases itself, so an
-                // interleaved load/sub/store chain would serialise 16 global round trips)
-                T oldv[M::NACC];
-                T *base = A + (jb + nb + ri) + (int64_t)(jb + nb) * ld;
-#pragma unroll
-                for (int reg = 0; reg < M::NACC; ++reg) {
-                    int rr;
-                    if constexpr (sizeof(T) == 4) rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                    else rr = (lane >> 4) + 4 * reg;
-                    const int cj = tj * MT + rr;
-                    oldv[reg] = (ri <= cj && cj < m) ? base[(int64_t)cj * ld] : (T)0;
-                }
-#pragma unroll
-                for (int reg = 0; reg < M::NACC; ++reg) {
-                    int rr;
-                    if constexpr (sizeof(T) == 4) rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                    else rr = (lane >> 4) + 4 * reg;
-                    const int cj = tj * MT + rr;
-                    if (ri <= cj && cj < m) base[(int64_t)cj * ld] = oldv[reg] - acc[reg];
-                }
-            }
-        }
-        PT(4)
-        __syncthreads();
-        PT(5)
-    }
-    if (*failp && tid == 0 && ctrl != nullptr) {
-        ctrl->status = posdef_status;
-        ctrl->done = 1;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// potrf! with the trailing matrix RESIDENT IN REGISTERS (round 6).  potrf_upper_kernel above keeps A in global memory: every block step
-// re-reads its diagonal block and row panel from L2 and sends the trailing update through a global read-modify-write -- 20 us per step
-// at k = 256, of which the one-wave factorisation of the 32 x 32 diagonal block is 7-11 us and the one-column-per-thread panel solve
-// 5 us (profiles/r04_potrf_bench_standalone.log).  Here one workgroup of 8 waves owns the whole upper triangle as 32 x 32 blocks in MFMA
-// accumulator layout (block t = bj (bj + 1) / 2 + bi lives in slot t / 8 of wave t % 8: 36 blocks = 5 slots x 16 registers at k = 256
-// in Float32), global memory is read once and written once, and a block step is
-//   A  the owners of block row b write their blocks to LDS as column images (E[block][column][row]);
-//   B  ELIMINATION: wave w < NBLK - 1 - b takes the diagonal block in lanes 0-31 and panel block (b, b + 1 + w) in lanes 32-63, lane =
-//      column, the 32 rows of the column in registers, and runs the 32 right-looking steps  u_j = a_j / sqrt(a_jj),  a_r -= u_jr u_j  on
-//      all 64 lanes at once: the multipliers u_jr are v_readlane broadcasts from the diagonal lanes.  Every wave repeats the factorisation
-//      of the diagonal block (same instructions, same bits) and gets the triangular solve of ITS 32 panel columns out of the very same
-//      instruction stream -- the panel solve costs nothing beyond the diagonal block's dependency chain, instead of following it.
-//      The scaling multiplies by 1 / sqrt(a_jj) (one correctly rounded division per step, as OpenBLAS' potf2 / trsm kernels do) and the
-//      updates are fused multiply-adds.  The solved panel goes to LDS in the MFMA operand image Rp[l][column] and to global memory.
-//      An idle wave inverts the PREVIOUS diagonal block meanwhile (Dinv != nullptr: what trtri_diag_kernel computes, one launch less).
-//   C  trailing update: every wave subtracts R'R from the blocks it owns, 16 v_mfma_f32_32x32x2 per block, operands from Rp.
-// Two workgroup barriers per block step, no global round trip inside the loop.  adddiag! (src/utils.jl:15-24) is fused into the load.
-// 512 threads: the workgroup fits the half of a CU that ProjectedALS' short-grid products leave free (projals_impl.hpp).
-// NBLK = K / 32 at compile time (the accumulator slots are indexed statically): Float32 up to 8 (k <= 256), Float64 up to 4.
-// ---------------------------------------------------------------------------------------------
+// ---- helpers shared by the factorisation kernels (static loops, pins, the pivot, the 32-step elimination of one wave) ----
 template <typename F, int... I> __device__ __forceinline__ void strip_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
 }
@@ -253,6 +70,247 @@ __device__ __forceinline__ void pivot_sqrt_rcp(double d, double &s, double &r) {
     r = 1.0 / s;
 }
 
+// The 32 right-looking elimination steps on one wave: lanes 0-31 hold the columns of a 32 x 32 diagonal block (rows 0 .. lane meaningful),
+// lanes 32-63 the columns of a panel block to its right (or a copy of the diagonal block's), 32 rows each in col[].  On return the diagonal
+// lanes hold U_bb (upper triangle), the panel lanes inv(U_bb') times their columns, myrinv of lane j < 32 is 1 / U_bb(j, j), bad is set
+// on a non-positive pivot.  Shared by potrf_reg_kernel and potrf_upper_kernel.
+template <typename T> __device__ __forceinline__ void chol_eliminate32(T (&col)[32], int lane, T &myrinv, bool &bad) {
+    constexpr int NB = 32;
+    // Software-pipelined over the steps: the pivot of step j + 1 (broadcast, square root, reciprocal: a chain of ten dependent
+    // instructions with two transcendental latencies) is started as soon as column j + 1 has its update from step j, and runs
+    // under the 30 - j independent updates of the other columns.
+    T dj, rj;
+    {
+        const T d0 = lane_bcast(col[0], 0);
+        bad = !(d0 > (T)0);
+        pivot_sqrt_rcp(d0, dj, rj);
+    }
+    strip_static_for<NB>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        int lj = lane;
+        pin_v(lj);     // (keeps the 32 masks lane == j out of the scalar registers: hoisted out of the block loop they spill)
+        const bool diag = lj == j;
+        if (diag) myrinv = rj;
+        col[j] = diag ? dj : col[j] * rj;
+        if constexpr (j + 1 < NB) {
+            col[j + 1] = nmfx_fma(-lane_bcast(col[j], j + 1), col[j], col[j + 1]);
+            const T d = lane_bcast(col[j + 1], j + 1);
+            bad = bad || !(d > (T)0);
+            pivot_sqrt_rcp(d, dj, rj);
+        }
+        // (the broadcasts eight at a time into scalar registers BEFORE the updates that use them: a scalar written by v_readlane is
+        // not available to the next vector instruction for several cycles, and broadcast / update pairs issued back to back ran at
+        // ~16 cycles per pair)
+        strip_static_for<(NB - j - 2 > 0 ? (NB - j - 2 + 7) / 8 : 0)>([&](auto gc_) {
+            constexpr int r0 = j + 2 + 8 * decltype(gc_)::value;
+            T m[8];
+            strip_static_for<8>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if constexpr (r0 + u < NB) m[u] = lane_bcast(col[j], r0 + u); else m[u] = (T)0;
+            });
+            asm volatile("" : "+s"(m[0]), "+s"(m[1]), "+s"(m[2]), "+s"(m[3]), "+s"(m[4]), "+s"(m[5]), "+s"(m[6]), "+s"(m[7]));
+            strip_static_for<8>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if constexpr (r0 + u < NB) col[r0 + u] = nmfx_fma(-m[u], col[j], col[r0 + u]);
+            });
+        });
+        // RIGHT-looking as written: the updates of a step are independent of each other.  Left alone, instruction selection sinks
+        // every update to its use (left-looking: column r takes its r updates as one dependent chain right before its own pivot,
+        // with the multipliers of all earlier steps parked in -- and spilled from -- scalar registers); the empty asm statements
+        // pin each updated value, and the next pivot, to their step
+        pin_from<j + 2>(col);
+        pin_v(dj, rj);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// A: k x k leading block of a column-major matrix with leading dimension ld.  On a non-positive pivot sets
+// ctrl->status = posdef_status and ctrl->done = 1 (PosDefException of potrf!, src/utils.jl:68,78).
+// Dynamic LDS: 32*32 (diagonal block) + 32*kps (row panel; kps = max(32, kp - 32), kp = k rounded up to 32: the panel right of
+// the first diagonal block is the widest) elements of T (32 KiB for k = 256 in f32).
+// Per 32-column panel:  (1) wave 0 factors the diagonal block in registers (lane = column, v_readlane
+// broadcasts);  (2) the 32 x m row panel is staged through LDS with coalesced loads and solved one column per
+// thread;  (3) the trailing update A22 -= R'R runs on the matrix cores (MFMA 32x32x2 f32 / 16x16x4 f64) with
+// both operands read from the LDS panel -- the same [k][row] image the GEMM template calls KSTRIDED.
+// GPANEL: the row panel lives in a global scratch buffer (`gpanel`, 32 x kps elements, L2-resident) instead of LDS -- the fallback for
+// k beyond what one workgroup's LDS holds (k > 1248 in Float32, 608 in Float64): slower (every panel access is a global round trip,
+// ordered inside the workgroup by the barriers), but the reference's potrf! has no size limit either.
+template <typename T, bool GPANEL = false>
+__global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int k, Ctrl *ctrl, int posdef_status, T *gpanel = nullptr) {
+    if (ctrl != nullptr && ctrl->done) return;
+    // ProjectedALS runs this workgroup on a CU it shares with a block of the big product (projals_impl.hpp): its waves are the
+    // YOUNGER ones on their SIMDs and lose every issue arbitration against the GEMM's waves (4x slower than alone).  The
+    // factorisation is a latency chain that needs few issue slots, the GEMM a throughput kernel that has plenty: raise the wave
+    // priority (priority outranks age, MI355X_MICROARCH.md "Two waves per SIMD").
+    __builtin_amdgcn_s_setprio(3);
+    using M = Mfma<T>;
+    constexpr int NB = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char chol_smem[];
+    const int kp0 = (k + 31) / 32 * 32;
+    const int kp = (kp0 > 64) ? kp0 - 32 : 32;          // row stride of the panel image (>= the widest panel, m <= k - 32)
+    T *D11 = reinterpret_cast<T *>(chol_smem);          // D11[l*NB + c] = A(jb+l, jb+c) of the current diagonal block, identity-padded
+    T *Rp = GPANEL ? gpanel : D11 + NB * NB;            // Rp[l*kp + c]  = U(jb+l, jb+nb+c), zero for c >= m
+    // (the flag lives in element (l = 1, c = 0) of the diagonal block's image -- below the diagonal: staged as 0 every step, never used by
+    // the elimination -- so that the kernel needs no static LDS on top of the dynamic 160 KiB of the largest panel)
+    int *failp = reinterpret_cast<int *>(D11 + NB);
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+    if (tid == 0) *failp = 0;
+    __syncthreads();
+#ifdef NMFX_POTRF_TIMING
+    extern __device__ long long nmfx_potrf_dbg[];
+#define PT(i) if (tid == 0) nmfx_potrf_dbg[(jb / NB) * 8 + (i)] = (long long)__builtin_readcyclecounter();
+#else
+#define PT(i)
+#endif
+    for (int jb = 0; jb < k; jb += NB) {
+        const int nb = (k - jb < NB) ? (k - jb) : NB;
+        const int m = k - jb - nb;
+        const int mp = (m + 31) / 32 * 32;
+        PT(0)
+        // stage the row panel (nb x m) into LDS, zero-padded to (NB x mp): thread <-> (l = tid%32, c = tid/32 + ...), and the diagonal
+        // block, a partial one padded with the identity (the 32 elimination steps are branch-free straight-line code; entries below the
+        // diagonal are never used)
+        for (int e0 = tid; e0 < NB * mp; e0 += 8 * nt) {      // (eight trips' loads in flight, unconditional on clamped addresses)
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * nt, l = e % NB, c = e / NB;
+                const bool in = e < NB * mp && l < nb && c < m;
+                v[u] = A[in ? (jb + l) + (int64_t)(jb + nb + c) * ld : 0];
+                v[u] = in ? v[u] : (T)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * nt;
+                if (e < NB * mp) Rp[(e % NB) * kp + e / NB] = v[u];
+            }
+        }
+        for (int e = tid; e < NB * NB; e += nt) {
+            const int l = e % NB, c = e / NB;
+            const bool in = l < nb && c < nb && l <= c;
+            const T v = A[in ? (jb + l) + (int64_t)(jb + c) * ld : 0];
+            D11[l * NB + c] = in ? v : ((l == c) ? (T)1 : (T)0);
+        }
+        __syncthreads();
+        PT(1)
+        // Round 6: diagonal block and row panel in ONE instruction stream per wave (chol_eliminate32, as potrf_reg_kernel): wave w takes the
+        // diagonal block in lanes 0-31 and 32 panel columns in lanes 32-63 -- every wave repeats the diagonal block's 32 elimination steps
+        // (same instructions, same bits) and gets the triangular solve of its panel columns out of the same stream.  Before, one wave
+        // factored the diagonal block (17-27 k cycles), THEN the panel was solved one column per thread (12.6 k cycles).
+        {
+            const int ngroups = (mp > 0) ? mp / 32 : 1;
+            for (int pg = wave; pg < ngroups; pg += nwaves) {
+                const bool panel = (m > 0) && lane >= NB;
+                const int c = 32 * pg + lane - NB;
+                T col[NB];
+#pragma unroll
+                for (int l = 0; l < NB; ++l) col[l] = panel ? Rp[l * kp + (panel ? c : 0)] : D11[l * NB + (lane & 31)];
+                T myrinv = (T)0;
+                bool bad = false;
+                chol_eliminate32(col, lane, myrinv, bad);
+                if (panel) {
+#pragma unroll
+                    for (int l = 0; l < NB; ++l) Rp[l * kp + c] = col[l];
+                }
+                if (pg == 0 && lane < NB) {
+#pragma unroll
+                    for (int r = 0; r < NB; ++r)
+                        if (lane < nb && r <= lane) A[(jb + r) + (int64_t)(jb + lane) * ld] = col[r];
+                    if (bad && lane == 0) *failp = 1;
+                }
+            }
+        }
+        __syncthreads();
+        PT(2)
+        if (*failp) break;
+        PT(3)
+        // write the solved panel back (coalesced along l) ...
+        for (int e = tid; e < NB * m; e += nt) {
+            const int l = e % NB, c = e / NB;
+            if (l < nb) A[(jb + l) + (int64_t)(jb + nb + c) * ld] = Rp[l * kp + c];
+        }
+        // ... and update the trailing matrix on the matrix cores: for tiles (ti <= tj) of size MT x MT
+        //   A22(ri, cj) -= sum_l R'(l, ri) R'(l, cj).   MFMA lanes run along the matrix ROW index (contiguous in memory).
+        {
+            constexpr int MT = M::MT, KS = M::KS;
+            const int nt_t = mp / MT;
+            const int ntiles = nt_t * (nt_t + 1) / 2;
+            const int ks = lane / MT, li = lane % MT;
+            auto acc_row = [&](int reg) { return (sizeof(T) == 4) ? ((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) : ((lane >> 4) + 4 * reg); };
+            // (round 6) TWO tiles of a wave in flight -- the read-modify-write of a tile is a global round trip the wave has nothing
+            // else to do under -- and the loads of the old values UNCONDITIONAL on clamped addresses (under the per-lane triangle test
+            // every load was its own basic block and was waited for before the next one was issued); the test selects afterwards
+            for (int tile0 = wave; tile0 < ntiles; tile0 += 2 * nwaves) {
+                int tis[2], tjs[2];
+                bool live[2];
+                typename M::acc_t acc[2];
+                T oldv[2][M::NACC];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int tile = tile0 + h * nwaves;
+                    live[h] = tile < ntiles;
+                    // unrank (ti <= tj) from the linear index over the upper triangle, row by row of tj
+                    int tj = 0, rem = live[h] ? tile : 0;
+                    while (rem > tj) { rem -= tj + 1; ++tj; }
+                    tis[h] = rem; tjs[h] = tj;
+                    T *base = A + (jb + nb + tis[h] * MT + li) + (int64_t)(jb + nb) * ld;
+#pragma unroll
+                    for (int reg = 0; reg < M::NACC; ++reg) oldv[h][reg] = base[(int64_t)(tjs[h] * MT + acc_row(reg)) * ld];   // (inside the padded K x K buffer)
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r) acc[h][r] = (T)0;
+#pragma unroll
+                    for (int kk = 0; kk < NB / KS; ++kk) {
+                        const T a = Rp[(kk * KS + ks) * kp + tjs[h] * MT + li];   // D rows <-> matrix column index cj
+                        const T b = Rp[(kk * KS + ks) * kp + tis[h] * MT + li];   // D cols (lanes) <-> matrix row index ri
+                        acc[h] = M::mma(a, b, acc[h]);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ri = tis[h] * MT + li;
+                    T *base = A + (jb + nb + ri) + (int64_t)(jb + nb) * ld;
+#pragma unroll
+                    for (int reg = 0; reg < M::NACC; ++reg) {
+                        const int cj = tjs[h] * MT + acc_row(reg);
+                        if (live[h] && ri <= cj && cj < m) base[(int64_t)cj * ld] = oldv[h][reg] - acc[h][reg];
+                    }
+                }
+            }
+        }
+        PT(4)
+        __syncthreads();
+        PT(5)
+    }
+    if (*failp && tid == 0 && ctrl != nullptr) {
+        ctrl->status = posdef_status;
+        ctrl->done = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// potrf! with the trailing matrix RESIDENT IN REGISTERS (round 6).  potrf_upper_kernel above keeps A in global memory: every block step
+// re-reads its diagonal block and row panel from L2 and sends the trailing update through a global read-modify-write -- 20 us per step
+// at k = 256, of which the one-wave factorisation of the 32 x 32 diagonal block is 7-11 us and the one-column-per-thread panel solve
+// 5 us (profiles/r04_potrf_bench_standalone.log).  Here one workgroup of 8 waves owns the whole upper triangle as 32 x 32 blocks in MFMA
+// accumulator layout (block t = bj (bj + 1) / 2 + bi lives in slot t / 8 of wave t % 8: 36 blocks = 5 slots x 16 registers at k = 256
+// in Float32), global memory is read once and written once, and a block step is
+//   A  the owners of block row b write their blocks to LDS as column images (E[block][column][row]);
+//   B  ELIMINATION: wave w < NBLK - 1 - b takes the diagonal block in lanes 0-31 and panel block (b, b + 1 + w) in lanes 32-63, lane =
+//      column, the 32 rows of the column in registers, and runs the 32 right-looking steps  u_j = a_j / sqrt(a_jj),  a_r -= u_jr u_j  on
+//      all 64 lanes at once: the multipliers u_jr are v_readlane broadcasts from the diagonal lanes.  Every wave repeats the factorisation
+//      of the diagonal block (same instructions, same bits) and gets the triangular solve of ITS 32 panel columns out of the very same
+//      instruction stream -- the panel solve costs nothing beyond the diagonal block's dependency chain, instead of following it.
+//      The scaling multiplies by 1 / sqrt(a_jj) (one correctly rounded division per step, as OpenBLAS' potf2 / trsm kernels do) and the
+//      updates are fused multiply-adds.  The solved panel goes to LDS in the MFMA operand image Rp[l][column] and to global memory.
+//      An idle wave inverts the PREVIOUS diagonal block meanwhile (Dinv != nullptr: what trtri_diag_kernel computes, one launch less).
+//   C  trailing update: every wave subtracts R'R from the blocks it owns, 16 v_mfma_f32_32x32x2 per block, operands from Rp.
+// Two workgroup barriers per block step, no global round trip inside the loop.  adddiag! (src/utils.jl:15-24) is fused into the load.
+// 512 threads: the workgroup fits the half of a CU that ProjectedALS' short-grid products leave free (projals_impl.hpp).
+// NBLK = K / 32 at compile time (the accumulator slots are indexed statically): Float32 up to 8 (k <= 256), Float64 up to 4.
+// ---------------------------------------------------------------------------------------------
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also releases global memory, i.e. waits for every outstanding global
 // store of the wave (s_waitcnt vmcnt(0): a 1-2 us round trip); the factorisation's stores of finished parts of U are never read back
 // inside the kernel, so its barriers must not wait for them.
@@ -399,52 +457,7 @@ __global__ __launch_bounds__(512) void potrf_reg_kernel(T *A, int64_t ld, int k,
                 for (int u = 0; u < V; ++u) col[q * V + u] = v[u];
             }
             bool bad = false;
-            // Software-pipelined over the steps: the pivot of step j + 1 (broadcast, square root, reciprocal: a chain of ten dependent
-            // instructions with two transcendental latencies) is started as soon as column j + 1 has its update from step j, and runs
-            // under the 30 - j independent updates of the other columns.
-            T dj, rj;
-            {
-                const T d0 = lane_bcast(col[0], 0);
-                bad = !(d0 > (T)0);
-                pivot_sqrt_rcp(d0, dj, rj);
-            }
-            strip_static_for<NB>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                int lj = lane;
-                pin_v(lj);     // (keeps the 32 masks lane == j out of the scalar registers: hoisted out of the block loop they spill)
-                const bool diag = lj == j;
-                if (diag) myrinv = rj;
-                col[j] = diag ? dj : col[j] * rj;
-                if constexpr (j + 1 < NB) {
-                    col[j + 1] = nmfx_fma(-lane_bcast(col[j], j + 1), col[j], col[j + 1]);
-                    const T d = lane_bcast(col[j + 1], j + 1);
-                    bad = bad || !(d > (T)0);
-                    pivot_sqrt_rcp(d, dj, rj);
-                }
-                // (the broadcasts eight at a time into scalar registers BEFORE the updates that use them: a scalar written by v_readlane is
-                // not available to the next vector instruction for several cycles, and broadcast / update pairs issued back to back ran at
-                // ~16 cycles per pair)
-                strip_static_for<(NB - j - 2 > 0 ? (NB - j - 2 + 7) / 8 : 0)>([&](auto gc_) {
-                    constexpr int r0 = j + 2 + 8 * decltype(gc_)::value;
-                    T m[8];
-                    strip_static_for<8>([&](auto uc) {
-                        constexpr int u = decltype(uc)::value;
-                        if constexpr (r0 + u < NB) m[u] = lane_bcast(col[j], r0 + u); else m[u] = (T)0;
-                    });
-                    asm volatile("" : "+s"(m[0]), "+s"(m[1]), "+s"(m[2]), "+s"(m[3]), "+s"(m[4]), "+s"(m[5]), "+s"(m[6]), "+s"(m[7]));
-                    strip_static_for<8>([&](auto uc) {
-                        constexpr int u = decltype(uc)::value;
-                        if constexpr (r0 + u < NB) col[r0 + u] = nmfx_fma(-m[u], col[j], col[r0 + u]);
-                    });
-                });
-                // RIGHT-looking as written: the updates of a step are independent of each other.  Left alone, instruction selection sinks
-                // every update to its use (left-looking: column r takes its r updates as one dependent chain right before its own pivot,
-                // with the multipliers of all earlier steps parked in -- and spilled from -- scalar registers); the empty asm statements
-                // pin each updated value, and the next pivot, to their step
-                pin_from<j + 2>(col);
-                pin_v(dj, rj);
-                __builtin_amdgcn_sched_barrier(0);
-            });
+            chol_eliminate32(col, lane, myrinv, bad);
             if (nrem > 0 && lane >= NB) {
                 const int c = NB * wave + lane - NB;                      // column of the panel
 #pragma unroll

@@ -584,10 +584,15 @@ template <typename T, int KMAX> struct GreedyRow {
     float r32[KMAX];                                                // RN(1 / den) in Float32 (greedy_div_fma; Float32 rows only)
     __device__ __forceinline__ void load(const SampleView<const T> &W, const SampleView<const T> &G, const T *P, int64_t ldp,
                                          int64_t i, int k, int km, int lane, T lambda, T epsT) {
+        (void)km;
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
-            const int c = lane + 64 * m;
-            const bool ok = (m < km) && (c < k);
+            // Round 6: lane l owns the KMAX CONSECUTIVE components KMAX l .. KMAX l + KMAX - 1 (slot m <-> component KMAX l + m), not
+            // l, l + 64, ...: the row P(q, :) a step needs is then ONE 16-byte load per lane (KMAX = 4, Float32) instead of four 4-byte
+            // ones -- the address path of the CU (one instruction of 64 lanes at a time, whatever its width) is what the sweep's eight
+            // waves per SIMD queue for.  Which lane holds which component changes no arithmetic.
+            const int c = KMAX * lane + m;
+            const bool ok = c < k;
             w[m] = ok ? W.at(i, c) : (T)0;
             // a lane without a component (c >= k) carries G = +inf: S = max(0, 0 - inf) - 0 = 0 and D = -inf * 0 - ... = NaN, now and after
             // every step (its entries of P's rows are the zero padding: inf + S(q) * 0 = inf), and NaN is what the arg-max skips -- the
@@ -602,10 +607,11 @@ template <typename T, int KMAX> struct GreedyRow {
         }
     }
     // arg-max of D with the first index on ties: the VALUE by a DPP max reduction (2 operations per step instead of the 7 of a
-    // (value, index) reduction -- this sits on every greedy step's dependency chain), then the index from wave ballots: slots are
-    // visited in ascending m and a slot's lowest set lane is its smallest component index c = lane + 64 m
-    // FULL: ceil(k / 64) == KMAX -- every slot is live, and the lanes of the last one beyond k hold D = NaN (see load): no validity masks
+    // (value, index) reduction -- this sits on every greedy step's dependency chain), then the index from wave ballots: a slot's lowest
+    // set lane l gives its smallest component index c = KMAX l + m, and the smallest of the slots' candidates is the first index
+    // FULL: ceil(k / 64) == KMAX -- the lanes beyond k hold D = NaN (see load): no validity masks
     template <bool FULL = false> __device__ __forceinline__ void argmax(int k, int km, int lane, T &best, int &q) const {
+        (void)km;
         best = -INFINITY;
         if constexpr (FULL) {
             // `d > best ? d : best` from -inf == the NaN-skipping maximum (v_max: a NaN operand yields the other one), and v_max3 takes
@@ -616,28 +622,22 @@ template <typename T, int KMAX> struct GreedyRow {
         } else {
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
-                const int c = lane + 64 * m;
-                const bool take = ((m < km) && (c < k)) && (d[m] > best);
+                const int c = KMAX * lane + m;
+                const bool take = (c < k) && (d[m] > best);
                 best = take ? d[m] : best;
             }
         }
         best = wave_max_uniform(best);
-        if constexpr (FULL) {          // from the last slot down: the lowest slot with a hit wins (s_ff1 of an empty ballot is -1: unused)
-            q = 64 * (KMAX - 1) + (__ffsll((long long)__builtin_amdgcn_ballot_w64(d[KMAX - 1] == best)) - 1);
+        // (s_ff1 of an empty ballot is -1: KMAX * -1 + m as an unsigned number is larger than every index, so the unsigned minimum skips it)
+        unsigned qu = 0x7fffffffu;
 #pragma unroll
-            for (int m = KMAX - 2; m >= 0; --m) {
-                const unsigned long long hit = __builtin_amdgcn_ballot_w64(d[m] == best);
-                q = (hit != 0ull) ? 64 * m + (int)__builtin_ctzll(hit) : q;
-            }
-        } else {
-            q = 0x7fffffff;
-#pragma unroll
-            for (int m = 0; m < KMAX; ++m) {
-                const int c = lane + 64 * m;
-                const unsigned long long hit = __builtin_amdgcn_ballot_w64(((m < km) && (c < k)) && (d[m] == best));
-                if (hit != 0ull && q == 0x7fffffff) q = 64 * m + (int)__builtin_ctzll(hit);
-            }
+        for (int m = 0; m < KMAX; ++m) {
+            const int c = KMAX * lane + m;
+            const unsigned long long hit = FULL ? __builtin_amdgcn_ballot_w64(d[m] == best) : __builtin_amdgcn_ballot_w64((c < k) && (d[m] == best));
+            const unsigned cand = (unsigned)(KMAX * (__ffsll((long long)hit) - 1) + m);
+            qu = (cand < qu) ? cand : qu;
         }
+        q = (int)qu;
     }
 };
 
@@ -705,7 +705,7 @@ __device__ __forceinline__ long long greedy_sweep_row(SampleView<const T> Wold, 
     for (; step < max_steps; ++step) {
         if (dq < thresh) break;                       // wave-uniform (dq, q come out of wave_argmax as scalars)
         // S(q): owned by lane q % 64, slot q / 64
-        const int ql = q & 63, qm = q >> 6;
+        const int ql = q / KMAX, qm = q % KMAX;       // owner lane and slot of component q (KMAX is a compile-time constant)
         constexpr bool TAKE = FULL && KMAX <= 4 && std::is_same<T, float>::value;
         T sq;
         T pq[KMAX];
@@ -757,8 +757,8 @@ __device__ __forceinline__ long long greedy_sweep_row(SampleView<const T> Wold, 
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
                 wnew[m] = (m == qm && lane == ql) ? op_add(wnew[m], sq) : wnew[m];
-                if (m < km) {                             // uniform; lanes c in [k, K) of a live slot read P's zero padding: G stays put
-                    const T pq = fetch(q, m);
+                {                                         // (lanes beyond k take P(q, c) = 0: G stays put; KMAX lane + m may lie beyond the padded row)
+                    const T pq = (KMAX * lane + m < k) ? fetch(q, m) : (T)0;
                     row.g[m] = op_add(row.g[m], op_mul(sq, pq));
                     greedy_sd(row.w[m], row.g[m], row.prr[m], row.den[m], row.rden[m], row.s[m], row.d[m]);
                 }
@@ -768,8 +768,8 @@ __device__ __forceinline__ long long greedy_sweep_row(SampleView<const T> Wold, 
     }
 #pragma unroll
     for (int m = 0; m < KMAX; ++m) {
-        const int c = lane + 64 * m;
-        if ((m < km) && (c < k)) {
+        const int c = KMAX * lane + m;
+        if (c < k) {
             T v = op_add(row.w[m], wnew[m]);
             v = (v < (T)0) ? (T)0 : v;      // projectnn!
             Wout.at(i, c) = v;
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void greedy_sweep_kernel(SampleView<const T> W
     const int home = (int)(blockIdx.x & (GREEDY_NQ - 1));
     // (uniform row base + a 32-bit lane offset: the saddr form of the load, no 64-bit vector address arithmetic per step)
     const unsigned ldp32 = (unsigned)ldp, lane32 = (unsigned)lane;
-    auto fetch = [&](int q, int m) { const T *rowp = P + (unsigned)q * ldp32; return rowp[lane32 + 64u * (unsigned)m]; };
+    auto fetch = [&](int q, int m) { const T *rowp = P + (unsigned)q * ldp32; return rowp[(unsigned)KMAX * lane32 + (unsigned)m]; };
     long long steps = 0;
     for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < nsamples;
          i = (first_dyn < nsamples) ? greedy_next_row(queue, first_dyn, nsamples, home, lane) : nsamples) {

@@ -346,7 +346,7 @@ template <typename T>
 __device__ __forceinline__ void check_body(Ctrl *ctrl, const double *wstat, const double *hstat, int k, T tol, long long t, double *dev_out) {
     if (ctrl->done) return;
     __shared__ int first_bad;
-    __shared__ T wmax[4];
+    __shared__ T wmax[16];
     if (threadIdx.x == 0) first_bad = k;
     __syncthreads();
     for (int j = threadIdx.x; j < k; j += blockDim.x) {
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void col_stats_hfin_kernel(const T *Wn, const 
     }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void wfin_check_kernel(const double *wpart, int nchunks, int K, double *wstat, const double *hstat, Ctrl *ctrl, int k, T tol,
+__global__ __launch_bounds__(1024) void wfin_check_kernel(const double *wpart, int nchunks, int K, double *wstat, const double *hstat, Ctrl *ctrl, int k, T tol,
                                                          long long t, const int *done) {
     NMFX_DONE_GUARD(done);
     for (int e = threadIdx.x; e < 2 * K; e += blockDim.x) {

@@ -1253,7 +1253,8 @@ template <typename T> class Solver : public SolverBase {
         timed("stats_W_check", 0.0, 2.0 * P * K * sizeof(T), [&] {
             hipLaunchKernelGGL(col_stats_hfin_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wn, Wo, P, P, (int)K, stat_part_w.p,
                                o.update_H ? stat_part.p : (const double *)nullptr, h_stat_chunks, hstat.p, done);
-            hipLaunchKernelGGL(wfin_check_kernel<T>, dim3(1), dim3(256), 0, stream, stat_part_w.p, stat_chunks_w, (int)K, wstat.p,
+            // (a thread per output while 2K <= 1024: every partial of the block in flight at once, one round trip)
+            hipLaunchKernelGGL(wfin_check_kernel<T>, dim3(1), dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(256, 2 * K))), 0, stream, stat_part_w.p, stat_chunks_w, (int)K, wstat.p,
                                o.update_H ? hstat.p : (const double *)nullptr, ctrl, (int)k, (T)o.tol, t, done);
             HIP_TRY(hipGetLastError());
         });

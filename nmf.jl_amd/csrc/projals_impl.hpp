@@ -293,20 +293,19 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     const T *Wo = W[wcur].p;
     T *Wn = W[wcur ^ 1].p;
     if (under) {
+        // (H' for the transposed-image product first: in front of the fork, so that its 1024-block pass does not run beside the potrf's start)
+        const T *HtP = (xht_images && !rs) ? ht_for(Hp, done) : nullptr;
         gram_h_only(Hp, done);                                                 // :100 HH' of this rank's columns ...
         if (rs) timed("all_reduce_HHt", 0.0, (double)kk * sizeof(T), [&] { comm->all_reduce(gramH_p, kk, CT, false, stream); });   // ... summed
-        // (with XH' on the transposed images -- NMFX_PROJALS_XT=1 -- potri!'s product runs on the main stream behind XH': 10 us there,
-        // 156-252 us beside the product)
+        // (with XH' on the transposed images potri!'s product runs on the main stream behind XH': 13 us there, 156-252 us beside the product)
         potri_on_main = xht_images && !rs;
         factor_under(gramH_p, (T)o.lambda_w, "potrf_HHt", "trtri_HHt", true);  // :100 adddiag!, :102 potrf!, potri!, copytri!
         w_blocked = rs;
-        // (round 6, one GPU: XH' on the transposed images -- the contraction-contiguous kernel with its k-loop unrolled, as W'X runs.
-        // Round 5 measured this SLOWER: the chain beside it, 606 us of potrf + trtri + potri, fell behind the product.  With the
-        // register-resident potrf and nothing of the chain waiting for block slots any more the chain ends well inside the product)
-        // ... measured again with the pack off the chain and the memset gone: the product itself 983 -> 931 us, but trtri + potri beside the
-        // unrolled kernel take 166 + 210 instead of 89 + 155 us, the chain (952 us) ends after the product again and the iteration is
-        // SLOWER, 2.09-2.10 -> 2.14-2.17 ms.  Left off (NMFX_PROJALS_XT=1 to measure).
-        const T *HtP = (xht_images && !rs) ? ht_for(Hp, done) : nullptr;
+        // (round 6, one GPU: XH' on the transposed images -- the contraction-contiguous kernel with its k-loop unrolled, as W'X runs:
+        // 986 -> 931 us.  Round 5 measured the iteration SLOWER with it, and so did three attempts of this round -- until H's transposition
+        // pass moved in FRONT of the fork (above): issued behind it, its 1024 blocks ran beside the start of the potrf on the other stream
+        // and the chain lost more than the product gained.  With potri's product behind XH' on the main stream (13 us there, 156-252 beside
+        // the product) the chain under XH' is potrf + trtri, ~630 of the product's 931 us: 2.10-2.11 -> 2.06-2.07 ms per iteration.)
         short_grid = true;
         try { times_ht(X.p, Hp, false, done, false, HtP); } catch (...) { short_grid = false; w_blocked = false; throw; }   // :101 XH'
         short_grid = false;

@@ -1346,7 +1346,7 @@ template <typename T> class Solver : public SolverBase {
     // the products that share their CUs with the factorisation keep the k-loop unrolled by two when the factorisation is the short
     // register-resident one (launch_gemm_cfg); NMFX_CHOL_UNROLLED=0: the rolled loop as before (A/B)
     bool chol_unrolled = true;
-    bool xht_images = false;              // NMFX_PROJALS_XT=1 (development switch): ProjectedALS's XH' under the chain on the transposed images (measured slower twice)
+    bool xht_images = true;               // NMFX_PROJALS_XT=0 (development switch): ProjectedALS's XH' under the chain on the row-contiguous kernel (A/B)
     bool defer_pack = false;              // set around the H side's factor_under: spd_factor leaves the pack of the factor to the caller
     int spd_solve_left_potrs(const T *Tm, const T *B, T *out, bool clamp, const T *old, const int *done);
     void spd_solve_left(const T *Uinv, const T *B, T *Y, T *out, bool clamp, const int *done);

@@ -9,13 +9,13 @@ B="python bench.py --no-cpu-baseline --alg projals --steps 30 --warmup 10"
 : > "$O/projals.jsonl"
 for rep in 1 2 3; do
   $B --no-events >> "$O/projals.jsonl" 2>> "$O/err.log"
-  NMFX_PROJALS_XT=1 $B --no-events >> "$O/projals.jsonl" 2>> "$O/err.log"
+  NMFX_PROJALS_XT=0 $B --no-events >> "$O/projals.jsonl" 2>> "$O/err.log"
 done
 NMFX_CHOL_UNROLLED=0 $B --no-events >> "$O/projals.jsonl" 2>> "$O/err.log"
 $B --p 8192 --n 16384 --no-events >> "$O/projals.jsonl" 2>> "$O/err.log"
 NMFX_CHOL_UNDER_US=0 $B --p 8192 --n 16384 --no-events >> "$O/projals.jsonl" 2>> "$O/err.log"
 $B --all-events > "$O/projals_all_events.json" 2>> "$O/err.log"
-NMFX_PROJALS_XT=1 $B --all-events > "$O/projals_all_events_row_contiguous_xht.json" 2>> "$O/err.log"
+NMFX_PROJALS_XT=0 $B --all-events > "$O/projals_all_events_row_contiguous_xht.json" 2>> "$O/err.log"
 python - <<'PY'
 import json
 for l in open('gpurun_out/r06s/projals.jsonl'):

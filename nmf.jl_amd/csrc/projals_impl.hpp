@@ -294,11 +294,11 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     T *Wn = W[wcur ^ 1].p;
     if (under) {
         // (H' for the transposed-image product first: in front of the fork, so that its 1024-block pass does not run beside the potrf's start)
-        const T *HtP = (xht_images && !rs) ? ht_for(Hp, done) : nullptr;
+        const T *HtP = xht_images ? ht_for(Hp, done, /*sharded_too=*/true) : nullptr;   // (row-sharded step too: X' and H' of the rank's own columns)
         gram_h_only(Hp, done);                                                 // :100 HH' of this rank's columns ...
         if (rs) timed("all_reduce_HHt", 0.0, (double)kk * sizeof(T), [&] { comm->all_reduce(gramH_p, kk, CT, false, stream); });   // ... summed
         // (with XH' on the transposed images potri!'s product runs on the main stream behind XH': 13 us there, 156-252 us beside the product)
-        potri_on_main = xht_images && !rs;
+        potri_on_main = HtP != nullptr;
         factor_under(gramH_p, (T)o.lambda_w, "potrf_HHt", "trtri_HHt", true);  // :100 adddiag!, :102 potrf!, potri!, copytri!
         w_blocked = rs;
         // (round 6, one GPU: XH' on the transposed images -- the contraction-contiguous kernel with its k-loop unrolled, as W'X runs:
@@ -323,6 +323,10 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
                 comm->group_end();
             });
             HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
+            if (potri_on_main) {             // (potri! behind the product instead of beside it: see factor_under)
+                EpiStore<T> e1{invA, K, 0, nullptr};
+                gemm<KSTRIDED, KSTRIDED>("gemm_potri", Uinv, K, K, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * K * sizeof(T));
+            }
             const size_t chunk = (size_t)Pc * K * sizeof(T);
             T *mine = reinterpret_cast<T *>(ag_recv.p + (size_t)rank * chunk);
             EpiClampStore<T> e2{mine, Pc};                                     // :102 mul!, :103 projectnn!

@@ -524,8 +524,8 @@ template <typename T> class Solver : public SolverBase {
     // H' of `Hp` for ONE X*H' product on the transposed images (the coordinate-descent updaters: their sweeps write H, not H'), or
     // nullptr: not Float32, sharded, or no room for the images.  One 2 K N element transpose pass (~10 us at 16384 columns, k = 256)
     // buys the contraction-contiguous kernel for the product: 1043 -> ~930 us at 16384 x 16384 (round 6).
-    const T *ht_for(const T *Hp, const int *done) {
-        if (!want_xt() || sharded()) return nullptr;
+    const T *ht_for(const T *Hp, const int *done, bool sharded_too = false) {
+        if (!want_xt() || (sharded() && !sharded_too)) return nullptr;
         ensure_xt();
         if (!xt_valid) return nullptr;
         try {

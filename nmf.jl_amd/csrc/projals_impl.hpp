@@ -279,13 +279,15 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
         }
         if (subst) {   // :94 potrs! (two blocked triangular substitutions), :95 projectnn!, stop_condition's sums over H -- one launch
             const int chunks = spd_solve_left_potrs(invA, numH_p, Hn, true, Ho, done);
-            stats_h_finalize(chunks, done);
+            h_stat_chunks = chunks;
+            if (!stats_fuse_ok(o)) stats_h_finalize(chunks, done);   // (one GPU, nothing tracked: finalised by the launch behind the W update, as MultUpdate-MSE's)
         } else {   // :94 potrs! as Uinv * (Uinv' * B), :95 projectnn! and stop_condition's sums over H in the second product's epilogue
             EpiStore<T> e1{Y, K, 0, nullptr};
             gemm<KCONTIG, KCONTIG>("gemm_UinvtB", numH_p, K, N, Uinv, K, K, K, 1, true, e1, done, 2.0 * K * N * sizeof(T));
             EpiClampStats<T> e2{Ho, Hn, K, stat_part.p, (int)K};
             gemm<KCONTIG, KSTRIDED>("gemm_UinvY_clampH", Y, K, N, Uinv, K, K, K, 1, true, e2, done, 3.0 * K * N * sizeof(T));
-            stats_h_finalize(last_tiles_r, done);
+            h_stat_chunks = last_tiles_r;
+            if (!stats_fuse_ok(o)) stats_h_finalize(last_tiles_r, done);
         }
         hcur ^= 1;
     }
@@ -381,6 +383,8 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     if (rs) {
         stats_w_rows(Wn, Wo, done);
         gather_w_rows(Wn, true, done);
+    } else if (stats_fuse_ok(o)) {
+        stats_w_check_fused(Wn, Wo, o, t, done);
     } else {
         stats_w(Wn, Wo, done);
     }

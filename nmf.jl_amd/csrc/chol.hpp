@@ -19,6 +19,10 @@
 #include "kernels.hpp"
 
 namespace nmfx {
+#ifdef NMFX_POTRF_TIMING_LIB
+// (instrumented build only: scripts/r06_potrf_coresident_stamps.sh -- phase stamps of the last potrf_reg_kernel launch)
+static __device__ long long nmfx_potrf_dbg[2048];
+#endif
 
 __device__ __forceinline__ float nmfx_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double nmfx_sqrt(double x) { return sqrt(x); }
@@ -157,7 +161,9 @@ __global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int
     if (tid == 0) *failp = 0;
     __syncthreads();
 #ifdef NMFX_POTRF_TIMING
+#ifndef NMFX_POTRF_TIMING_LIB
     extern __device__ long long nmfx_potrf_dbg[];
+#endif
 #define PT(i) if (tid == 0) nmfx_potrf_dbg[(jb / NB) * 8 + (i)] = (long long)__builtin_readcyclecounter();
 #else
 #define PT(i)
@@ -360,7 +366,9 @@ template <typename T, int LDE> __device__ __forceinline__ void store_upper32(T *
 }
 
 #ifdef NMFX_POTRF_TIMING
+#ifndef NMFX_POTRF_TIMING_LIB
 extern __device__ long long nmfx_potrf_dbg[];
+#endif
 #endif
 template <typename T, int NBLK>
 __global__ __launch_bounds__(512) void potrf_reg_kernel(T *A, int64_t ld, int k, T lambda, T *Dinv, Ctrl *ctrl, int posdef_status) {
@@ -383,6 +391,9 @@ __global__ __launch_bounds__(512) void potrf_reg_kernel(T *A, int64_t ld, int k,
     const int li = lane % MT, ks = lane / MT;
     auto acc_row = [&](int reg) { return (sizeof(T) == 4) ? ((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) : ((lane >> 4) + 4 * reg); };
     if (tid == 0) *failp = 0;
+#ifdef NMFX_POTRF_TIMING
+    if (lane == 0) { nmfx_potrf_dbg[128 + wave] = (long long)__builtin_readcyclecounter(); nmfx_potrf_dbg[136 + wave] = (long long)wall_clock64(); }
+#endif
     // the blocks of this wave
     int sbi[NS], sbj[NS];
     typename M::acc_t acc[NS][SUB][SUB];

@@ -214,6 +214,13 @@ template <typename T> void Solver<T>::enqueue_projals(const nmfx_opts &o, long l
     // 0.53-0.62 ms at k = 256 -- seven times its stand-alone 77 us: it is bound by instruction issue, which the product's waves
     // contend for -- so under a short product the chain is the iteration (8192 x 4096: 0.58 ms under the 115 us products, 0.54 in
     // stream order); from ~200 us on hiding wins: solver.hpp, chol_under_min_us)
+    // (end of round 6 -- what the two paragraphs above describe is NOT co-residency.  A workgroup of another kernel executes nothing on a
+    // CU that holds a block of back-to-back MFMAs until that block has left, whatever its priority (scripts/kbench/coresident_probe.hip;
+    // cycle stamps inside potrf_reg_kernel: 67 us from its first to its last instruction in every form, the wait is in front of the
+    // first).  The short grid works because the LONE blocks of its chol_slots half-empty CUs run their half-length items with the matrix
+    // pipes to themselves and are gone at HALF TIME: from then on the chain has 8 empty CUs, one per XCD, and runs at stand-alone speed --
+    // potrf ends at half time + 66 us.  Hence the crossover below: a product whose half time is shorter than the chain cannot hide it.
+    // DESIGN.md section 3.2, item (6).)
     const double prod_us = 2.0 * (double)P * (double)N * (double)K / (sizeof(T) == 4 ? 150e6 : 70e6);
     const bool under = chol_slots > 0 && !use_bf16x3() && K % 128 == 0 && (!sharded() || rs) && prod_us >= chol_under_min_us;
     if (under) ensure_fstream();

@@ -150,6 +150,8 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = dev_env("NMFX_POTRS_STRIP")) strip_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_POTRF_REG")) potrf_reg_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_CHOL_UNROLLED")) chol_unrolled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_FUSE_GRAM")) fuse_gram = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_UNSPLIT")) unsplit_enabled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_PROJALS_XT")) xht_images = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_CHOL_UNDER_US")) chol_under_min_us = std::atof(e);
         if (const char *e = std::getenv("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
@@ -196,6 +198,10 @@ template <typename T> class Solver : public SolverBase {
         s_w = pick_splits((int)(P / 128) * (int)((K + 127) / 128), N);
         s_gw = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), P);
         s_gh = pick_splits((int)((K + 127) / 128) * (int)((K + 127) / 128), N);
+        if (const char *e = dev_env("NMFX_BIG_SPLITS")) {   // (experiment: force the split count of the two big products)
+            const int f = std::atoi(e);
+            if (f >= 1 && (P / BK) % f == 0 && (N / BK) % f == 0) { s_h = f; s_w = f; }
+        }
         // slab buffer = [ big-GEMM slabs | Gram slabs ]: the two live side by side so the update GEMM can consume
         // the un-reduced numerator slabs directly in its epilogue
         // (x PIPE_C: the pipelined exchange launches the big products per row super-chunk, each with its own split-K slabs)
@@ -1346,6 +1352,7 @@ template <typename T> class Solver : public SolverBase {
     // the products that share their CUs with the factorisation keep the k-loop unrolled by two when the factorisation is the short
     // register-resident one (launch_gemm_cfg); NMFX_CHOL_UNROLLED=0: the rolled loop as before (A/B)
     bool chol_unrolled = true;
+    bool unsplit_enabled = true;          // NMFX_UNSPLIT=0 (development switch): keep the 2-way split of the big products everywhere (solver_impl.hpp: iterate)
     bool xht_images = true;               // NMFX_PROJALS_XT=0 (development switch): ProjectedALS's XH' under the chain on the row-contiguous kernel (A/B)
     bool defer_pack = false;              // set around the H side's factor_under: spd_factor leaves the pack of the factor to the caller
     int spd_solve_left_potrs(const T *Tm, const T *B, T *out, bool clamp, const T *old, const int *done);

@@ -687,6 +687,23 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
         HIP_TRY(hipMemcpyAsync(trace_dev.p, nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    // One block per CU instead of two for the big products of MultUpdate-MSE and CoordinateDescent, where the output is
+    // exactly one 128 x 128 tile per CU (the headline shape): the 2-way split exists to put two blocks on a CU, but one block's waves
+    // keep the matrix pipe as busy as two blocks' do -- a ProjectedALS product of this shape runs 892-895 us unsplit on 256 blocks
+    // against 922-931 split, round 6 -- and there is one slab to write instead of two.  Measured (profiles/r06_big_products_unsplit_ab.jsonl):
+    // MultUpdate-MSE 1.9384-1.9481 -> 1.9292-1.9344 ms per iteration, CoordinateDescent 2.069-2.073 -> 2.051-2.052; MultUpdate-Div
+    // 4.046-4.053 -> 4.072-4.075 (SLOWER: left split); ProjectedALS keeps the short 2-per-CU grid its factorisations live under; GreedyCD
+    // keeps the split too (its per-iteration time is a function of the greedy trajectory, which moves with the last bits of the
+    // numerators: no like-for-like timing exists, and the step counts of earlier rounds' lines stay comparable).
+    struct SplitGuard {
+        Solver<T> &s; int sh, sw;
+        ~SplitGuard() { s.s_h = sh; s.s_w = sw; }
+    } split_guard{*this, s_h, s_w};
+    if (unsplit_enabled && !sharded() && !use_bf16x3() && sizeof(T) == 4 && K % 128 == 0 &&
+        (alg == NMFX_ALG_MULTMSE || alg == NMFX_ALG_CD)) {
+        if ((N / 128) * (K / 128) == num_cu && s_h == 2) s_h = 1;
+        if ((P / 128) * (K / 128) == num_cu && s_w == 2) s_w = 1;
+    }
     // MultUpdate-MSE, general path, Float32: the X*H' product on the transposed images (solver.hpp: Xt)
     ht_active = false;
     if (alg == NMFX_ALG_MULTMSE && !smallk_ok() && !pipelined() && want_xt()) {
@@ -749,6 +766,22 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     }
     HIP_TRY(hipMemcpyAsync(ctrl_host, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+#ifdef NMFX_POTRF_TIMING_LIB
+    if (alg == NMFX_ALG_PROJALS && sizeof(T) == 4 && std::getenv("NMFX_POTRF_DUMP") != nullptr) {   // instrumented build: phases of the last potrf, wave by wave
+        if (fstream != nullptr) HIP_TRY(hipStreamSynchronize(fstream));
+        static long long dbg[2048];
+        HIP_TRY(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(nmfx_potrf_dbg), sizeof dbg));
+        const long long t0 = dbg[256];
+        std::fprintf(stderr, "  entry (cycles before the first step's stamp), waves 0..7: %lld %lld %lld %lld %lld %lld %lld %lld\n", t0 - dbg[128], t0 - dbg[129], t0 - dbg[130], t0 - dbg[131],
+                     t0 - dbg[132], t0 - dbg[133], t0 - dbg[134], t0 - dbg[135]);
+        for (int b = 0; b <= 8; ++b)
+            for (int w = 0; w < 8; w += 7) {
+                const long long *d = dbg + 256 + (b * 8 + w) * 8;
+                std::fprintf(stderr, "  step %d wave %d: at %lld  A %lld  wait %lld  B %lld  wait %lld  C %lld (copy %lld)\n", b, w, d[0] - t0, d[1] - d[0], d[2] - d[1], d[3] - d[2],
+                             d[4] - d[3], d[5] - d[4], w == 7 ? d[6] - d[4] : 0);
+            }
+    }
+#endif
     const long long niters = ctrl_host->niters;
     // iterations enqueued after the stop were no-ops: the live buffers are those of iteration `niters`
     wcur = (int)((w0 + niters) & 1);

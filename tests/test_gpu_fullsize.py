@@ -259,3 +259,44 @@ def test_c3_updates_are_bit_identical_on_exact_inputs(built):
             assert np.array_equal(got.view(np.uint32), np.asfortranarray(expect).view(np.uint32)), float(np.max(np.abs(got - expect)))
             if not update_H:
                 assert np.array_equal(H, H0)
+
+
+@pytest.mark.parametrize("alg", ["multmse", "cd"])
+def test_c3_big_products_one_block_per_cu_against_the_split_form(built, monkeypatch, alg):
+    """C3 shape, f32: the output of each big product is exactly one 128 x 128 tile per CU, so MultUpdate-MSE and CoordinateDescent launch
+    them UNSPLIT (solver_impl.hpp: iterate) -- no smaller test shape takes that branch.  One iteration from the same start with the
+    branch on and off (NMFX_UNSPLIT=0, the 2-way split every other test shape runs and the oracle comparisons pin): the two differ by
+    the summation order of 16384-term Float32 sums only."""
+    X, W0, H0 = _c3_inputs()
+    T = np.float32
+    p, n = X.shape
+    k = W0.shape[1]
+    inst = {"multmse": nmfx.MultUpdate(T, obj="mse", maxiter=2, tol=1e-30), "cd": nmfx.CoordinateDescent(T, maxiter=2, tol=1e-30)}[alg]
+    monkeypatch.setenv("NMFX_DEV", "1")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NMFX_UNSPLIT", mode)
+        with nmfx.Context(T, p, n, k) as ctx:
+            ctx.set_X(X)
+            W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+            res, trace = ctx.solve(inst._alg(), nmfx.make_opts(T, maxiter=1, tol=1e-30, track_objective=True), W1, H1)
+            assert res.niters == 1
+            out[mode] = (W1, H1, trace[1])
+    (Wa, Ha, oa), (Wb, Hb, ob) = out["1"], out["0"]
+    dw = np.abs(Wa - Wb) / np.max(np.abs(Wb))
+    dh = np.abs(Ha - Hb) / np.max(np.abs(Hb))
+    assert abs(oa - ob) <= 1e-5 * abs(ob)
+    assert dw.max() <= 1e-4          # (7.5e-6 / 9.1e-6 measured)
+    if alg == "multmse":
+        assert dh.max() <= 1e-4      # (6.9e-6 measured)
+        return
+    # The coordinate sweep amplifies the last bits of its inputs (a Gauss-Seidel pass over k = 256 coordinates against the Gram of a
+    # random start: the two runs' W differ by 9e-6 and their H by up to 4 % in some columns -- and so do the Float64 sweeps evaluated from
+    # the two W), so each form is compared with a Float64 evaluation of the sweep from ITS OWN W, on 8 columns of H at random plus the 8
+    # in which the two runs differ most: 1.6e-4 (unsplit) and 7e-5 (split) measured.
+    J = np.concatenate([np.random.default_rng(1).choice(n, 8, replace=False), np.argsort(np.max(np.abs(Ha - Hb), axis=0))[-8:]])
+    for mode, (W1, H1, _) in out.items():
+        W64 = W1.astype(np.float64)
+        WtW, XtW = W64.T @ W64, X[:, J].astype(np.float64).T @ W64
+        Href = _cd_row_sweep(H0.T[J].astype(np.float64), WtW, XtW).T
+        assert np.max(np.abs(H1[:, J] - Href)) <= 1e-3 * np.max(np.abs(Href)), mode

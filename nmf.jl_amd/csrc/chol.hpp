@@ -317,14 +317,8 @@ __global__ __launch_bounds__(1024) void potrf_upper_kernel(T *A, int64_t ld, int
 // 512 threads: the workgroup fits the half of a CU that ProjectedALS' short-grid products leave free (projals_impl.hpp).
 // NBLK = K / 32 at compile time (the accumulator slots are indexed statically): Float32 up to 8 (k <= 256), Float64 up to 4.
 // ---------------------------------------------------------------------------------------------
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also releases global memory, i.e. waits for every outstanding global
-// store of the wave (s_waitcnt vmcnt(0): a 1-2 us round trip); the factorisation's stores of finished parts of U are never read back
-// inside the kernel, so its barriers must not wait for them.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
+// (lds_barrier(), kernels.hpp: the factorisation's stores of finished parts of U are never read back inside the kernel, so its barriers must
+// not wait for them)
 
 template <typename T, int NBLK> struct PotrfReg {
     static constexpr int NW = 8, NB = 32, NT = NBLK * (NBLK + 1) / 2, NS = (NT + NW - 1) / NW;

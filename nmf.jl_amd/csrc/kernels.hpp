@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace nmfx {
 
@@ -254,6 +255,129 @@ __global__ void finalize_partials_kernel(const double *partial, int nchunks, int
     if (lane == 0) out[e] = (OutT)s;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also releases global memory, i.e. waits for every outstanding global
+// access of the wave (s_waitcnt vmcnt(0): a 1-2 us round trip) -- stores that are never read back inside the kernel, or loads that were
+// requested several steps ahead on purpose.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// stop_condition's sums EXACTLY as the reference forms them, second form (round 6; the kernel below is the first, kept for A/B:
+// NMFX_STOP_SUMS_V1=1).  The work is 4 k chains of dependent T-precision adds, 2 per factor and component, each as long as the factor is
+// tall / wide: a wave issues one such add per 4 cycles whatever the number of active lanes, so a chain of 16384 terms cannot take less
+// than 27 us -- and nothing else may sit in that wave's instruction stream.  Hence: CH = 4 chains per workgroup (k / 4 workgroups per
+// factor, both factors in ONE launch: 128 workgroups at k = 256 instead of 16 + 16 one after the other); wave 0 runs the four `dev`
+// chains and wave 1 the four `sum` chains, lane <-> chain, and do nothing else -- a 16-byte LDS read per V terms, V dependent adds; waves
+// 2 .. 7 are producers: they fetch both factors with 16-byte loads TWO tiles ahead (the barrier between tiles orders LDS only, see
+// lds_barrier), form the terms (T)((a - b)^2), (T)((a + b)^2) and stage them [chain][element] in a double-buffered LDS image whose row
+// stride (TILE + 16 bytes) puts the four chains' reads on different banks.  Terms past `len` are staged as +0 (sums that are never -0).
+template <typename T, bool ALONG_ELEM, int CH>
+__device__ __forceinline__ void stop_sums_exact2_side(const T *An, const T *Ao, int64_t len, int64_t elem_stride, int64_t chain_stride, int nchains, int c0,
+                                                      double *out, T *lds) {
+    constexpr int V = 16 / (int)sizeof(T), TILE = 2048 / (int)sizeof(T), LD = TILE + V, NPROD = 384;
+    constexpr int UNITS = CH * TILE / V, ROUNDS = (UNITS + NPROD - 1) / NPROD;
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    static_assert(CH % V == 0 || ALONG_ELEM, "a 16-byte load along the chains covers V of them");
+    T *sd = lds, *ss = lds + 2 * CH * LD;          // sd[stage][chain][LD], ss likewise
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ptid = tid - 128;
+    const int64_t ntiles = (len + TILE - 1) / TILE;
+    vec_t ra[2][ROUNDS], rb[2][ROUNDS];
+    // unit e of a tile: ALONG_ELEM: chain e / (TILE / V), elements V (e % (TILE / V)) ..; else element e / (CH / V), chains V (e % (CH / V)) ..
+    auto unit = [&](int e, int &c, int &i) {
+        if constexpr (ALONG_ELEM) { c = e / (TILE / V); i = V * (e % (TILE / V)); }
+        else { i = e / (CH / V); c = V * (e % (CH / V)); }
+    };
+    auto fetch = [&](int64_t t, auto SET) {
+        constexpr int set = decltype(SET)::value;
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int e = ptid + NPROD * u;
+            int c, i;
+            unit(e < UNITS ? e : 0, c, i);
+            const int64_t ii = t * TILE + i;
+            const bool in = e < UNITS && t < ntiles && ii < len;       // (len is a multiple of V: a vector is inside or outside as a whole)
+            const int64_t off = in ? (int64_t)(c0 + c) * chain_stride + ii * elem_stride : 0;   // unconditional loads (a clamped address), selected afterwards
+            const vec_t a = *reinterpret_cast<const vec_t *>(An + off), b = *reinterpret_cast<const vec_t *>(Ao + off);
+#pragma unroll
+            for (int q = 0; q < V; ++q) { ra[set][u][q] = in ? a[q] : (T)0; rb[set][u][q] = in ? b[q] : (T)0; }
+        }
+    };
+    auto stash = [&](int stage, auto SET) {
+        constexpr int set = decltype(SET)::value;
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int e = ptid + NPROD * u;
+            if (e >= UNITS) continue;
+            int c, i;
+            unit(e, c, i);
+            vec_t td, ts;
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                const T d = ra[set][u][q] - rb[set][u][q], sp = ra[set][u][q] + rb[set][u][q];
+                td[q] = (T)(d * d);
+                ts[q] = (T)(sp * sp);
+            }
+            if constexpr (ALONG_ELEM) {
+                *reinterpret_cast<vec_t *>(sd + (stage * CH + c) * LD + i) = td;
+                *reinterpret_cast<vec_t *>(ss + (stage * CH + c) * LD + i) = ts;
+            } else {
+#pragma unroll
+                for (int q = 0; q < V; ++q) { sd[(stage * CH + c + q) * LD + i] = td[q]; ss[(stage * CH + c + q) * LD + i] = ts[q]; }
+            }
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const bool producer = wave >= 2;
+    if (producer) {
+        fetch(0, S0{});
+        fetch(1, S1{});
+        stash(0, S0{});
+        fetch(2, S0{});
+    }
+    lds_barrier();
+    T acc = (T)0;
+    const T *img = (wave == 0) ? sd : ss;
+    auto step = [&](int64_t t, auto SET_NEXT) {       // SET_NEXT: the register set that holds tile t + 1
+        const int stage = (int)(t & 1);
+        if (producer) {
+            stash(stage ^ 1, SET_NEXT);
+            fetch(t + 3, SET_NEXT);
+        } else if (lane < CH) {
+            const T *row = img + (stage * CH + lane) * LD;
+#pragma unroll 1
+            for (int i = 0; i < TILE; i += 8 * V) {
+                vec_t x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const vec_t *>(row + i + V * u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int q = 0; q < V; ++q) acc = acc + x[u][q];
+            }
+        }
+        lds_barrier();
+    };
+    int64_t t = 0;
+    for (; t + 1 < ntiles; t += 2) { step(t, S1{}); step(t + 1, S0{}); }
+    if (t < ntiles) step(t, S1{});
+    if (wave < 2 && lane < CH && c0 + lane < nchains) out[2 * (c0 + lane) + wave] = (double)acc;
+}
+
+// blocks [0, nbw): chains of W (elements contiguous); blocks [nbw, ...): chains of H (chains contiguous), if Hn != nullptr
+template <typename T>
+__global__ __launch_bounds__(512) void stop_sums_exact2_kernel(const T *Wn, const T *Wo, int64_t P, const T *Hn, const T *Ho, int64_t N, int64_t K, int nchains, int nbw,
+                                                               double *wout, double *hout, const int *done) {
+    NMFX_DONE_GUARD(done);
+    constexpr int CH = 4, V = 16 / (int)sizeof(T), TILE = 2048 / (int)sizeof(T), LD = TILE + V;
+    __shared__ __attribute__((aligned(16))) T lds[4 * CH * LD];
+    if ((int)blockIdx.x < nbw) stop_sums_exact2_side<T, true, CH>(Wn, Wo, P, (int64_t)1, P, nchains, (int)blockIdx.x * CH, wout, lds);
+    else stop_sums_exact2_side<T, false, CH>(Hn, Ho, N, K, (int64_t)1, nchains, ((int)blockIdx.x - nbw) * CH, hout, lds);
+}
+
+// (first form)
 // stop_condition's sums EXACTLY as the reference forms them (src/common.jl:95-104; nmfx_opts.stop_sums = 1): per component j
 //     dev_w += (W[i,j] - preW[i,j])^2,  sum_w += (W[i,j] + preW[i,j])^2   for i in index order, accumulated in T
 // and the same over row j of H.  One thread per chain pair: the adds are a dependent chain by definition.

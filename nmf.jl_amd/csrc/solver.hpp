@@ -152,6 +152,7 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = dev_env("NMFX_CHOL_UNROLLED")) chol_unrolled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_FUSE_GRAM")) fuse_gram = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_UNSPLIT")) unsplit_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_STOP_SUMS_V1")) stop_sums_v1 = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_PROJALS_XT")) xht_images = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_CHOL_UNDER_US")) chol_under_min_us = std::atof(e);
         if (const char *e = std::getenv("NMFX_XT")) xt_enabled = std::atoi(e) != 0;
@@ -1352,6 +1353,7 @@ template <typename T> class Solver : public SolverBase {
     // the products that share their CUs with the factorisation keep the k-loop unrolled by two when the factorisation is the short
     // register-resident one (launch_gemm_cfg); NMFX_CHOL_UNROLLED=0: the rolled loop as before (A/B)
     bool chol_unrolled = true;
+    bool stop_sums_v1 = false;            // NMFX_STOP_SUMS_V1=1 (development switch): the first form of the exact stop sums (16 chains per workgroup, a launch per factor)
     bool unsplit_enabled = true;          // NMFX_UNSPLIT=0 (development switch): keep the 2-way split of the big products everywhere (solver_impl.hpp: iterate)
     bool xht_images = true;               // NMFX_PROJALS_XT=0 (development switch): ProjectedALS's XH' under the chain on the row-contiguous kernel (A/B)
     bool defer_pack = false;              // set around the H side's factor_under: spd_factor leaves the pack of the factor to the caller
@@ -1388,11 +1390,18 @@ template <typename T> class Solver : public SolverBase {
             // the reference's sequential T-precision sums (nmfx_opts.stop_sums): the factors of iteration t against those of t - 1 (the
             // ping-pong partners), overwriting the tree sums the update launches left in wstat / hstat
             w_sync(done_flag());
+            if (!stop_sums_v1) {   // both factors' chains in one launch, 4 per workgroup (kernels.hpp: stop_sums_exact2_kernel)
+                const int nbw = (int)((k + 3) / 4);
+                hipLaunchKernelGGL((stop_sums_exact2_kernel<T>), dim3((unsigned)(o.update_H ? 2 * nbw : nbw)), dim3(512), 0, stream, W[wcur].p, W[wcur ^ 1].p, P,
+                                   o.update_H ? H[hcur].p : (const T *)nullptr, o.update_H ? H[hcur ^ 1].p : (const T *)nullptr, N, K, (int)k, nbw, wstat.p,
+                                   o.update_H ? hstat.p : (double *)nullptr, done_flag());
+            } else {
             hipLaunchKernelGGL((stop_sums_exact_kernel<T, true>), dim3((unsigned)((k + 15) / 16)), dim3(256), 0, stream, W[wcur].p, W[wcur ^ 1].p, P, (int64_t)1, P, (int)k, wstat.p,
                                done_flag());
             if (o.update_H)
                 hipLaunchKernelGGL((stop_sums_exact_kernel<T, false>), dim3((unsigned)((k + 15) / 16)), dim3(256), 0, stream, H[hcur].p, H[hcur ^ 1].p, N, K, (int64_t)1, (int)k,
                                    hstat.p, done_flag());
+            }
             HIP_TRY(hipGetLastError());
             check_fused = false;
         }

@@ -124,7 +124,7 @@ typedef struct {
      * tree order, inside the update launches (free; differs from the reference's totals by <= ~eps(T) sqrt(length) relative, so the
      * decision can differ only when an iteration's relative change sits that close to tol).  1: the reference's own arithmetic -- every
      * sum accumulated SEQUENTIALLY in T, one chain per component, in index order -- by a pass of its own after each iteration
-     * (measured +0.07 ms per iteration at 16384 x 16384, k = 256, Float32 since round 6 -- 0.44 before: one dependent add per element and
+     * (measured +0.08-0.09 ms per iteration at 16384 x 16384, k = 256, Float32 since round 6 -- 0.42 before: one dependent add per element and
      * chain, a wave per kind of sum that does nothing else, k / 4 workgroups per factor in one launch); `niters`,
      * `converged` and the relchange column are then the
      * reference's bit for bit whenever W and H are.  One GPU only (the chains would have to run through the ranks in turn). */

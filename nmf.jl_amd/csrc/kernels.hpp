@@ -267,16 +267,21 @@ __device__ __forceinline__ void lds_barrier() {
 // stop_condition's sums EXACTLY as the reference forms them, second form (round 6; the kernel below is the first, kept for A/B:
 // NMFX_STOP_SUMS_V1=1).  The work is 4 k chains of dependent T-precision adds, 2 per factor and component, each as long as the factor is
 // tall / wide: a wave issues one such add per 4 cycles whatever the number of active lanes, so a chain of 16384 terms cannot take less
-// than 27 us -- and nothing else may sit in that wave's instruction stream.  Hence: CH = 4 chains per workgroup (k / 4 workgroups per
+// than 27 us (a lone wave in fact issues one instruction per ~5.3 cycles: 36 us) -- and nothing else may sit in that wave's instruction stream.  Hence: CH = 4 chains per workgroup (k / 4 workgroups per
 // factor, both factors in ONE launch: 128 workgroups at k = 256 instead of 16 + 16 one after the other); wave 0 runs the four `dev`
 // chains and wave 1 the four `sum` chains, lane <-> chain, and do nothing else -- a 16-byte LDS read per V terms, V dependent adds; waves
 // 2 .. 7 are producers: they fetch both factors with 16-byte loads TWO tiles ahead (the barrier between tiles orders LDS only, see
 // lds_barrier), form the terms (T)((a - b)^2), (T)((a + b)^2) and stage them [chain][element] in a double-buffered LDS image whose row
 // stride (TILE + 16 bytes) puts the four chains' reads on different banks.  Terms past `len` are staged as +0 (sums that are never -0).
+// (tile = 2 KiB of terms per chain and kind of sum; 8 KiB tiles -- 131 KB of LDS, 244 registers -- measured the same 95-100 us: the kernel is
+// paced by the chain waves' instruction issue, ~2.2 ns per instruction of a lone wave whatever it is (profiles/r04_valu_rate_probe.log),
+// at 1.5 instructions per term: the add, a quarter of a 16-byte LDS read and of its s_waitcnt)
+constexpr int STOP_SUMS_CH = 4, STOP_SUMS_TILE_BYTES = 2048;
+template <typename T> constexpr size_t stop_sums_exact2_lds() { return (size_t)4 * STOP_SUMS_CH * (STOP_SUMS_TILE_BYTES / sizeof(T) + 16 / sizeof(T)) * sizeof(T); }
 template <typename T, bool ALONG_ELEM, int CH>
 __device__ __forceinline__ void stop_sums_exact2_side(const T *An, const T *Ao, int64_t len, int64_t elem_stride, int64_t chain_stride, int nchains, int c0,
                                                       double *out, T *lds) {
-    constexpr int V = 16 / (int)sizeof(T), TILE = 2048 / (int)sizeof(T), LD = TILE + V, NPROD = 384;
+    constexpr int V = 16 / (int)sizeof(T), TILE = STOP_SUMS_TILE_BYTES / (int)sizeof(T), LD = TILE + V, NPROD = 384;
     constexpr int UNITS = CH * TILE / V, ROUNDS = (UNITS + NPROD - 1) / NPROD;
     typedef T vec_t __attribute__((ext_vector_type(V)));
     static_assert(CH % V == 0 || ALONG_ELEM, "a 16-byte load along the chains covers V of them");
@@ -284,6 +289,7 @@ __device__ __forceinline__ void stop_sums_exact2_side(const T *An, const T *Ao, 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ptid = tid - 128;
     const int64_t ntiles = (len + TILE - 1) / TILE;
     vec_t ra[2][ROUNDS], rb[2][ROUNDS];
+    bool rin[2][ROUNDS];
     // unit e of a tile: ALONG_ELEM: chain e / (TILE / V), elements V (e % (TILE / V)) ..; else element e / (CH / V), chains V (e % (CH / V)) ..
     auto unit = [&](int e, int &c, int &i) {
         if constexpr (ALONG_ELEM) { c = e / (TILE / V); i = V * (e % (TILE / V)); }
@@ -299,9 +305,10 @@ __device__ __forceinline__ void stop_sums_exact2_side(const T *An, const T *Ao, 
             const int64_t ii = t * TILE + i;
             const bool in = e < UNITS && t < ntiles && ii < len;       // (len is a multiple of V: a vector is inside or outside as a whole)
             const int64_t off = in ? (int64_t)(c0 + c) * chain_stride + ii * elem_stride : 0;   // unconditional loads (a clamped address), selected afterwards
-            const vec_t a = *reinterpret_cast<const vec_t *>(An + off), b = *reinterpret_cast<const vec_t *>(Ao + off);
-#pragma unroll
-            for (int q = 0; q < V; ++q) { ra[set][u][q] = in ? a[q] : (T)0; rb[set][u][q] = in ? b[q] : (T)0; }
+            // (the select waits for the data: it happens in stash(), two tiles later -- done here it turned the prefetch into a load-and-wait)
+            ra[set][u] = *reinterpret_cast<const vec_t *>(An + off);
+            rb[set][u] = *reinterpret_cast<const vec_t *>(Ao + off);
+            rin[set][u] = in;
         }
     };
     auto stash = [&](int stage, auto SET) {
@@ -315,7 +322,8 @@ __device__ __forceinline__ void stop_sums_exact2_side(const T *An, const T *Ao, 
             vec_t td, ts;
 #pragma unroll
             for (int q = 0; q < V; ++q) {
-                const T d = ra[set][u][q] - rb[set][u][q], sp = ra[set][u][q] + rb[set][u][q];
+                const T a = rin[set][u] ? ra[set][u][q] : (T)0, b = rin[set][u] ? rb[set][u][q] : (T)0;
+                const T d = a - b, sp = a + b;
                 td[q] = (T)(d * d);
                 ts[q] = (T)(sp * sp);
             }
@@ -346,16 +354,23 @@ __device__ __forceinline__ void stop_sums_exact2_side(const T *An, const T *Ao, 
             stash(stage ^ 1, SET_NEXT);
             fetch(t + 3, SET_NEXT);
         } else if (lane < CH) {
+            // (the reads of group g + 1 are requested before the adds of group g: read-then-add exposed the ~130 cycles of an LDS round trip
+            // once per 8 reads -- as long as the 8 V dependent adds they feed)
             const T *row = img + (stage * CH + lane) * LD;
-#pragma unroll 1
-            for (int i = 0; i < TILE; i += 8 * V) {
-                vec_t x[8];
+            constexpr int NG = TILE / (8 * V);
+            vec_t x[2][8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const vec_t *>(row + i + V * u);
+            for (int u = 0; u < 8; ++u) x[0][u] = *reinterpret_cast<const vec_t *>(row + V * u);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[(g + 1) & 1][u] = *reinterpret_cast<const vec_t *>(row + (g + 1) * 8 * V + V * u);
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
 #pragma unroll
-                    for (int q = 0; q < V; ++q) acc = acc + x[u][q];
+                    for (int q = 0; q < V; ++q) acc = acc + x[g & 1][u][q];
             }
         }
         lds_barrier();
@@ -371,10 +386,18 @@ template <typename T>
 __global__ __launch_bounds__(512) void stop_sums_exact2_kernel(const T *Wn, const T *Wo, int64_t P, const T *Hn, const T *Ho, int64_t N, int64_t K, int nchains, int nbw,
                                                                double *wout, double *hout, const int *done) {
     NMFX_DONE_GUARD(done);
-    constexpr int CH = 4, V = 16 / (int)sizeof(T), TILE = 2048 / (int)sizeof(T), LD = TILE + V;
-    __shared__ __attribute__((aligned(16))) T lds[4 * CH * LD];
+    constexpr int CH = STOP_SUMS_CH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char stop_sums_smem[];
+    T *lds = reinterpret_cast<T *>(stop_sums_smem);
     if ((int)blockIdx.x < nbw) stop_sums_exact2_side<T, true, CH>(Wn, Wo, P, (int64_t)1, P, nchains, (int)blockIdx.x * CH, wout, lds);
-    else stop_sums_exact2_side<T, false, CH>(Hn, Ho, N, K, (int64_t)1, nchains, ((int)blockIdx.x - nbw) * CH, hout, lds);
+    else {
+        // 128 / sizeof(T) adjacent chains of H share every 128-byte line, i.e. 8 (Float32) or 4 (Float64) workgroups: give those to ONE XCD
+        // (workgroup b runs on XCD b % 8, each with an L2 of its own) -- dealt round-robin, every XCD fetched every line of both factors
+        int hb = (int)blockIdx.x - nbw;
+        const int nhb = (int)gridDim.x - nbw;
+        if ((nhb & 7) == 0) hb = (hb & 7) * (nhb >> 3) + (hb >> 3);
+        stop_sums_exact2_side<T, false, CH>(Hn, Ho, N, K, (int64_t)1, nchains, hb * CH, hout, lds);
+    }
 }
 
 // (first form)

@@ -1267,7 +1267,11 @@ template <typename T> class Solver : public SolverBase {
         });
         check_fused = true;
     }
+    // (nmfx_opts.stop_sums = 1: the pass of enqueue_check overwrites wstat / hstat with the sequential sums -- the stand-alone tree-sum
+    // passes are skipped; partials that come out of an update's epilogue are simply not finalised)
+    bool skip_tree_stats = false;
     void stats_w(const T *Wn, const T *Wo, const int *done) {
+        if (skip_tree_stats) return;
         timed("stats_W", 0.0, 2.0 * P * K * sizeof(T), [&] {
             hipLaunchKernelGGL(col_stats_kernel<T>, dim3(stat_chunks_w, (unsigned)K), dim3(256), 0, stream, Wn, Wo, P, P,
                                (int)K, stat_part.p, done);
@@ -1278,6 +1282,7 @@ template <typename T> class Solver : public SolverBase {
     }
     // H statistics whose per-r-tile partials were produced by the update GEMM's epilogue (EpiMultUpdate<T,1>)
     void stats_h_finalize(int chunks, const int *done) {
+        if (skip_tree_stats) return;
         timed("stats_H", 0.0, (double)chunks * 2 * K * sizeof(double), [&] {
             hipLaunchKernelGGL(finalize_partials_kernel<double>, dim3((unsigned)((2 * K + 3) / 4)), dim3(256), 0, stream,
                                stat_part.p, chunks, (int)(2 * K), (int)(2 * K), hstat.p, done);
@@ -1285,6 +1290,7 @@ template <typename T> class Solver : public SolverBase {
         });
     }
     void stats_h(const T *Hn, const T *Ho, const int *done) {
+        if (skip_tree_stats) return;
         timed("stats_H", 0.0, 2.0 * K * N * sizeof(T), [&] {
             hipLaunchKernelGGL(row_stats_kernel<T>, dim3(stat_chunks_h), dim3(256), 0, stream, Hn, Ho, N, K, (int)K,
                                stat_part.p, done);
@@ -1392,7 +1398,8 @@ template <typename T> class Solver : public SolverBase {
             w_sync(done_flag());
             if (!stop_sums_v1) {   // both factors' chains in one launch, 4 per workgroup (kernels.hpp: stop_sums_exact2_kernel)
                 const int nbw = (int)((k + 3) / 4);
-                hipLaunchKernelGGL((stop_sums_exact2_kernel<T>), dim3((unsigned)(o.update_H ? 2 * nbw : nbw)), dim3(512), 0, stream, W[wcur].p, W[wcur ^ 1].p, P,
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&stop_sums_exact2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stop_sums_exact2_lds<T>()));
+                hipLaunchKernelGGL((stop_sums_exact2_kernel<T>), dim3((unsigned)(o.update_H ? 2 * nbw : nbw)), dim3(512), stop_sums_exact2_lds<T>(), stream, W[wcur].p, W[wcur ^ 1].p, P,
                                    o.update_H ? H[hcur].p : (const T *)nullptr, o.update_H ? H[hcur ^ 1].p : (const T *)nullptr, N, K, (int)k, nbw, wstat.p,
                                    o.update_H ? hstat.p : (double *)nullptr, done_flag());
             } else {

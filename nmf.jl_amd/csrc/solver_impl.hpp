@@ -697,8 +697,9 @@ template <typename T> void Solver<T>::iterate(int alg, const nmfx_opts &o, nmfx_
     // numerators: no like-for-like timing exists, and the step counts of earlier rounds' lines stay comparable).
     struct SplitGuard {
         Solver<T> &s; int sh, sw;
-        ~SplitGuard() { s.s_h = sh; s.s_w = sw; }
+        ~SplitGuard() { s.s_h = sh; s.s_w = sw; s.skip_tree_stats = false; }
     } split_guard{*this, s_h, s_w};
+    skip_tree_stats = o.stop_sums != 0;   // (one GPU only: checked above)
     if (unsplit_enabled && !sharded() && !use_bf16x3() && sizeof(T) == 4 && K % 128 == 0 &&
         (alg == NMFX_ALG_MULTMSE || alg == NMFX_ALG_CD)) {
         if ((N / 128) * (K / 128) == num_cu && s_h == 2) s_h = 1;

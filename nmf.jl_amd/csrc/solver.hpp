@@ -1010,12 +1010,19 @@ template <typename T> class Solver : public SolverBase {
             const int tt = (int)((K / 128) * (K / 128));
             const int per = tail_piece(tiles * s_h, tt, (int)(P / BK));
             const int pieces = (int)((P / BK + per - 1) / per);
-            EpiStore<T> e{reg, K, h_stride, nullptr};
+            // (an unsplit product whose consumer wants the combined numerator stores it where the combine would have copied it)
+            const bool straight = s_h == 1 && !keep_slabs;
+            EpiStore<T> e{straight ? numH_p : reg, K, h_stride, nullptr};
             e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = (int64_t)K * K; e.r_off = N; e.c_off = 0;
             Seg sg;
             sg.A2 = Wp; sg.lda2 = P; sg.r_split = N; sg.tail_tiles = (int)(K / 128);
             gemm<KCONTIG, KCONTIG>("gemm_WtX", Bmat, P, N, Wp, P, K, P, s_h, true, e, done,
                                    (double)(P * N + 2 * P * K) * sizeof(T), sg, 2.0 * K * K * P);
+            if (straight) {
+                reduce_slabs_from("reduce_WtW", gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
+                h_in_slabs = false;
+                return;
+            }
             if (h_reduce_pair && (!keep_slabs || h_nslab > 2)) {   // both combines in one launch
                 reduce_pair("reduce_WtX_WtW", numH_p, reg, h_stride, h_nslab, h_stride, gramW_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces,
                             (int64_t)K * K, done);
@@ -1172,10 +1179,18 @@ template <typename T> class Solver : public SolverBase {
                 if (const char *ev = dev_env("NMFX_P2P_STAGE16")) e.stage16 = std::atoi(ev) != 0;   // 16-byte staged peer stores (gemm_mfma.hpp: measured slower on the stand-in)
                 big(sw, e, (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
             } else {
-            EpiStore<T> e{direct ? numW_p : reg, direct ? Pc : P, w_stride, nullptr};
+            // (straight: an unsplit product whose consumer wants the combined numerator in the standard layout stores it there itself)
+            const bool straight = !direct && sw == 1 && !keep_slabs && !w_blocked && !w_defer_combine;
+            EpiStore<T> e{(direct || straight) ? numW_p : reg, direct ? Pc : P, w_stride, nullptr};
             if (direct) { e.piece_rows = Pc; e.piece_stride = (int64_t)K * Pc; }
             e.C2 = slabs.p + gram_slab_off; e.ld2 = K; e.stride2 = (int64_t)K * K; e.r_off = 0; e.c_off = P;
             big(sw, e, (double)(P * N + 2 * K * N) * sizeof(T), sg, 2.0 * K * K * N);
+            if (straight) {
+                w_direct = false;
+                reduce_slabs_from("reduce_HHt", gramH_p, slabs.p + gram_slab_off, (int64_t)K * K, pieces, done);
+                w_in_slabs = false;
+                return;
+            }
             }
             w_direct = direct;
             if (w_defer_combine) { w_pieces = pieces; w_in_slabs = false; return; }   // the caller's combine launch sums both

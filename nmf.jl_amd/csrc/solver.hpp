@@ -152,6 +152,8 @@ template <typename T> class Solver : public SolverBase {
         if (const char *e = dev_env("NMFX_CHOL_UNROLLED")) chol_unrolled = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_FUSE_GRAM")) fuse_gram = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_UNSPLIT")) unsplit_enabled = std::atoi(e) != 0;
+        if (const char *e = dev_env("NMFX_DIRECT_MAX_KTILES")) direct_max_ktiles = std::max(32, std::atoi(e));
+        if (const char *e = dev_env("NMFX_DIRECT_LONG")) direct_long_local = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_STOP_SUMS_V1")) stop_sums_v1 = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_PROJALS_XT")) xht_images = std::atoi(e) != 0;
         if (const char *e = dev_env("NMFX_CHOL_UNDER_US")) chol_under_min_us = std::atof(e);
@@ -1161,7 +1163,12 @@ template <typename T> class Solver : public SolverBase {
             // problem, scripts/kbench/gemm_bench.hip: 153 us unsplit on 256 blocks against 150 us 2-way split on 512)
             // (only where it pays: a local contraction of 1024 .. 4096 -- 4 or more ranks at the headline shape -- and enough tiles to
             // give every CU one; longer contractions keep the 2-way split that puts two blocks on a CU)
-            const bool direct = w_defer_combine && w_blocked && N / BK >= 32 && N / BK <= 128 && (K / 128) * (P / 128) >= num_cu;
+            // (round 6: no upper limit on the send-buffer route any more -- one block per CU keeps the matrix pipes as busy as two at a long
+            // contraction too (solver_impl.hpp: iterate), and there is no slab to combine: the 2-rank shard of the headline problem, 256
+            // k-tiles, 1.030 -> 1.008 ms per simulated rank; the peer transport's epilogue, whose blocks store a whole tile into uncached
+            // peer memory, measured SLOWER there, 1.049 -> 1.077 ms, and keeps the limit: profiles/r06_simranks2_unsplit_send_buffer_ab.jsonl)
+            const bool direct = w_defer_combine && w_blocked && N / BK >= 32 && (N / BK <= direct_max_ktiles || (direct_long_local && peer_dst == nullptr)) &&
+                                (K / 128) * (P / 128) >= num_cu;
             const int sw = direct ? 1 : s_w;
             w_nslab = sw; w_stride = (int64_t)P * K;
             const int tiles = (int)((K / 128) * (P / 128));
@@ -1375,6 +1382,8 @@ template <typename T> class Solver : public SolverBase {
     // register-resident one (launch_gemm_cfg); NMFX_CHOL_UNROLLED=0: the rolled loop as before (A/B)
     bool chol_unrolled = true;
     bool stop_sums_v1 = false;            // NMFX_STOP_SUMS_V1=1 (development switch): the first form of the exact stop sums (16 chains per workgroup, a launch per factor)
+    int64_t direct_max_ktiles = 128;      // row-sharded fused step: longest local contraction (in k-tiles) whose X_g H_g' runs unsplit into the PEERS' slots
+    bool direct_long_local = true;        // ... no such limit when it goes into the local send buffer (NMFX_DIRECT_LONG=0: the limit there too)
     bool unsplit_enabled = true;          // NMFX_UNSPLIT=0 (development switch): keep the 2-way split of the big products everywhere (solver_impl.hpp: iterate)
     bool xht_images = true;               // NMFX_PROJALS_XT=0 (development switch): ProjectedALS's XH' under the chain on the row-contiguous kernel (A/B)
     bool defer_pack = false;              // set around the H side's factor_under: spd_factor leaves the pack of the factor to the caller

@@ -60,3 +60,19 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".jl")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "nmf_oracle" not in txt and "c_oracle" not in txt, os.path.join(dp, f)
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """INTEGRATION.md lists every NMFX_* variable the library reads -- the development switches behind NMFX_DEV=1 (csrc/comm.hpp: dev_env)
+    and the user switches read with getenv -- so that a maintainer can tell from the document alone which code paths exist beside the
+    defaults."""
+    csrc = os.path.join(ROOT, "nmf.jl_amd", "csrc")
+    names = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hpp", ".hip")):
+            txt = open(os.path.join(csrc, f), errors="ignore").read()
+            names |= set(re.findall(r'(?:dev_env|getenv)\("(NMFX_[A-Z0-9_]+)"\)', txt))
+    assert len(names) >= 30      # (the pattern still matches the source)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
